@@ -1,0 +1,113 @@
+"""Deterministic synthetic gaussian clouds at the reference's README shapes.
+
+The reference ships no .ply (README.md:103 points at the INRIA downloads), so every benchmark
+and parity test here runs on clouds from this generator: own PRNG (splitmix64, no
+platform-dependent distributions), records laid out exactly like the reference's 336-byte
+`GaussianData` (Engine/Graphics/ShaderStructs.h:59-70) and stored in Morton order like
+`ResourceManager::loadGaussians` leaves them (Engine/ResourceManager.cpp:284-297).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+FLOATS_PER_GAUSSIAN = 84  # 21 x vec4
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_DRAWS_PER_SPLAT = 128
+
+# name -> (num gaussians, width, height, log-scale mean mu).  mu is calibrated (tools/calibrate_mu.py)
+# so that the number of sort elements E matches README.md:61 / :76 within 1 %.
+CONFIGS = {
+    "A": dict(n=100_000, width=640, height=360, mu=-3.48486, seed=20240807 + 0),
+    "B": dict(n=559_263, width=1280, height=720, mu=-3.48486, seed=20240807 + 1),
+    "C": dict(n=5_834_784, width=1920, height=1080, mu=-4.65381, seed=20240807 + 2),
+    "D": dict(n=5_834_784, width=3840, height=2160, mu=-4.65381, seed=20240807 + 2),
+    "E": dict(n=50_000_000, width=1920, height=1080, mu=-6.0, seed=20240807 + 4),
+}
+
+
+def _splitmix64(seed: int, index: np.ndarray) -> np.ndarray:
+    """index-th output (0-based) of a splitmix64 stream started at `seed`."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (index.astype(np.uint64) + np.uint64(1)) * _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _uniform(seed, base, k):
+    """u in [0,1): top 24 bits of draw k of every splat."""
+    return (_splitmix64(seed, base + np.uint64(k)) >> np.uint64(40)).astype(np.float64) * 2.0**-24
+
+
+def _normal(seed, base, k):
+    """Box-Muller on draws k, k+1."""
+    u1 = ((_splitmix64(seed, base + np.uint64(k)) >> np.uint64(40)).astype(np.float64) + 1.0) * 2.0**-24
+    u2 = _uniform(seed, base, k + 1)
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def morton_codes(pos: np.ndarray) -> np.ndarray:
+    """Z-order code per position as ResourceManager.cpp:226-297 computes it (including the
+    `maxPos` initialised with numeric_limits<float>::min(), i.e. the smallest positive float)."""
+    pos = pos.astype(np.float32)
+    min_pos = np.minimum(np.float32(np.finfo(np.float32).max), pos.min(axis=0))
+    max_pos = np.maximum(np.float32(np.finfo(np.float32).tiny), pos.max(axis=0))
+    delta = (max_pos - min_pos).astype(np.float32)
+    m = ((pos - min_pos) / delta * np.float32(1023.0)).astype(np.float32)
+    q = m.astype(np.uint32)  # glm::uvec3(vec3): truncation
+
+    def part(x):
+        x = x & np.uint32(0x3FF)
+        x = (x ^ (x << np.uint32(16))) & np.uint32(0xFF0000FF)
+        x = (x ^ (x << np.uint32(8))) & np.uint32(0x0300F00F)
+        x = (x ^ (x << np.uint32(4))) & np.uint32(0x030C30C3)
+        x = (x ^ (x << np.uint32(2))) & np.uint32(0x09249249)
+        return x
+
+    return (part(q[:, 2]) << np.uint32(2)) + (part(q[:, 1]) << np.uint32(1)) + part(q[:, 0])
+
+
+def generate(n: int, width: int, height: int, mu: float, seed: int, morton: bool = True,
+             chunk: int = 400_000) -> np.ndarray:
+    """Returns float32 [n, 84] records in the reference's AoS layout (already in 'loaded' space:
+    scale exp'd, rotation normalised, opacity sigmoid'd into shCoeffs[0].w)."""
+    aspect = float(width) / float(height)
+    out = np.zeros((n, FLOATS_PER_GAUSSIAN), dtype=np.float32)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        base = np.arange(lo, hi, dtype=np.uint64) * np.uint64(_DRAWS_PER_SPLAT)
+        rec = out[lo:hi]
+        d = 0.5 + 19.5 * _uniform(seed, base, 0)
+        rec[:, 0] = d * aspect * (-1.5 + 3.0 * _uniform(seed, base, 1))
+        rec[:, 1] = d * (-1.5 + 3.0 * _uniform(seed, base, 2))
+        rec[:, 2] = d
+        for a in range(3):
+            rec[:, 4 + a] = np.exp(mu + 0.6 * _normal(seed, base, 3 + 2 * a))
+        q = np.stack([_normal(seed, base, 9 + 2 * a) for a in range(4)], axis=1)
+        q /= np.sqrt((q * q).sum(axis=1, keepdims=True))
+        rec[:, 8:12] = q
+        logit = -2.0 + 6.0 * _uniform(seed, base, 17)
+        for c in range(3):
+            rec[:, 12 + c] = -1.5 + 3.0 * _uniform(seed, base, 18 + c)
+        rec[:, 15] = 1.0 / (1.0 + np.exp(-logit))
+        for k in range(15):
+            for c in range(3):
+                rec[:, 16 + 4 * k + c] = 0.1 * _normal(seed, base, 21 + 2 * (3 * k + c))
+    if morton:
+        order = np.argsort(morton_codes(out[:, 0:3]), kind="stable")
+        out = out[order]
+    return np.ascontiguousarray(out)
+
+
+def generate_config(name: str, n: int | None = None) -> tuple[np.ndarray, dict]:
+    cfg = dict(CONFIGS[name])
+    if n is not None:
+        cfg["n"] = int(n)
+    aos = generate(cfg["n"], cfg["width"], cfg["height"], cfg["mu"], cfg["seed"])
+    return aos, cfg
+
+
+def default_camera(width: int, height: int):
+    """Camera of the synthetic configs: origin, yaw = pitch = 0 => looking down +z
+    (Scenes/TestSortScene.cpp:11-12).  Returns (pos, yaw, pitch, aspect)."""
+    return np.zeros(3, dtype=np.float32), 0.0, 0.0, float(width) / float(height)
