@@ -1,0 +1,193 @@
+/*
+ * gsplat.h -- C-ABI of libgsplat_hip.so, the MI355X-native replacement for the per-frame splat
+ * path of SiTronXD/vk3dGaussianSplatting (InitSortList -> 4-bit radix sort over 64-bit
+ * tile|depth keys -> FindRanges -> RenderGaussians).
+ *
+ * The reference has no FFI: the seam this library replaces is the public surface of its
+ * `Renderer` class plus the `GpuSort` plug-in interface.  Each entry point cites the reference
+ * interface it stands in for; paths are relative to /root/reference/vkGaussianSplatting/.
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes only; every function returns an int status
+ * (0 = GS_OK, > 0 = warning, < 0 = error) and never aborts or throws (the reference reports
+ * errors through a modal MessageBox and continues, Engine/Dev/Log.cpp:40-43); the caller owns
+ * every host pointer for the duration of the call only; the library owns all device memory.
+ * A gs_ctx is bound to one GPU and one HIP stream and is not thread-safe; independent contexts
+ * may be used concurrently.  Matrices are column-major float[16] exactly as glm::mat4 lies in
+ * memory (CamUBO, Engine/Graphics/ShaderStructs.h:37-41).
+ */
+#ifndef GSPLAT_H
+#define GSPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_API_VERSION 1
+
+/* status codes */
+#define GS_OK 0
+#define GS_WARN_OVERFLOW 1      /* more sort elements than capacity; list truncated like InitSortList.comp:140-148 */
+#define GS_ERR_INVALID (-1)     /* bad argument / call order */
+#define GS_ERR_HIP (-2)         /* HIP runtime failure, see gs_last_error */
+#define GS_ERR_NO_SCENE (-3)    /* gs_upload_gaussians / gs_set_resolution not called yet */
+#define GS_ERR_IO (-4)          /* file cannot be opened (ResourceManager.cpp:169-173) */
+#define GS_ERR_FORMAT (-5)      /* .ply header/property problem */
+#define GS_ERR_NO_DEVICE (-6)   /* no usable GPU: the library has NO CPU fallback */
+
+/* The reference's 336-byte record, Engine/Graphics/ShaderStructs.h:59-70:
+ * position.xyz0, scale.xyz0 (already exp'd), rot (permuted unit quaternion, .x scalar part),
+ * shCoeffs[16] ([0].w = sigmoid opacity), color, covariance (scratch, ignored on upload). */
+#define GS_GAUSSIAN_RECORD_BYTES 336u
+
+/* sort back-ends (the GpuSort seam, Engine/Graphics/Sort/GpuSort.h:8-22, selected at compile
+ * time in the reference by GPU_SORT_ALGORITHM, Renderer.h:33) */
+#define GS_SORT_RADIX4 0u       /* the contractual nine-stage 4-bit LSD radix sort */
+
+/* render arithmetic */
+#define GS_RENDER_EXACT 0u      /* bit-identical to the CPU oracle (no contraction, pinned exp) */
+#define GS_RENDER_FAST 1u       /* fused multiply-adds + hardware exp2; <= 1 step per 8-bit channel */
+
+typedef struct gs_ctx gs_ctx;
+
+/* Replaces the compile-time constants of Renderer.h:145-147, RadixSort.h:36-39,
+ * Camera.cpp:4-5 and Resources/Shaders/Common/Common.glsl:2-15. */
+typedef struct gs_config {
+    int32_t device_ordinal;   /* HIP device index */
+    uint32_t tile_size;       /* 16; only 16 is supported (TILE_SIZE) */
+    float near_plane;         /* 0.1f   Camera::NEAR_PLANE */
+    float far_plane;          /* 100.0f Camera::FAR_PLANE */
+    float ndc_cull;           /* 1.3f   CULLING_NDC_LIMIT */
+    float in_view_limit;      /* 0.8f   IN_VIEW_LIMIT */
+    float fov_y;              /* 3.1415f*0.5f FOV_Y (the covariance one, not the projection's) */
+    uint32_t sort_algorithm;  /* GS_SORT_* */
+    uint32_t render_mode;     /* GS_RENDER_* */
+    uint32_t record_timings;  /* 1 = hipEvents at the reference's 7 timestamp points (RECORD_GPU_TIMES, Renderer.h:35) */
+} gs_config;
+
+/* The five buckets of Renderer.cpp:471-475 (ms) + the sort element count ("Elements To Sort"
+ * in README.md:43-93).  InitSortList includes the per-frame clears, RadixSort includes the
+ * IndirectSetup-equivalent, exactly like the reference's timestamp placement (Renderer.cpp:557-622). */
+typedef struct gs_timings {
+    float init_sort_list_ms;
+    float radix_sort_ms;
+    float find_ranges_ms;
+    float render_ms;
+    float total_ms;
+    uint32_t num_sort_elements;   /* min(counter, capacity) */
+    uint32_t overflowed;          /* counter > capacity this frame */
+    uint64_t emitted_elements;    /* un-truncated counter */
+} gs_timings;
+
+/* Scene-derived sizes: Renderer.cpp:696-701 (tiles), :725 (capacity), RadixSort.cpp:203-204 (bits). */
+typedef struct gs_scene_info {
+    uint32_t num_gaussians;
+    uint32_t width, height;
+    uint32_t tiles_x, tiles_y;
+    uint32_t capacity;            /* C = ceilPow2(N + 64*16*T) */
+    uint32_t num_sort_bits;       /* 4 * P */
+    uint32_t row_begin, row_end;  /* tile-row band rendered by this context */
+} gs_scene_info;
+
+/* buffers readable through gs_debug_read (state after the last gs_render*) */
+#define GS_BUF_SORTED_TILE 0   /* uint32[num_sort_elements]  high half of the key   */
+#define GS_BUF_SORTED_DEPTH 1  /* uint32[num_sort_elements]  low half of the key    */
+#define GS_BUF_SORTED_ID 2     /* uint32[num_sort_elements]  gaussian index payload */
+#define GS_BUF_RANGES 3        /* uint32[tiles][2]           {start,end} per tile (GaussianTileRangeData.xy) */
+#define GS_BUF_COLOR 4         /* float[N][4]                GaussianData.color      */
+#define GS_BUF_COV 5           /* float[N][4]                GaussianData.covariance (w = 0) */
+#define GS_BUF_COUNT 6         /* uint64[1]                  un-truncated element counter */
+#define GS_BUF_UNSORTED_TILE 7 /* uint32[num_sort_elements]  list as emitted by InitSortList */
+#define GS_BUF_UNSORTED_DEPTH 8
+#define GS_BUF_UNSORTED_ID 9
+#define GS_BUF_IMAGE 10        /* uint8[H][W][4]             internal framebuffer */
+
+void gs_default_config(gs_config* cfg);
+
+/* Renderer::init (Renderer.cpp:688-694) + GpuSort::singleInitResources (RadixSort.cpp:23-142). */
+int gs_create(const gs_config* cfg, gs_ctx** out);
+/* Renderer::cleanup (Renderer.cpp:230-270) + RadixSort::cleanup (RadixSort.cpp:655-674). */
+int gs_destroy(gs_ctx* ctx);
+/* Text of the last error on ctx (ctx may be NULL: last gs_create failure). Log::error, Dev/Log.cpp:40-43. */
+const char* gs_last_error(const gs_ctx* ctx);
+
+/* Renderer::initForScene, gaussian upload (Renderer.cpp:712-724): n records of
+ * GS_GAUSSIAN_RECORD_BYTES each, as ResourceManager::getGaussians() returns them
+ * (ResourceManager.h:53).  Converted once to the device SoA layout. */
+int gs_upload_gaussians(gs_ctx* ctx, const void* aos336, uint32_t n);
+/* ResourceManager::loadGaussians (ResourceManager.cpp:167-300): binary little-endian .ply with the
+ * INRIA property names -> records (axis flips, exp, quaternion permutation, sigmoid, SH repack,
+ * Morton order) -> upload. */
+int gs_load_ply(gs_ctx* ctx, const char* path);
+/* The same conversion without a context: writes up to max_records records to aos336_out (may be
+ * NULL to query) and the record count to n_out. */
+int gs_convert_ply(const char* path, void* aos336_out, uint32_t max_records, uint32_t* n_out);
+/* Text of the last gs_load_ply / gs_convert_ply failure on this thread (happly throws instead,
+ * happly.h:1089-1094). */
+const char* gs_ply_last_error(void);
+
+/* Swapchain extent -> tile grid, list capacity and pass count (Renderer.cpp:696-701, 725-755;
+ * RadixSort::initForScene, RadixSort.cpp:144-205).  Must follow gs_upload_gaussians. */
+int gs_set_resolution(gs_ctx* ctx, uint32_t width, uint32_t height);
+/* Multi-GPU extension (no reference counterpart): this context emits/sorts/renders only tile rows
+ * [row_begin,row_end) with GLOBAL tile ids, so keys, per-tile order and pixels equal the 1-GPU
+ * result.  Default after gs_set_resolution: all rows. */
+int gs_set_tile_rows(gs_ctx* ctx, uint32_t row_begin, uint32_t row_end);
+int gs_get_scene_info(const gs_ctx* ctx, gs_scene_info* out);
+
+/* Renderer::draw (Renderer.cpp:297-515): updateUniformBuffer(view, proj) (:531-538), the push
+ * constants of Subrenderer.cpp:152-160 (camPos, shMode as an INTEGER 0/1/2), then the recorded
+ * frame (:540-629).  rgba_out: height*width*4 bytes on the HOST, row-major, top row first,
+ * R,G,B,A with A = 255 (the R8G8B8A8_UNORM storage image of Swapchain.cpp:27).  Synchronous. */
+int gs_render(gs_ctx* ctx, const float view[16], const float proj[16], const float cam_pos[3],
+              uint32_t sh_mode, uint8_t* rgba_out);
+/* Same frame, image left in HBM: rgba_out_device is a DEVICE pointer of height*width*4 bytes
+ * (e.g. a torch tensor's data_ptr) or NULL for the internal framebuffer (GS_BUF_IMAGE).
+ * Enqueued on the context's stream; returns after the frame has completed (timings valid). */
+int gs_render_device(gs_ctx* ctx, const float view[16], const float proj[16],
+                     const float cam_pos[3], uint32_t sh_mode, void* rgba_out_device);
+/* As gs_render_device but returns right after enqueueing (no host sync, timings not updated):
+ * the CPU never waits on the GPU inside a frame, like the reference's single vkQueueSubmit. */
+int gs_render_device_async(gs_ctx* ctx, const float view[16], const float proj[16],
+                           const float cam_pos[3], uint32_t sh_mode, void* rgba_out_device);
+/* Wait for everything enqueued on the context's stream (vkDeviceWaitIdle, Renderer.cpp:459). */
+int gs_synchronize(gs_ctx* ctx);
+
+/* computeDiffs buckets of the last synchronous frame (Renderer.cpp:463-475). */
+int gs_get_timings(const gs_ctx* ctx, gs_timings* out);
+
+/* No reference counterpart (its buffers are only visible in a GPU debugger): copies one device
+ * buffer of the last frame to dst; bytes must not exceed the buffer's size. */
+int gs_debug_read(gs_ctx* ctx, int which, void* dst, size_t bytes);
+
+/* Runs ONLY the InitSortList stage of a frame (project + count scan + emit) and waits; afterwards
+ * GS_BUF_UNSORTED_*, GS_BUF_COLOR, GS_BUF_COV and GS_BUF_COUNT are readable (stage-level parity). */
+int gs_debug_init_sort_list(gs_ctx* ctx, const float view[16], const float proj[16],
+                            const float cam_pos[3], uint32_t sh_mode);
+
+/* Use a caller-owned hipStream_t (passed as void*) instead of the context's own stream. */
+int gs_set_stream(gs_ctx* ctx, void* hip_stream);
+
+/* Camera::updateDirVectors + updateMatrices (Engine/Graphics/Camera.cpp:7-48): yaw/pitch/position
+ * -> view (glm::lookAt) and proj (glm::perspective(radians(90), aspect, near, far), depth 0..1). */
+int gs_camera_matrices(const float pos[3], float yaw, float pitch, float aspect, float near_plane,
+                       float far_plane, float view_out[16], float proj_out[16]);
+
+/* GpuSort seam used stand-alone (GpuSort.h:8-22: initForScene + gpuClearBuffers + computeSort on
+ * caller data): sorts n (tile, depth, id) triples held in HOST arrays, stable, by the low
+ * num_sort_bits of (tile<<32 | depth), with the same kernels the frame uses.  In place. */
+int gs_sort_host(gs_ctx* ctx, uint32_t* tile, uint32_t* depth, uint32_t* id, uint32_t n,
+                 uint32_t num_sort_bits);
+/* Stress run for the sorter alone (BASELINE config E): n random triples generated on the device
+ * (seeded), sorted `iters` times; returns the mean milliseconds of one full sort and verifies
+ * sortedness on the device (sorted_ok = 1). */
+int gs_sort_bench(gs_ctx* ctx, uint32_t n, uint32_t num_tiles, uint32_t iters, uint64_t seed,
+                  float* ms_per_sort, uint32_t* sorted_ok);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_H */

@@ -1,0 +1,16 @@
+"""vk3dgaussiansplatting_amd -- MI355X-native drop-in for the per-frame splat path of
+SiTronXD/vk3dGaussianSplatting (InitSortList -> radix sort -> FindRanges -> RenderGaussians).
+
+Only what that path needs lives here: csrc/ (HIP kernels + the C-ABI of include/gsplat.h),
+the host-side mirror of the reference's Renderer/Camera/ResourceManager/GpuSort interface,
+the synthetic cloud generator used by tests and bench, and the multi-GPU tile-row sharding.
+"""
+from . import _lib
+from ._lib import (GS_OK, GS_WARN_OVERFLOW, GS_RENDER_EXACT, GS_RENDER_FAST, GsplatLibraryMissing,
+                   BUF_SORTED_TILE, BUF_SORTED_DEPTH, BUF_SORTED_ID, BUF_RANGES, BUF_COLOR, BUF_COV,
+                   BUF_COUNT, BUF_UNSORTED_TILE, BUF_UNSORTED_DEPTH, BUF_UNSORTED_ID, BUF_IMAGE)
+from .renderer import (Camera, GpuSort, GsplatError, PlyScene, RadixSort, Renderer, ResourceManager,
+                       Scene, SimpleTestGaussiansScene, SphericalHarmonicsMode, TestSortScene,
+                       makeGaussian)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

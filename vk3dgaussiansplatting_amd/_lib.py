@@ -1,0 +1,140 @@
+"""ctypes loader for the in-tree libgsplat_hip.so (C-ABI in include/gsplat.h).
+
+The product path has no CPU fallback: if the HIP library is missing or cannot be loaded this
+module raises; it never imports anything from oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgsplat_hip.so")
+
+GS_OK = 0
+GS_WARN_OVERFLOW = 1
+GS_ERR_INVALID = -1
+GS_ERR_HIP = -2
+GS_ERR_NO_SCENE = -3
+GS_ERR_IO = -4
+GS_ERR_FORMAT = -5
+GS_ERR_NO_DEVICE = -6
+
+GS_RENDER_EXACT = 0
+GS_RENDER_FAST = 1
+GS_SORT_RADIX4 = 0
+
+(BUF_SORTED_TILE, BUF_SORTED_DEPTH, BUF_SORTED_ID, BUF_RANGES, BUF_COLOR, BUF_COV, BUF_COUNT,
+ BUF_UNSORTED_TILE, BUF_UNSORTED_DEPTH, BUF_UNSORTED_ID, BUF_IMAGE) = range(11)
+
+RECORD_BYTES = 336
+
+
+class GsConfig(C.Structure):
+    _fields_ = [
+        ("device_ordinal", C.c_int32),
+        ("tile_size", C.c_uint32),
+        ("near_plane", C.c_float),
+        ("far_plane", C.c_float),
+        ("ndc_cull", C.c_float),
+        ("in_view_limit", C.c_float),
+        ("fov_y", C.c_float),
+        ("sort_algorithm", C.c_uint32),
+        ("render_mode", C.c_uint32),
+        ("record_timings", C.c_uint32),
+    ]
+
+
+class GsTimings(C.Structure):
+    _fields_ = [
+        ("init_sort_list_ms", C.c_float),
+        ("radix_sort_ms", C.c_float),
+        ("find_ranges_ms", C.c_float),
+        ("render_ms", C.c_float),
+        ("total_ms", C.c_float),
+        ("num_sort_elements", C.c_uint32),
+        ("overflowed", C.c_uint32),
+        ("emitted_elements", C.c_uint64),
+    ]
+
+
+class GsSceneInfo(C.Structure):
+    _fields_ = [
+        ("num_gaussians", C.c_uint32),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("tiles_x", C.c_uint32),
+        ("tiles_y", C.c_uint32),
+        ("capacity", C.c_uint32),
+        ("num_sort_bits", C.c_uint32),
+        ("row_begin", C.c_uint32),
+        ("row_end", C.c_uint32),
+    ]
+
+
+# every symbol include/gsplat.h declares (tests check the .so exports exactly these)
+EXPORTS = [
+    "gs_default_config", "gs_create", "gs_destroy", "gs_last_error", "gs_upload_gaussians",
+    "gs_load_ply", "gs_convert_ply", "gs_ply_last_error", "gs_set_resolution", "gs_set_tile_rows",
+    "gs_get_scene_info", "gs_render", "gs_render_device", "gs_render_device_async",
+    "gs_synchronize", "gs_get_timings", "gs_debug_read", "gs_debug_init_sort_list",
+    "gs_set_stream", "gs_camera_matrices", "gs_sort_host", "gs_sort_bench",
+]
+
+
+class GsplatLibraryMissing(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of the library, in-tree (make -C csrc)."""
+    args = ["make", "-C", CSRC, "-j8"]
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(args, check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GsplatLibraryMissing(
+            f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, f32 = C.c_void_p, C.c_uint32, C.c_float
+    ctxp = C.c_void_p
+    L.gs_default_config.argtypes = [C.POINTER(GsConfig)]
+    L.gs_default_config.restype = None
+    L.gs_create.argtypes = [C.POINTER(GsConfig), C.POINTER(ctxp)]
+    L.gs_destroy.argtypes = [ctxp]
+    L.gs_last_error.argtypes = [ctxp]
+    L.gs_last_error.restype = C.c_char_p
+    L.gs_upload_gaussians.argtypes = [ctxp, vp, u32]
+    L.gs_load_ply.argtypes = [ctxp, C.c_char_p]
+    L.gs_convert_ply.argtypes = [C.c_char_p, vp, u32, C.POINTER(u32)]
+    L.gs_ply_last_error.argtypes = []
+    L.gs_ply_last_error.restype = C.c_char_p
+    L.gs_set_resolution.argtypes = [ctxp, u32, u32]
+    L.gs_set_tile_rows.argtypes = [ctxp, u32, u32]
+    L.gs_get_scene_info.argtypes = [ctxp, C.POINTER(GsSceneInfo)]
+    L.gs_render.argtypes = [ctxp, vp, vp, vp, u32, vp]
+    L.gs_render_device.argtypes = [ctxp, vp, vp, vp, u32, vp]
+    L.gs_render_device_async.argtypes = [ctxp, vp, vp, vp, u32, vp]
+    L.gs_synchronize.argtypes = [ctxp]
+    L.gs_get_timings.argtypes = [ctxp, C.POINTER(GsTimings)]
+    L.gs_debug_read.argtypes = [ctxp, C.c_int, vp, C.c_size_t]
+    L.gs_debug_init_sort_list.argtypes = [ctxp, vp, vp, vp, u32]
+    L.gs_set_stream.argtypes = [ctxp, vp]
+    L.gs_camera_matrices.argtypes = [vp, f32, f32, f32, f32, f32, vp, vp]
+    L.gs_sort_host.argtypes = [ctxp, vp, vp, vp, u32, u32]
+    L.gs_sort_bench.argtypes = [ctxp, u32, u32, u32, C.c_uint64, C.POINTER(f32), C.POINTER(u32)]
+    _lib = L
+    return L

@@ -1,0 +1,589 @@
+// gs_api.cpp -- host side of libgsplat_hip.so: the C-ABI of include/gsplat.h over the HIP kernels.
+// Mirrors the reference's frame orchestration (Engine/Graphics/Renderer.cpp, Subrenderer.cpp,
+// Sort/RadixSort.cpp) with HIP streams/events in place of Vulkan command buffers/timestamps.
+// There is NO CPU fallback: without a GPU every entry point that computes fails with
+// GS_ERR_NO_DEVICE / GS_ERR_HIP.
+#include "../../include/gsplat.h"
+#include "gs_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace gs;
+
+static thread_local std::string g_create_error;
+
+struct gs_ctx {
+    gs_config cfg{};
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[7] = {};
+    std::string last_error;
+
+    // scene
+    uint32_t n = 0;
+    SceneBuffers scene{};
+    SplatScratch scratch{};
+    uint32_t num_blocks = 0;
+
+    // resolution-dependent
+    uint32_t width = 0, height = 0, grid_w = 0, grid_h = 0;
+    uint32_t row_begin = 0, row_end = 0;
+    uint32_t capacity = 0, num_sort_bits = 0;
+    SortBuffers sort{};
+    uint32_t* ranges = nullptr;
+    uint8_t* framebuffer = nullptr;
+    int sorted_index = 0;       // which ping-pong half holds the sorted list after the last frame
+
+    gs_timings timings{};
+    bool have_frame = false;
+    bool unsorted_valid = false;   // last thing run was gs_debug_init_sort_list
+};
+
+namespace {
+
+int fail(gs_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->last_error = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail((ctx), GS_ERR_HIP,                                                       \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                      \
+    } while (0)
+
+template <typename T>
+void free_dev(T*& p) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+void free_scene(gs_ctx* c) {
+    free_dev(c->scene.pos); free_dev(c->scene.scale); free_dev(c->scene.rot);
+    free_dev(c->scene.sh); free_dev(c->scene.opacity);
+    free_dev(c->scratch.raster); free_dev(c->scratch.depth_key); free_dev(c->scratch.tiles_touched);
+    free_dev(c->scratch.extents); free_dev(c->scratch.block_sums); free_dev(c->scratch.block_offsets);
+    c->n = 0;
+}
+
+void free_sort(SortBuffers& s) {
+    for (int k = 0; k < 2; ++k) { free_dev(s.lo[k]); free_dev(s.hi[k]); free_dev(s.id[k]); }
+    free_dev(s.table); free_dev(s.seg_sum); free_dev(s.params);
+}
+
+void free_resolution(gs_ctx* c) {
+    free_sort(c->sort);
+    free_dev(c->ranges); free_dev(c->framebuffer);
+    c->capacity = 0; c->width = c->height = 0;
+    c->have_frame = false;
+}
+
+// Renderer.cpp:703-710
+uint32_t ceil_pow2(uint32_t x) { uint32_t v = 1; while (v < x) v *= 2; return v; }
+
+// RadixSort.cpp:7-16 + 203-204
+uint32_t num_sort_bits_for(uint32_t num_tiles) {
+    uint32_t x = num_tiles - 1u, bits = 0;
+    for (int i = 31; i >= 0; --i) if ((x >> i) & 1u) { bits = (uint32_t)i + 1u; break; }
+    return ((32u + bits + kRadixBits - 1u) / kRadixBits) * kRadixBits;
+}
+
+int alloc_sort(gs_ctx* ctx, SortBuffers& s, uint32_t capacity) {
+    const size_t bytes = (size_t)capacity * sizeof(uint32_t);
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(ctx, hipMalloc((void**)&s.lo[k], bytes));
+        HIP_TRY(ctx, hipMalloc((void**)&s.hi[k], bytes));
+        HIP_TRY(ctx, hipMalloc((void**)&s.id[k], bytes));
+    }
+    const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
+    const uint32_t max_segments = (max_groups + kSegGroups - 1) / kSegGroups;
+    HIP_TRY(ctx, hipMalloc((void**)&s.table, (size_t)kBins * max_groups * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&s.seg_sum, (size_t)16 * kBins * max_segments * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&s.params, sizeof(SortParams)));
+    HIP_TRY(ctx, hipMemset(s.params, 0, sizeof(SortParams)));
+    return GS_OK;
+}
+
+int check_launch(gs_ctx* ctx, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, GS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return GS_OK;
+}
+
+FrameParams make_frame_params(const gs_ctx* c, const float* view, const float* proj,
+                              const float* cam_pos, uint32_t sh_mode) {
+    FrameParams fp{};
+    std::memcpy(fp.view, view, sizeof(fp.view));
+    std::memcpy(fp.proj, proj, sizeof(fp.proj));
+    std::memcpy(fp.cam_pos, cam_pos, sizeof(fp.cam_pos));
+    fp.sh_mode = sh_mode;
+    fp.width = c->width; fp.height = c->height;
+    fp.grid_w = c->grid_w; fp.grid_h = c->grid_h;
+    fp.row_begin = c->row_begin; fp.row_end = c->row_end;
+    fp.num_gaussians = c->n;
+    fp.capacity = c->capacity;
+    fp.near_plane = c->cfg.near_plane; fp.far_plane = c->cfg.far_plane;
+    fp.ndc_cull = c->cfg.ndc_cull; fp.in_view_limit = c->cfg.in_view_limit;
+    fp.tan_fov_y = (float)std::tan((double)(c->cfg.fov_y * 0.5f));   // Common.glsl:53, host-folded
+    return fp;
+}
+
+// Renderer::recordCommandBuffer (Renderer.cpp:540-629): stage order + the 7 timestamp points.
+int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* cam_pos,
+                  uint32_t sh_mode, uint8_t* out_dev) {
+    if (!c->n) return fail(c, GS_ERR_NO_SCENE, "gs_render: no gaussians uploaded");
+    if (!c->capacity) return fail(c, GS_ERR_NO_SCENE, "gs_render: gs_set_resolution not called");
+    if (!view || !proj || !cam_pos) return fail(c, GS_ERR_INVALID, "gs_render: null camera argument");
+    if (sh_mode > 2u) return fail(c, GS_ERR_INVALID, "gs_render: sh_mode must be 0, 1 or 2");
+    const FrameParams fp = make_frame_params(c, view, proj, cam_pos, sh_mode);
+    const bool tm = c->cfg.record_timings != 0;
+    hipStream_t st = c->stream;
+
+    c->unsorted_valid = false;
+    if (tm) { HIP_TRY(c, hipEventRecord(c->ev[0], st)); HIP_TRY(c, hipEventRecord(c->ev[1], st)); }
+    // computeInitSortList (Subrenderer.cpp:37-170): per-frame resets, then the dispatch.  Only the
+    // ranges need clearing here: the 0xFF sentinel fill of both lists (Subrenderer.cpp:42-46,
+    // RadixSort.cpp:676-692) is unobservable once every later stage runs over E instead of C.
+    HIP_TRY(c, hipMemsetAsync(c->ranges, 0, (size_t)c->grid_w * c->grid_h * 2 * sizeof(uint32_t), st));
+    launch_project(fp, c->scene, c->scratch, st);
+    launch_scan_blocks(fp, c->scratch, c->sort.params, st);
+    launch_emit(fp, c->scratch, c->sort, st);
+    if (int r = check_launch(c, "InitSortList")) return r;
+    if (tm) HIP_TRY(c, hipEventRecord(c->ev[2], st));
+    // gpuSort->computeSort (RadixSort.cpp:207-653)
+    c->sorted_index = launch_radix_sort(c->sort, c->capacity, c->num_sort_bits, st);
+    if (int r = check_launch(c, "RadixSort")) return r;
+    if (tm) HIP_TRY(c, hipEventRecord(c->ev[3], st));
+    // computeRanges (Subrenderer.cpp:172-216)
+    launch_find_ranges(c->sort.hi[c->sorted_index], c->sort.params, c->capacity, c->ranges, st);
+    if (int r = check_launch(c, "FindRanges")) return r;
+    if (tm) HIP_TRY(c, hipEventRecord(c->ev[4], st));
+    // computeRenderGaussians (Subrenderer.cpp:218-346)
+    launch_render(fp, c->scratch.raster, c->sort.id[c->sorted_index], c->ranges,
+                  out_dev ? out_dev : c->framebuffer, c->cfg.render_mode, st);
+    if (int r = check_launch(c, "RenderGaussians")) return r;
+    if (tm) { HIP_TRY(c, hipEventRecord(c->ev[5], st)); HIP_TRY(c, hipEventRecord(c->ev[6], st)); }
+    c->have_frame = true;
+    return GS_OK;
+}
+
+// Renderer.cpp:458-475: wait, read the timestamps, compute the five buckets.
+int finish_frame(gs_ctx* c) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    SortParams sp{};
+    HIP_TRY(c, hipMemcpy(&sp, c->sort.params, sizeof(sp), hipMemcpyDeviceToHost));
+    gs_timings t{};
+    if (c->cfg.record_timings) {
+        HIP_TRY(c, hipEventElapsedTime(&t.init_sort_list_ms, c->ev[1], c->ev[2]));
+        HIP_TRY(c, hipEventElapsedTime(&t.radix_sort_ms, c->ev[2], c->ev[3]));
+        HIP_TRY(c, hipEventElapsedTime(&t.find_ranges_ms, c->ev[3], c->ev[4]));
+        HIP_TRY(c, hipEventElapsedTime(&t.render_ms, c->ev[4], c->ev[5]));
+        HIP_TRY(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[6]));
+    }
+    t.num_sort_elements = sp.num_elems;
+    t.overflowed = sp.overflow;
+    t.emitted_elements = sp.counter;
+    c->timings = t;
+    return sp.overflow ? GS_WARN_OVERFLOW : GS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void gs_default_config(gs_config* cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->device_ordinal = 0;
+    cfg->tile_size = 16;            // Renderer.h:146
+    cfg->near_plane = 0.1f;         // Camera.cpp:4
+    cfg->far_plane = 100.0f;        // Camera.cpp:5
+    cfg->ndc_cull = 1.3f;           // Common.glsl:5
+    cfg->in_view_limit = 0.8f;      // Common.glsl:9
+    cfg->fov_y = 3.1415f * 0.5f;    // Common.glsl:2
+    cfg->sort_algorithm = GS_SORT_RADIX4;
+    cfg->render_mode = GS_RENDER_EXACT;
+    cfg->record_timings = 1;
+}
+
+int gs_create(const gs_config* cfg_in, gs_ctx** out) {
+    if (!out) return fail(nullptr, GS_ERR_INVALID, "gs_create: out is null");
+    *out = nullptr;
+    gs_config cfg;
+    if (cfg_in) cfg = *cfg_in; else gs_default_config(&cfg);
+    if (cfg.tile_size != 16) return fail(nullptr, GS_ERR_INVALID, "gs_create: only tile_size 16 is supported");
+    if (cfg.sort_algorithm != GS_SORT_RADIX4) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown sort_algorithm");
+    if (cfg.render_mode > GS_RENDER_FAST) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown render_mode");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, GS_ERR_NO_DEVICE,
+                    "gs_create: no HIP device available (this library has no CPU fallback)");
+    if (cfg.device_ordinal < 0 || cfg.device_ordinal >= count)
+        return fail(nullptr, GS_ERR_INVALID, "gs_create: device_ordinal out of range");
+    gs_ctx* c = new (std::nothrow) gs_ctx();
+    if (!c) return fail(nullptr, GS_ERR_INVALID, "gs_create: out of host memory");
+    c->cfg = cfg;
+    c->device = cfg.device_ordinal;
+    if ((e = hipSetDevice(c->device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        std::string msg = std::string("gs_create: ") + hipGetErrorString(e);
+        delete c;
+        return fail(nullptr, GS_ERR_HIP, msg);
+    }
+    c->stream = c->own_stream;
+    for (auto& ev : c->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) {
+            std::string msg = std::string("gs_create: ") + hipGetErrorString(e);
+            gs_destroy(c);
+            return fail(nullptr, GS_ERR_HIP, msg);
+        }
+    *out = c;
+    return GS_OK;
+}
+
+int gs_destroy(gs_ctx* c) {
+    if (!c) return GS_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_resolution(c);
+    free_scene(c);
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return GS_OK;
+}
+
+const char* gs_last_error(const gs_ctx* c) { return c ? c->last_error.c_str() : g_create_error.c_str(); }
+
+int gs_set_stream(gs_ctx* c, void* hip_stream) {
+    if (!c) return GS_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return GS_OK;
+}
+
+int gs_upload_gaussians(gs_ctx* c, const void* aos336, uint32_t n) {
+    if (!c) return GS_ERR_INVALID;
+    if (!aos336 || n == 0) return fail(c, GS_ERR_INVALID, "gs_upload_gaussians: empty input");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_resolution(c);   // capacity depends on n (Renderer.cpp:725)
+    free_scene(c);
+    const size_t N = n;
+    HIP_TRY(c, hipMalloc((void**)&c->scene.pos, 3 * N * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->scene.scale, 3 * N * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->scene.rot, 4 * N * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->scene.sh, 48 * N * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->scene.opacity, N * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.raster, N * sizeof(SplatRaster)));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.depth_key, N * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.tiles_touched, N * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.extents, N * sizeof(uint2)));
+    c->num_blocks = (n + kProjThreads - 1) / kProjThreads;
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.block_sums, (size_t)c->num_blocks * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.block_offsets, (size_t)c->num_blocks * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->scratch.raster, 0, N * sizeof(SplatRaster), c->stream));
+
+    // AoS -> SoA on the device, through a bounded staging buffer
+    const uint32_t chunk = n < (1u << 20) ? n : (1u << 20);
+    float* staging = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&staging, (size_t)chunk * GS_GAUSSIAN_RECORD_BYTES));
+    const char* src = static_cast<const char*>(aos336);
+    int rc = GS_OK;
+    for (uint32_t first = 0; first < n && rc == GS_OK; first += chunk) {
+        const uint32_t cnt = (n - first) < chunk ? (n - first) : chunk;
+        hipError_t e = hipMemcpyAsync(staging, src + (size_t)first * GS_GAUSSIAN_RECORD_BYTES,
+                                      (size_t)cnt * GS_GAUSSIAN_RECORD_BYTES, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            launch_aos_to_soa(staging, first, cnt, n, c->scene, c->stream);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // staging is reused
+        if (e != hipSuccess) rc = fail(c, GS_ERR_HIP, std::string("gs_upload_gaussians: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(staging);
+    if (rc != GS_OK) { free_scene(c); return rc; }
+    c->n = n;
+    return GS_OK;
+}
+
+int gs_set_resolution(gs_ctx* c, uint32_t width, uint32_t height) {
+    if (!c) return GS_ERR_INVALID;
+    if (!c->n) return fail(c, GS_ERR_NO_SCENE, "gs_set_resolution: upload gaussians first");
+    if (width == 0 || height == 0 || width > 65535u * 16u || height > 65535u * 16u)
+        return fail(c, GS_ERR_INVALID, "gs_set_resolution: bad extent");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_resolution(c);
+    const uint32_t gw = (width + kTile - 1) / kTile, gh = (height + kTile - 1) / kTile; // Renderer.cpp:696-701
+    const uint64_t want = (uint64_t)c->n + 64ull * 16ull * gw * gh;                       // Renderer.cpp:725
+    if (want > (1ull << 31)) return fail(c, GS_ERR_INVALID, "gs_set_resolution: sort list would exceed 2^31 elements");
+    c->width = width; c->height = height; c->grid_w = gw; c->grid_h = gh;
+    c->row_begin = 0; c->row_end = gh;
+    c->capacity = ceil_pow2((uint32_t)want);
+    c->num_sort_bits = num_sort_bits_for(gw * gh);
+    int rc = alloc_sort(c, c->sort, c->capacity);
+    if (rc != GS_OK) { free_resolution(c); return rc; }
+    HIP_TRY(c, hipMalloc((void**)&c->ranges, (size_t)gw * gh * 2 * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->framebuffer, (size_t)width * height * 4));
+    HIP_TRY(c, hipMemset(c->ranges, 0, (size_t)gw * gh * 2 * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemset(c->framebuffer, 0, (size_t)width * height * 4));
+    return GS_OK;
+}
+
+int gs_set_tile_rows(gs_ctx* c, uint32_t row_begin, uint32_t row_end) {
+    if (!c) return GS_ERR_INVALID;
+    if (!c->capacity) return fail(c, GS_ERR_NO_SCENE, "gs_set_tile_rows: gs_set_resolution not called");
+    if (row_begin > row_end || row_end > c->grid_h)
+        return fail(c, GS_ERR_INVALID, "gs_set_tile_rows: need row_begin <= row_end <= tiles_y");
+    c->row_begin = row_begin; c->row_end = row_end;
+    return GS_OK;
+}
+
+int gs_get_scene_info(const gs_ctx* c, gs_scene_info* out) {
+    if (!c || !out) return GS_ERR_INVALID;
+    out->num_gaussians = c->n;
+    out->width = c->width; out->height = c->height;
+    out->tiles_x = c->grid_w; out->tiles_y = c->grid_h;
+    out->capacity = c->capacity; out->num_sort_bits = c->num_sort_bits;
+    out->row_begin = c->row_begin; out->row_end = c->row_end;
+    return GS_OK;
+}
+
+int gs_render_device_async(gs_ctx* c, const float view[16], const float proj[16],
+                           const float cam_pos[3], uint32_t sh_mode, void* rgba_out_device) {
+    if (!c) return GS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return enqueue_frame(c, view, proj, cam_pos, sh_mode, static_cast<uint8_t*>(rgba_out_device));
+}
+
+int gs_render_device(gs_ctx* c, const float view[16], const float proj[16], const float cam_pos[3],
+                     uint32_t sh_mode, void* rgba_out_device) {
+    int rc = gs_render_device_async(c, view, proj, cam_pos, sh_mode, rgba_out_device);
+    if (rc != GS_OK) return rc;
+    return finish_frame(c);
+}
+
+int gs_render(gs_ctx* c, const float view[16], const float proj[16], const float cam_pos[3],
+              uint32_t sh_mode, uint8_t* rgba_out) {
+    if (!c) return GS_ERR_INVALID;
+    if (!rgba_out) return fail(c, GS_ERR_INVALID, "gs_render: rgba_out is null");
+    int rc = gs_render_device_async(c, view, proj, cam_pos, sh_mode, nullptr);
+    if (rc != GS_OK) return rc;
+    rc = finish_frame(c);
+    if (rc < 0) return rc;
+    HIP_TRY(c, hipMemcpy(rgba_out, c->framebuffer, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost));
+    return rc;
+}
+
+int gs_debug_init_sort_list(gs_ctx* c, const float view[16], const float proj[16],
+                            const float cam_pos[3], uint32_t sh_mode) {
+    if (!c) return GS_ERR_INVALID;
+    if (!c->n || !c->capacity) return fail(c, GS_ERR_NO_SCENE, "gs_debug_init_sort_list: scene/resolution not set");
+    if (!view || !proj || !cam_pos || sh_mode > 2u) return fail(c, GS_ERR_INVALID, "gs_debug_init_sort_list: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const FrameParams fp = make_frame_params(c, view, proj, cam_pos, sh_mode);
+    launch_project(fp, c->scene, c->scratch, c->stream);
+    launch_scan_blocks(fp, c->scratch, c->sort.params, c->stream);
+    launch_emit(fp, c->scratch, c->sort, c->stream);
+    if (int r = check_launch(c, "InitSortList")) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->have_frame = false;
+    c->unsorted_valid = true;
+    SortParams sp{};
+    HIP_TRY(c, hipMemcpy(&sp, c->sort.params, sizeof(sp), hipMemcpyDeviceToHost));
+    return sp.overflow ? GS_WARN_OVERFLOW : GS_OK;
+}
+
+int gs_synchronize(gs_ctx* c) {
+    if (!c) return GS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+int gs_get_timings(const gs_ctx* c, gs_timings* out) {
+    if (!c || !out) return GS_ERR_INVALID;
+    *out = c->timings;
+    return GS_OK;
+}
+
+int gs_debug_read(gs_ctx* c, int which, void* dst, size_t bytes) {
+    if (!c || !dst) return GS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!c->have_frame && !c->unsorted_valid && which != GS_BUF_IMAGE) return fail(c, GS_ERR_NO_SCENE, "gs_debug_read: no frame rendered yet");
+    SortParams sp{};
+    HIP_TRY(c, hipMemcpy(&sp, c->sort.params, sizeof(sp), hipMemcpyDeviceToHost));
+    const size_t e_bytes = (size_t)sp.num_elems * sizeof(uint32_t);
+    const void* src = nullptr;
+    size_t avail = 0;
+    const int si = c->sorted_index;
+    switch (which) {
+        case GS_BUF_SORTED_TILE: src = c->sort.hi[si]; avail = e_bytes; break;
+        case GS_BUF_SORTED_DEPTH: src = c->sort.lo[si]; avail = e_bytes; break;
+        case GS_BUF_SORTED_ID: src = c->sort.id[si]; avail = e_bytes; break;
+        case GS_BUF_RANGES: src = c->ranges; avail = (size_t)c->grid_w * c->grid_h * 8; break;
+        case GS_BUF_COUNT: {
+            if (bytes > sizeof(uint64_t)) return fail(c, GS_ERR_INVALID, "gs_debug_read: size");
+            std::memcpy(dst, &sp.counter, bytes);
+            return GS_OK;
+        }
+        case GS_BUF_IMAGE: src = c->framebuffer; avail = (size_t)c->width * c->height * 4; break;
+        case GS_BUF_UNSORTED_TILE:
+        case GS_BUF_UNSORTED_DEPTH:
+        case GS_BUF_UNSORTED_ID:
+            // the list as emitted lives in ping-pong half 0 and is overwritten by the second pass
+            if (!c->unsorted_valid)
+                return fail(c, GS_ERR_INVALID, "gs_debug_read: unsorted list only valid after gs_debug_init_sort_list");
+            src = which == GS_BUF_UNSORTED_TILE ? c->sort.hi[0] : which == GS_BUF_UNSORTED_DEPTH ? c->sort.lo[0] : c->sort.id[0];
+            avail = e_bytes;
+            break;
+        case GS_BUF_COLOR:
+        case GS_BUF_COV: {
+            const size_t need = (size_t)c->n * 4 * sizeof(float);
+            if (bytes > need) return fail(c, GS_ERR_INVALID, "gs_debug_read: size exceeds buffer");
+            std::vector<SplatRaster> host(c->n);
+            HIP_TRY(c, hipMemcpy(host.data(), c->scratch.raster, (size_t)c->n * sizeof(SplatRaster), hipMemcpyDeviceToHost));
+            std::vector<float> outv((size_t)c->n * 4);
+            for (uint32_t i = 0; i < c->n; ++i) {
+                const SplatRaster& r = host[i];
+                float* o = &outv[(size_t)i * 4];
+                if (which == GS_BUF_COLOR) { o[0] = r.r; o[1] = r.g; o[2] = r.b; o[3] = r.a; }
+                else { o[0] = r.cx; o[1] = r.cy; o[2] = r.cz; o[3] = 0.0f; }
+            }
+            std::memcpy(dst, outv.data(), bytes);
+            return GS_OK;
+        }
+        default: return fail(c, GS_ERR_INVALID, "gs_debug_read: unknown buffer id");
+    }
+    if (bytes > avail) return fail(c, GS_ERR_INVALID, "gs_debug_read: size exceeds buffer");
+    if (bytes) HIP_TRY(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return GS_OK;
+}
+
+// Camera.cpp:7-48 over the glm 0.9.9.8 formulas (lookAtRH, perspectiveRH_ZO, normalize, cross).
+int gs_camera_matrices(const float pos[3], float yaw, float pitch, float aspect, float near_plane,
+                       float far_plane, float view[16], float proj[16]) {
+    if (!pos || !view || !proj) return GS_ERR_INVALID;
+    auto normalize3 = [](float v[3]) {
+        const float d = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        const float inv = 1.0f / std::sqrt(d);
+        v[0] *= inv; v[1] *= inv; v[2] *= inv;
+    };
+    auto cross3 = [](const float a[3], const float b[3], float o[3]) {
+        o[0] = a[1] * b[2] - b[1] * a[2];
+        o[1] = a[2] * b[0] - b[2] * a[0];
+        o[2] = a[0] * b[1] - b[0] * a[1];
+    };
+    auto dot3 = [](const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    float fwd[3] = {(float)(std::sin((double)yaw) * std::cos((double)pitch)), (float)std::sin((double)pitch),
+                    (float)(std::cos((double)yaw) * std::cos((double)pitch))};   // Camera.cpp:10-16
+    normalize3(fwd);
+    const float up[3] = {0.0f, 1.0f, 0.0f};
+    const float center[3] = {pos[0] + fwd[0], pos[1] + fwd[1], pos[2] + fwd[2]}; // Camera.cpp:34-38
+    float f[3] = {center[0] - pos[0], center[1] - pos[1], center[2] - pos[2]};
+    normalize3(f);
+    float s[3], u[3];
+    cross3(f, up, s);
+    normalize3(s);
+    cross3(s, f, u);
+    std::memset(view, 0, 16 * sizeof(float));
+    view[0] = s[0]; view[4] = s[1]; view[8] = s[2];
+    view[1] = u[0]; view[5] = u[1]; view[9] = u[2];
+    view[2] = -f[0]; view[6] = -f[1]; view[10] = -f[2];
+    view[12] = -dot3(s, pos); view[13] = -dot3(u, pos); view[14] = dot3(f, pos);
+    view[15] = 1.0f;
+    const float fovy = 90.0f * 0.01745329251994329576923690768489f;                // Camera.cpp:42
+    const float tan_half = std::tan(fovy / 2.0f);
+    std::memset(proj, 0, 16 * sizeof(float));
+    proj[0] = 1.0f / (aspect * tan_half);
+    proj[5] = 1.0f / tan_half;
+    proj[10] = far_plane / (near_plane - far_plane);
+    proj[11] = -1.0f;
+    proj[14] = -(far_plane * near_plane) / (far_plane - near_plane);
+    return GS_OK;
+}
+
+int gs_sort_host(gs_ctx* c, uint32_t* tile, uint32_t* depth, uint32_t* id, uint32_t n,
+                 uint32_t num_sort_bits) {
+    if (!c || !tile || !depth || !id) return GS_ERR_INVALID;
+    if (num_sort_bits == 0 || num_sort_bits > 64 || (num_sort_bits % kRadixBits) != 0)
+        return fail(c, GS_ERR_INVALID, "gs_sort_host: num_sort_bits must be a multiple of 4 in [4,64]");
+    if (n == 0) return GS_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    SortBuffers sb{};
+    int rc = alloc_sort(c, sb, n);
+    if (rc != GS_OK) { free_sort(sb); return rc; }
+    const size_t bytes = (size_t)n * sizeof(uint32_t);
+    hipError_t e = hipMemcpyAsync(sb.hi[0], tile, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sb.lo[0], depth, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sb.id[0], id, bytes, hipMemcpyHostToDevice, c->stream);
+    int si = 0;
+    if (e == hipSuccess) {
+        launch_set_sort_params(sb.params, n, c->stream);
+        si = launch_radix_sort(sb, n, num_sort_bits, c->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(tile, sb.hi[si], bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(depth, sb.lo[si], bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(id, sb.id[si], bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    free_sort(sb);
+    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_sort_host: ") + hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_sort_bench(gs_ctx* c, uint32_t n, uint32_t num_tiles, uint32_t iters, uint64_t seed,
+                  float* ms_per_sort, uint32_t* sorted_ok) {
+    if (!c || !ms_per_sort || n == 0 || num_tiles == 0 || iters == 0) return GS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    SortBuffers sb{};
+    int rc = alloc_sort(c, sb, n);
+    if (rc != GS_OK) { free_sort(sb); return rc; }
+    const uint32_t bits = num_sort_bits_for(num_tiles);
+    uint32_t* bad = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void**)&bad, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float total_ms = 0.0f;
+    int si = 0;
+    for (uint32_t it = 0; it < iters + 1 && e == hipSuccess; ++it) {   // iteration 0 = warm-up
+        launch_fill_random_keys(sb.lo[0], sb.hi[0], sb.id[0], n, num_tiles, seed + it, c->stream);
+        launch_set_sort_params(sb.params, n, c->stream);
+        e = hipEventRecord(e0, c->stream);
+        if (e != hipSuccess) break;
+        si = launch_radix_sort(sb, n, bits, c->stream);
+        e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (it > 0) total_ms += ms;
+    }
+    uint32_t bad_host = 0;
+    if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) {
+        launch_check_sorted(sb.lo[si], sb.hi[si], n, bad, c->stream);
+        e = hipMemcpyAsync(&bad_host, bad, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (bad) (void)hipFree(bad);
+    free_sort(sb);
+    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_sort_bench: ") + hipGetErrorString(e));
+    *ms_per_sort = total_ms / (float)iters;
+    if (sorted_ok) *sorted_ok = bad_host == 0 ? 1u : 0u;
+    return GS_OK;
+}
+
+} // extern "C"

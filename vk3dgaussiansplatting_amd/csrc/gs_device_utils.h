@@ -1,0 +1,71 @@
+// gs_device_utils.h -- wave64 / workgroup primitives for gfx950.  Wave width is hard-coded to 64.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gs {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// number of set bits of `mask` below this lane (v_mbcnt_lo/hi)
+__device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v; // every lane holds the sum
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint64_t wave_inclusive_scan64(uint64_t v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t lo = __shfl_up((uint32_t)v, off, 64);
+        uint32_t hi = __shfl_up((uint32_t)(v >> 32), off, 64);
+        uint64_t t = ((uint64_t)hi << 32) | lo;
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// GLSL clamp(x, lo, hi) = min(max(x, lo), hi) with the comparison forms the oracle uses.
+__device__ __forceinline__ float clampf(float x, float lo, float hi) {
+    float t = x > lo ? x : lo;
+    return t < hi ? t : hi;
+}
+__device__ __forceinline__ float maxf(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ int clampi(int x, int lo, int hi) {
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+
+// GLSL int(float) / uint(float): truncate, saturate, NaN -> 0 (what v_cvt_i32_f32 / v_cvt_u32_f32 do;
+// written out so the result does not depend on the compiler's treatment of out-of-range casts).
+__device__ __forceinline__ int f2i_sat(float x) {
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)x;
+}
+__device__ __forceinline__ uint32_t f2u_sat(float x) {
+    if (x != x) return 0u;
+    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+    if (x <= 0.0f) return 0u;
+    return (uint32_t)x;
+}
+
+} // namespace gs

@@ -1,0 +1,116 @@
+// gs_internal.h -- shared between the HIP kernels and the C-ABI host code of libgsplat_hip.so.
+// gfx950 (MI355X / CDNA4) only: wave64, no other targets, no compatibility paths.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gs {
+
+constexpr int kWave = 64;
+constexpr int kTile = 16;              // TILE_SIZE, Common.glsl:12 / Renderer.h:146
+constexpr int kRadixBits = 4;          // RS_BITS_PER_PASS, RadixSort.h:36
+constexpr int kBins = 1 << kRadixBits; // RS_BIN_COUNT
+
+// ---- radix-sort tiling -------------------------------------------------------------------
+// One workgroup (256 threads = 4 waves) owns kSortTile consecutive keys of the current pass.
+// The reference uses 64 keys per group (RS_WORK_GROUP_SIZE, RadixSort.h:38); a 4096-key tile
+// shrinks the histogram table 64x and makes every global access of a pass a >= 256-byte run.
+constexpr int kSortThreads = 256;
+constexpr int kSortKeysPerThread = 16;
+constexpr int kSortTile = kSortThreads * kSortKeysPerThread; // 4096 keys
+constexpr int kSegGroups = 64;         // groups per reduce segment (one wave-load of the table)
+
+// ---- InitSortList tiling -----------------------------------------------------------------
+constexpr int kProjThreads = 256;      // splats per workgroup in project + emit
+
+// Per-frame constants: CamUBO (ShaderStructs.h:37-41) + InitSortListPCD (7-12) + the shader
+// #defines of Common.glsl:2-15.  Passed by value as a kernel argument.
+struct FrameParams {
+    float view[16];       // column-major
+    float proj[16];
+    float cam_pos[3];
+    uint32_t sh_mode;     // integer, not float
+    uint32_t width, height;
+    uint32_t grid_w, grid_h;
+    uint32_t row_begin, row_end;  // tile-row band of this context
+    uint32_t num_gaussians;
+    uint32_t capacity;
+    float near_plane, far_plane;
+    float ndc_cull, in_view_limit;
+    float tan_fov_y;      // tan(FOV_Y*0.5f), folded on the host (Common.glsl:53)
+};
+
+// Device-side dispatch record: the role of RadixIndirectDispatch (ShaderStructs.h:45-57) +
+// GaussianCullData (77-82).  Written by the scan kernel (IndirectSetup-equivalent), read by every
+// later kernel, so the host never reads the element count back inside a frame.
+struct SortParams {
+    uint32_t num_elems;      // E' = min(counter, capacity)   (RadixSortIndirectSetup.comp:28)
+    uint32_t num_groups;     // G  = ceil(E' / kSortTile)     (countSizeX)
+    uint32_t num_segments;   // S  = ceil(G / kSegGroups)     (reduceSizeX / 16)
+    uint32_t overflow;       // counter > capacity
+    uint64_t counter;        // un-truncated atomic-counter equivalent
+    uint32_t pad[2];
+};
+
+// What RenderGaussians needs per splat, written once by the project kernel (the reference keeps
+// color/covariance in the 336-byte record and recomputes the screen position per tile,
+// RenderGaussians.comp:88-107; the expressions and operand order are the same).  48 B, 16-aligned.
+struct alignas(16) SplatRaster {
+    float sx, sy;        // getScreenSpacePosition(...).xy
+    float cx, cy, cz;    // GaussianData.covariance.xyz (raw, +0.3 dilation applied)
+    float r, g, b, a;    // GaussianData.color
+    float pad[3];
+};
+static_assert(sizeof(SplatRaster) == 48, "SplatRaster must be 48 bytes");
+
+// Device SoA image of the scene (converted once at upload from the 336-byte AoS records).
+struct SceneBuffers {
+    float* pos;      // [3][N] planes
+    float* scale;    // [3][N]
+    float* rot;      // [4][N]
+    float* sh;       // [48][N], plane index = coeff*3 + channel
+    float* opacity;  // [N]   shCoeffs[0].w
+};
+
+// Per-splat scratch of one frame.
+struct SplatScratch {
+    SplatRaster* raster;     // [N]
+    uint32_t* depth_key;     // [N]
+    uint32_t* tiles_touched; // [N]  0 for culled / zero-extent splats
+    uint2* extents;          // [N]  packed u16: .x = minx | miny<<16, .y = maxx | maxy<<16 (row-clamped)
+    uint32_t* block_sums;    // [ceil(N/kProjThreads)]  tile counts per project workgroup
+    uint32_t* block_offsets; // same size, exclusive scan
+};
+
+struct SortBuffers {
+    uint32_t *lo[2], *hi[2], *id[2]; // ping-pong: depth word, tile word, gaussian index; [capacity]
+    uint32_t* table;                 // [16][G_max]  per-group digit counts (sumTable)
+    uint32_t* seg_sum;               // [passes][16][S_max]  per-segment digit counts (reduce buffer)
+    SortParams* params;
+};
+
+// ---- launchers (each enqueues on `stream`, no host sync) ------------------------------------
+void launch_project(const FrameParams& fp, const SceneBuffers& scene, const SplatScratch& sc,
+                    hipStream_t stream);
+void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParams* params,
+                        hipStream_t stream);
+void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb,
+                 hipStream_t stream);
+// Sorts buffers [0] -> result index returned (0 or 1) after num_sort_bits/4 passes.
+int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
+                      hipStream_t stream);
+void launch_find_ranges(const uint32_t* sorted_tile, const SortParams* params, uint32_t capacity,
+                        uint32_t* ranges, hipStream_t stream);
+void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
+                   const uint32_t* ranges, uint8_t* rgba, uint32_t render_mode, hipStream_t stream);
+void launch_aos_to_soa(const float* chunk, uint32_t first, uint32_t count, uint32_t n,
+                       const SceneBuffers& s, hipStream_t stream);
+// helpers for the stand-alone sorter entry points
+void launch_set_sort_params(SortParams* params, uint32_t n, hipStream_t stream);
+void launch_fill_random_keys(uint32_t* lo, uint32_t* hi, uint32_t* id, uint32_t n,
+                             uint32_t num_tiles, uint64_t seed, hipStream_t stream);
+void launch_check_sorted(const uint32_t* lo, const uint32_t* hi, uint32_t n, uint32_t* bad_count,
+                         hipStream_t stream);
+
+} // namespace gs

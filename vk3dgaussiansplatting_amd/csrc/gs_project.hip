@@ -1,0 +1,386 @@
+// gs_project.hip -- InitSortList for gfx950, as three kernels:
+//   k_project     : cull -> view/proj transform -> 2D covariance -> tile bbox -> SH colour
+//                   (InitSortList.comp:82-127 + Common.glsl:17-170), one splat per lane, SoA loads
+//   k_scan_blocks : exclusive scan of the per-workgroup tile counts + the IndirectSetup record
+//                   (replaces the contended global atomicAdd of InitSortList.comp:131 and
+//                   RadixSortIndirectSetup.comp:25-37)
+//   k_emit        : one (tile, depth, id) element per overlapped tile (InitSortList.comp:132-150),
+//                   load-balanced over OUTPUT elements, in the canonical deterministic order
+//                   "ascending splat index, then row-major tile".
+// Arithmetic follows the reference expression by expression, left to right, with contraction off
+// (build flag -ffp-contract=off), IEEE division and sqrt: sort keys and tile extents are bit-exact
+// against oracle/gs_oracle.c.  Paths are relative to /root/reference/vkGaussianSplatting/Resources/Shaders/.
+#include "gs_device_utils.h"
+#include "gs_internal.h"
+
+namespace gs {
+
+struct Mat3 { float m[3][3]; }; // column-major m[col][row], like GLSL mat3x3
+
+// C = A*B, C[j][i] = (A[0][i]*B[j][0] + A[1][i]*B[j][1]) + A[2][i]*B[j][2]
+__device__ __forceinline__ Mat3 mat3_mul(const Mat3& a, const Mat3& b) {
+    Mat3 c;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float acc = a.m[0][i] * b.m[j][0];
+            acc = acc + a.m[1][i] * b.m[j][1];
+            acc = acc + a.m[2][i] * b.m[j][2];
+            c.m[j][i] = acc;
+        }
+    return c;
+}
+__device__ __forceinline__ Mat3 mat3_transpose(const Mat3& a) {
+    Mat3 t;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t.m[j][i] = a.m[i][j];
+    return t;
+}
+
+// GLSL `M * v`, M column-major: ((M[0]*v.x + M[1]*v.y) + M[2]*v.z) + M[3]*v.w
+__device__ __forceinline__ void mat4_mul_vec4(const float* m, float vx, float vy, float vz,
+                                              float vw, float out[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float acc = m[0 * 4 + r] * vx;
+        acc = acc + m[1 * 4 + r] * vy;
+        acc = acc + m[2 * 4 + r] * vz;
+        acc = acc + m[3 * 4 + r] * vw;
+        out[r] = acc;
+    }
+}
+
+// Common/Common.glsl:17-30 (column-major constructor: col0, col1, col2)
+__device__ __forceinline__ Mat3 get_rot_mat(float r, float x, float y, float z) {
+    Mat3 m;
+    m.m[0][0] = 1.0f - 2.0f * y * y - 2.0f * z * z;
+    m.m[0][1] = 2.0f * x * y - 2.0f * r * z;
+    m.m[0][2] = 2.0f * x * z + 2.0f * r * y;
+    m.m[1][0] = 2.0f * x * y + 2.0f * r * z;
+    m.m[1][1] = 1.0f - 2.0f * x * x - 2.0f * z * z;
+    m.m[1][2] = 2.0f * y * z - 2.0f * r * x;
+    m.m[2][0] = 2.0f * x * z - 2.0f * r * y;
+    m.m[2][1] = 2.0f * y * z + 2.0f * r * x;
+    m.m[2][2] = 1.0f - 2.0f * x * x - 2.0f * y * y;
+    return m;
+}
+
+// Common/Common.glsl:32-78
+__device__ __forceinline__ void get_covariance(const FrameParams& fp, const float scale[3],
+                                               const float rot[4], const float pv_in[4],
+                                               float cov[3]) {
+    const float width = (float)fp.width, height = (float)fp.height;
+    float pv[3] = {pv_in[0], pv_in[1], pv_in[2]};
+
+    Mat3 rot_mat = get_rot_mat(rot[0], rot[1], rot[2], rot[3]);
+    Mat3 scale_mat;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) scale_mat.m[j][i] = (i == j) ? scale[i] : 0.0f;
+    Mat3 rs = mat3_mul(rot_mat, scale_mat);
+    Mat3 sigma = mat3_mul(rs, mat3_transpose(rs));
+
+    Mat3 w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) w.m[c][r] = fp.view[c * 4 + r];
+
+    const float tan_fov_y = fp.tan_fov_y;
+    const float tan_fov_x = tan_fov_y * width / height;
+    const float focal_x = width / (2.0f * tan_fov_x);
+    const float focal_y = height / (2.0f * tan_fov_y);
+
+    const float lim_x = tan_fov_x * fp.in_view_limit;
+    const float lim_y = tan_fov_y * fp.in_view_limit;
+    const float temp_x = pv[0] / pv[2];
+    const float temp_y = pv[1] / pv[2];
+    pv[0] = clampf(temp_x, -lim_x, lim_x) * pv[2];
+    pv[1] = clampf(temp_y, -lim_y, lim_y) * pv[2];
+
+    Mat3 j;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) j.m[c][r] = 0.0f;
+    j.m[0][0] = focal_x / pv[2];
+    j.m[1][1] = focal_y / pv[2];
+    j.m[2][0] = -(focal_x * pv[0]) / (pv[2] * pv[2]);
+    j.m[2][1] = -(focal_y * pv[1]) / (pv[2] * pv[2]);
+    Mat3 jw = mat3_mul(j, w);
+    Mat3 tmp = mat3_mul(jw, sigma);
+    Mat3 sp = mat3_mul(tmp, mat3_transpose(jw));
+
+    cov[0] = sp.m[0][0];
+    cov[1] = sp.m[0][1];
+    cov[2] = sp.m[1][1];
+    cov[0] += 0.3f;
+    cov[2] += 0.3f;
+}
+
+// Common/Common.glsl:94-138
+__device__ __forceinline__ void sh_eval4(float dx, float dy, float dz, float sh[16]) {
+    const float fX = -dx, fY = -dy, fZ = dz;
+    float fC0, fC1, fS0, fS1, fTmpA, fTmpB, fTmpC;
+    const float fZ2 = fZ * fZ;
+    sh[0] = 0.2820947917738781f;
+    sh[2] = 0.4886025119029199f * fZ;
+    sh[6] = 0.9461746957575601f * fZ2 + -0.31539156525252f;
+    sh[12] = fZ * (1.865881662950577f * fZ2 + -1.119528997770346f);
+    fC0 = fX;
+    fS0 = fY;
+    fTmpA = -0.48860251190292f;
+    sh[3] = fTmpA * fC0;
+    sh[1] = fTmpA * fS0;
+    fTmpB = -1.092548430592079f * fZ;
+    sh[7] = fTmpB * fC0;
+    sh[5] = fTmpB * fS0;
+    fTmpC = -2.285228997322329f * fZ2 + 0.4570457994644658f;
+    sh[13] = fTmpC * fC0;
+    sh[11] = fTmpC * fS0;
+    fC1 = fX * fC0 - fY * fS0;
+    fS1 = fX * fS0 + fY * fC0;
+    fTmpA = 0.5462742152960395f;
+    sh[8] = fTmpA * fC1;
+    sh[4] = fTmpA * fS1;
+    fTmpB = 1.445305721320277f * fZ;
+    sh[14] = fTmpB * fC1;
+    sh[10] = fTmpB * fS1;
+    fC0 = fX * fC1 - fY * fS1;
+    fS0 = fX * fS1 + fY * fC1;
+    fTmpC = -0.5900435899266435f;
+    sh[15] = fTmpC * fC0;
+    sh[9] = fTmpC * fS0;
+}
+
+__global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
+                                                           const SceneBuffers scene,
+                                                           const SplatScratch sc) {
+    __shared__ uint32_t s_wave_sum[kProjThreads / 64];
+    const uint32_t n = fp.num_gaussians;
+    const uint32_t g = blockIdx.x * kProjThreads + threadIdx.x;
+    uint32_t count = 0;
+
+    if (g < n) {
+        const float px = scene.pos[g], py = scene.pos[(size_t)n + g], pz = scene.pos[2 * (size_t)n + g];
+        float vp[4];
+        mat4_mul_vec4(fp.view, px, py, pz, 1.0f, vp);                 // InitSortList.comp:93
+        if (!(-vp[2] <= fp.near_plane)) {                            // :94
+            float q[4];
+            mat4_mul_vec4(fp.proj, vp[0], vp[1], vp[2], vp[3], q);    // :98
+            const float ndc_x = q[0] / q[3];                          // :99
+            const float ndc_y = q[1] / q[3];
+            if (!(fabsf(ndc_x) > fp.ndc_cull || fabsf(ndc_y) > fp.ndc_cull)) { // :100
+                // getDepthKey, :70-80 (float(MAX_UINT32) == 2^32)
+                float nd = (-vp[2] - fp.near_plane) / (fp.far_plane - fp.near_plane);
+                nd = clampf(nd, 0.0f, 1.0f);
+                const uint32_t depth_key = f2u_sat(nd * 4294967296.0f);
+
+                float scale[3], rot[4], cov[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) scale[a] = scene.scale[a * (size_t)n + g];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) rot[a] = scene.rot[a * (size_t)n + g];
+                get_covariance(fp, scale, rot, vp, cov);              // :113-120
+
+                // getScreenSpacePosition, Common.glsl:80-89 (same proj*viewPos and division as above)
+                float sx = ndc_x, sy = -ndc_y;
+                sx = (sx + 1.0f) * 0.5f;
+                sy = (sy + 1.0f) * 0.5f;
+                sx = sx * (float)fp.width;
+                sy = sy * (float)fp.height;
+
+                // getGaussianTileExtents, InitSortList.comp:47-68
+                const float det = cov[0] * cov[2] - cov[1] * cov[1];
+                const float m = (cov[0] + cov[2]) * 0.5f;
+                const float lambda0 = m + sqrtf(maxf(m * m - det, 0.0f));
+                const float lambda1 = m - sqrtf(maxf(m * m - det, 0.0f));
+                const float radius = ceilf(3.0f * sqrtf(maxf(lambda0, lambda1)));
+                const int gw = (int)fp.grid_w, gh = (int)fp.grid_h;
+                const int min_x = clampi(f2i_sat((sx - radius) / 16.0f), 0, gw);
+                const int min_y = clampi(f2i_sat((sy - radius) / 16.0f), 0, gh);
+                int tx = f2i_sat((sx + radius) / 16.0f);
+                int ty = f2i_sat((sy + radius) / 16.0f);
+                const int max_x = clampi(tx == 2147483647 ? tx : tx + 1, 0, gw);
+                const int max_y = clampi(ty == 2147483647 ? ty : ty + 1, 0, gh);
+
+                // colour, InitSortList.comp:124-126 + Common.glsl:141-170
+                const float ddx = px - fp.cam_pos[0], ddy = py - fp.cam_pos[1], ddz = pz - fp.cam_pos[2];
+                const float len = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+                float basis[16];
+                sh_eval4(ddx / len, ddy / len, ddz / len, basis);
+                float res[3] = {0.0f, 0.0f, 0.0f};
+                const float* shp = scene.sh + g;
+                if (fp.sh_mode == 0u) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            res[c] = res[c] + shp[(size_t)(i * 3 + c) * n] * basis[i];
+                } else if (fp.sh_mode == 1u) {
+#pragma unroll
+                    for (int i = 1; i < 16; ++i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            res[c] = res[c] + shp[(size_t)(i * 3 + c) * n] * basis[i];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) res[c] = res[c] - 0.5f;
+                } else if (fp.sh_mode == 2u) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) res[c] = res[c] + shp[(size_t)c * n] * basis[0];
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    res[c] = res[c] + 0.5f;
+                    res[c] = maxf(res[c], 0.0f);
+                }
+
+                // :126-127 stored for every non-culled splat, even with zero tiles (N6)
+                float4* rp = reinterpret_cast<float4*>(sc.raster + g);
+                rp[0] = make_float4(sx, sy, cov[0], cov[1]);
+                rp[1] = make_float4(cov[2], res[0], res[1], res[2]);
+                rp[2] = make_float4(scene.opacity[g], 0.0f, 0.0f, 0.0f);
+
+                // tile-row band of this context (multi-GPU); identity for [0, grid_h)
+                int y0 = min_y > (int)fp.row_begin ? min_y : (int)fp.row_begin;
+                int y1 = max_y < (int)fp.row_end ? max_y : (int)fp.row_end;
+                if (y1 < y0) y1 = y0;
+                count = (uint32_t)(max_x - min_x) * (uint32_t)(y1 - y0);   // :130
+                sc.depth_key[g] = depth_key;
+                sc.extents[g] = make_uint2((uint32_t)min_x | ((uint32_t)y0 << 16),
+                                           (uint32_t)max_x | ((uint32_t)y1 << 16));
+            }
+        }
+        sc.tiles_touched[g] = count;
+    }
+
+    // per-workgroup total -> block_sums (input of the scan that replaces the atomic counter)
+    const uint32_t wsum = wave_reduce_add(count);
+    if (lane_id() == 0) s_wave_sum[wave_id()] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kProjThreads / 64; ++w) t += s_wave_sum[w];
+        sc.block_sums[blockIdx.x] = t;
+    }
+}
+
+// One workgroup of 1024 threads: exclusive scan of block_sums (u64 running total so an overflowing
+// scene is still counted correctly), then the IndirectSetup record.
+__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict__ block_sums,
+                                                       uint32_t* __restrict__ block_offsets,
+                                                       uint32_t num_blocks, uint32_t capacity,
+                                                       SortParams* params) {
+    __shared__ uint64_t s_wave_tot[16];
+    __shared__ uint64_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    // rows of 1024 consecutive entries: coalesced loads, carry propagated row to row
+    for (uint32_t base = 0; base < num_blocks; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint64_t v = i < num_blocks ? block_sums[i] : 0u;
+        const uint64_t inc = wave_inclusive_scan64(v);
+        if (lane == 63) s_wave_tot[wave] = inc;
+        __syncthreads();
+        uint64_t wave_base = 0;
+        for (int w = 0; w < wave; ++w) wave_base += s_wave_tot[w];
+        const uint64_t carry = s_carry;
+        const uint64_t excl = carry + wave_base + inc - v;
+        if (i < num_blocks) block_offsets[i] = (uint32_t)(excl > 0xFFFFFFFFull ? 0xFFFFFFFFull : excl);
+        __syncthreads();
+        if (tid == 1023) s_carry = excl + v;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint64_t counter = s_carry;
+        const uint32_t e = counter < capacity ? (uint32_t)counter : capacity; // IndirectSetup.comp:28
+        params->counter = counter;
+        params->num_elems = e;
+        params->num_groups = (e + kSortTile - 1) / kSortTile;
+        params->num_segments = (params->num_groups + kSegGroups - 1) / kSegGroups;
+        params->overflow = counter > capacity ? 1u : 0u;
+    }
+}
+
+// Emit: workgroup b owns splats [b*256, b*256+256) and therefore output elements
+// [block_offsets[b], +block_sums[b]).  Threads walk the OUTPUT range (coalesced stores) and find
+// their splat by binary search in the LDS scan of the 256 tile counts.
+__global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, const SplatScratch sc,
+                                                        uint32_t* __restrict__ out_lo,
+                                                        uint32_t* __restrict__ out_hi,
+                                                        uint32_t* __restrict__ out_id) {
+    __shared__ uint32_t s_incl[kProjThreads];   // inclusive scan of tile counts
+    __shared__ uint32_t s_wave_tot[kProjThreads / 64];
+    const uint32_t n = fp.num_gaussians;
+    const uint32_t total = sc.block_sums[blockIdx.x];
+    if (total == 0) return;
+    const uint32_t base = sc.block_offsets[blockIdx.x];
+    if (base >= fp.capacity) return;             // whole block dropped (overflow, :143)
+    const int tid = threadIdx.x;
+    const uint32_t g = blockIdx.x * kProjThreads + tid;
+    const uint32_t cnt = g < n ? sc.tiles_touched[g] : 0u;
+    const uint32_t inc = wave_inclusive_scan(cnt);
+    if (lane_id() == 63) s_wave_tot[wave_id()] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave_id(); ++w) wbase += s_wave_tot[w];
+    s_incl[tid] = wbase + inc;
+    __syncthreads();
+
+    const uint32_t g0 = blockIdx.x * kProjThreads;
+    for (uint32_t j = tid; j < total; j += kProjThreads) {
+        // smallest s with s_incl[s] > j
+        int lo = 0, hi = kProjThreads - 1;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int mid = (lo + hi) >> 1;
+            if (s_incl[mid] > j) hi = mid; else lo = mid + 1;
+        }
+        const int s = lo;
+        const uint32_t excl = s > 0 ? s_incl[s - 1] : 0u;
+        const uint32_t id_local = j - excl;
+        const uint32_t gi = g0 + (uint32_t)s;
+        const uint2 ext = sc.extents[gi];
+        const uint32_t min_x = ext.x & 0xFFFFu, y0 = ext.x >> 16, max_x = ext.y & 0xFFFFu;
+        const uint32_t wdt = max_x - min_x;
+        const uint32_t ry = id_local / wdt;
+        const uint32_t rx = id_local - ry * wdt;
+        const uint32_t tile_key = (y0 + ry) * fp.grid_w + (min_x + rx);  // :137
+        const uint64_t out = (uint64_t)base + j;
+        if (out < fp.capacity) {                                          // :143
+            out_hi[out] = tile_key;
+            out_lo[out] = sc.depth_key[gi];
+            out_id[out] = gi;
+        }
+    }
+}
+
+void launch_project(const FrameParams& fp, const SceneBuffers& scene, const SplatScratch& sc,
+                    hipStream_t stream) {
+    const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_project, dim3(blocks), dim3(kProjThreads), 0, stream, fp, scene, sc);
+}
+
+void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParams* params,
+                        hipStream_t stream) {
+    const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, sc.block_sums,
+                       sc.block_offsets, blocks, fp.capacity, params);
+}
+
+void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb,
+                 hipStream_t stream) {
+    const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(kProjThreads), 0, stream, fp, sc, sb.lo[0],
+                       sb.hi[0], sb.id[0]);
+}
+
+} // namespace gs

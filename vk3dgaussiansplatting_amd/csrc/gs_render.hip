@@ -1,0 +1,237 @@
+// gs_render.hip -- FindRanges and RenderGaussians for gfx950.
+//
+// k_find_ranges: FindRanges.comp:42-71, launched over the E valid elements instead of the list
+//   capacity (the reference runs 2^24 threads in 16-wide groups over mostly 0xFFFFFFFF sentinels,
+//   Subrenderer.cpp:205-215); last end = E (differs from the reference only when the list
+//   overflowed, quirk Q1 in SURVEY.md).
+// k_render: RenderGaussians.comp:56-152.  One wave64 per 16x16 tile, four horizontally adjacent
+//   pixels per lane, so: no workgroup barriers (the wave is the workgroup), the staged splat is
+//   read from LDS once per four pixels, one 16-byte RGBA8 store per lane, and a wave vote gives the
+//   whole-tile early-out the reference lacks (its `done` only zeroes `limit`, :111).  The splat
+//   batch (64 per wave) is gathered through the sorted id list from the 48-byte SplatRaster
+//   records and prefetched one batch ahead of the blend loop.
+// GS_RENDER_EXACT evaluates every expression in the reference's order without contraction and with
+// the pinned exp of oracle/gs_oracle.h => pixels bit-identical to the CPU oracle.
+// GS_RENDER_FAST uses fused multiply-adds and the hardware exp2 (what a GLSL compiler is free to
+// emit for the same source); <= 1 step per 8-bit channel against the oracle.
+#include "gs_device_utils.h"
+#include "gs_internal.h"
+
+namespace gs {
+
+__global__ __launch_bounds__(256) void k_find_ranges(const uint32_t* __restrict__ tile,
+                                                      const SortParams* __restrict__ params,
+                                                      uint32_t* __restrict__ ranges) {
+    const uint32_t e = params->num_elems;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < e; i += gridDim.x * blockDim.x) {
+        const uint32_t t = tile[i];
+        if (i == 0) {
+            ranges[t * 2 + 0] = 0;                      // FindRanges.comp:59-64
+        } else {
+            const uint32_t p = tile[i - 1];
+            if (p != t) {                               // :48-58
+                ranges[p * 2 + 1] = i;
+                ranges[t * 2 + 0] = i;
+            }
+        }
+        if (i == e - 1) ranges[t * 2 + 1] = e;          // end of the last tile = E
+    }
+}
+
+// pinned exp: identical operation sequence to gso_exp() in oracle/gs_oracle.c
+__device__ __forceinline__ float exp_pinned(float x) {
+    float t = x * 0x1.715476p+0f;
+    t = t > -126.0f ? t : -126.0f;
+    t = t < 126.0f ? t : 126.0f;
+    const float n = __builtin_rintf(t);
+    const float r = t - n;
+    float p = 0x1.42059ap-13f;
+    p = __builtin_fmaf(p, r, 0x1.5f3e12p-10f);
+    p = __builtin_fmaf(p, r, 0x1.3b2d40p-7f);
+    p = __builtin_fmaf(p, r, 0x1.c6aeeap-5f);
+    p = __builtin_fmaf(p, r, 0x1.ebfbdcp-3f);
+    p = __builtin_fmaf(p, r, 0x1.62e430p-1f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    return __builtin_ldexpf(p, (int)n);
+}
+
+struct Fetched {
+    float4 a, b, c;   // raw SplatRaster
+    bool valid;
+};
+
+__device__ __forceinline__ Fetched fetch_splat(const SplatRaster* __restrict__ raster,
+                                               const uint32_t* __restrict__ sorted_id,
+                                               uint32_t idx, uint32_t end) {
+    Fetched f;
+    f.valid = idx < end;
+    if (f.valid) {
+        const uint32_t gi = sorted_id[idx];                            // RenderGaussians.comp:88
+        const float4* rp = reinterpret_cast<const float4*>(raster + gi);
+        f.a = rp[0];
+        f.b = rp[1];
+        f.c = rp[2];
+    } else {
+        f.a = f.b = f.c = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return f;
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(64) void k_render(const FrameParams fp,
+                                                const SplatRaster* __restrict__ raster,
+                                                const uint32_t* __restrict__ sorted_id,
+                                                const uint32_t* __restrict__ ranges,
+                                                uint32_t* __restrict__ rgba) {
+    // LDS image of the current batch: {sx, sy, inv.x, inv.y}, {inv.z, r, g, b}, {a, -, -, -}
+    __shared__ float4 s_batch[64][3];
+
+    const int lane = threadIdx.x;
+    const uint32_t tile_in_band = blockIdx.x;
+    const uint32_t ty = fp.row_begin + tile_in_band / fp.grid_w;
+    const uint32_t tx = tile_in_band % fp.grid_w;
+    const uint32_t tile_index = ty * fp.grid_w + tx;                   // :74-76
+    const uint32_t start = ranges[tile_index * 2 + 0];                 // :77
+    const uint32_t end = ranges[tile_index * 2 + 1];
+
+    const uint32_t py = ty * kTile + (uint32_t)(lane >> 2);
+    const uint32_t px0 = tx * kTile + (uint32_t)(lane & 3) * 4u;
+    const float fpy = (float)py;                                       // integer pixel coords (R1)
+    float fpx[4];
+    float col[4][3];
+    float T[4];
+    bool done[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        fpx[k] = (float)(px0 + k);
+        col[k][0] = col[k][1] = col[k][2] = 0.0f;
+        T[k] = 1.0f;
+        done[k] = !(px0 + k < fp.width && py < fp.height);             // never stored (:147)
+    }
+
+    Fetched nxt = fetch_splat(raster, sorted_id, start + lane, end);
+    for (uint32_t i = start; i < end; i += 64) {                       // :81
+        const uint32_t n = (end - i) < 64u ? (end - i) : 64u;
+        if (nxt.valid) {                                               // :86-108
+            const float cx = nxt.a.z, cy = nxt.a.w, cz = nxt.b.x;
+            float alpha0 = nxt.c.x;
+            const float det = cx * cz - cy * cy;                       // :96
+            float ix = 0.0f, iy = 0.0f, iz = 0.0f;
+            if (det != 0.0f) {
+                const float det_inv = 1.0f / det;                      // :99
+                ix = cz * det_inv;                                     // :100
+                iy = -cy * det_inv;
+                iz = cx * det_inv;
+            } else {
+                alpha0 = 0.0f;                                         // :104
+            }
+            s_batch[lane][0] = make_float4(nxt.a.x, nxt.a.y, ix, iy);
+            s_batch[lane][1] = make_float4(iz, nxt.b.y, nxt.b.z, nxt.b.w);
+            s_batch[lane][2] = make_float4(alpha0, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();                                               // :109 (single wave)
+        nxt = fetch_splat(raster, sorted_id, i + 64 + lane, end);      // prefetch next batch
+
+        for (uint32_t j = 0; j < n; ++j) {                             // :112
+            const float4 g0 = s_batch[j][0];
+            const float4 g1 = s_batch[j][1];
+            const float ga = s_batch[j][2].x;
+            float ey = g0.y - fpy;                                     // :119
+            ey = -ey;                                                  // :120
+            float f[4], alpha[4];
+            bool act[4];
+            bool any_act = false;
+            if constexpr (EXACT) {
+                const float c_term = g1.x * ey * ey;                   // gCovInv.z * y * y
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float ex = g0.x - fpx[k];
+                    f[k] = -0.5f * (g0.z * ex * ex + c_term) - g0.w * ex * ey;  // :123
+                    alpha[k] = ga * exp_pinned(f[k]);                           // :124
+                    act[k] = !done[k] && !(f[k] > 0.0f || alpha[k] < 1.0f / 255.0f); // :127
+                    any_act |= act[k];
+                }
+            } else {
+                const float c_term = g1.x * ey * ey;
+                const float b_term = g0.w * ey;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float ex = g0.x - fpx[k];
+                    const float q = __builtin_fmaf(g0.z * ex, ex, c_term);
+                    f[k] = __builtin_fmaf(-0.5f, q, -(b_term * ex));
+                    alpha[k] = ga * __builtin_amdgcn_exp2f(f[k] * 0x1.715476p+0f);
+                    act[k] = !done[k] && !(f[k] > 0.0f || alpha[k] < 1.0f / 255.0f);
+                    any_act |= act[k];
+                }
+            }
+            if (__any(any_act)) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float wgt = T[k] * alpha[k];                 // :131
+                    if constexpr (EXACT) {
+                        col[k][0] = act[k] ? col[k][0] + wgt * g1.y : col[k][0];
+                        col[k][1] = act[k] ? col[k][1] + wgt * g1.z : col[k][1];
+                        col[k][2] = act[k] ? col[k][2] + wgt * g1.w : col[k][2];
+                    } else {
+                        const float w0 = act[k] ? wgt : 0.0f;
+                        col[k][0] = __builtin_fmaf(w0, g1.y, col[k][0]);
+                        col[k][1] = __builtin_fmaf(w0, g1.z, col[k][1]);
+                        col[k][2] = __builtin_fmaf(w0, g1.w, col[k][2]);
+                    }
+                    const float next_t = T[k] * (1.0f - alpha[k]);     // :133
+                    const bool fin = act[k] && next_t < 0.0001f;       // :136-140, colour already added
+                    done[k] = done[k] || fin;
+                    T[k] = (act[k] && !fin) ? next_t : T[k];           // :142
+                }
+                if (__all(done[0] && done[1] && done[2] && done[3])) goto finish; // whole-tile early-out
+            }
+        }
+        __syncthreads();                                               // :84
+    }
+finish:
+    // :147-151 clamp + RGBA8 UNORM store, A = 255
+    uint32_t packed[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t v = 0xFF000000u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = clampf(col[k][c], 0.0f, 1.0f);
+            v |= (uint32_t)(x * 255.0f + 0.5f) << (8 * c);
+        }
+        packed[k] = v;
+    }
+    if (py < fp.height) {
+        uint32_t* row = rgba + (size_t)py * fp.width;
+        if ((fp.width & 3u) == 0u && px0 + 3 < fp.width) {
+            *reinterpret_cast<uint4*>(row + px0) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (px0 + k < fp.width) row[px0 + k] = packed[k];
+        }
+    }
+}
+
+void launch_find_ranges(const uint32_t* sorted_tile, const SortParams* params, uint32_t capacity,
+                        uint32_t* ranges, hipStream_t stream) {
+    uint32_t blocks = (capacity + 255u) / 256u;
+    if (blocks > 4096u) blocks = 4096u;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_find_ranges, dim3(blocks), dim3(256), 0, stream, sorted_tile, params, ranges);
+}
+
+void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
+                   const uint32_t* ranges, uint8_t* rgba, uint32_t render_mode, hipStream_t stream) {
+    const uint32_t rows = fp.row_end > fp.row_begin ? fp.row_end - fp.row_begin : 0u;
+    const uint32_t tiles = rows * fp.grid_w;
+    if (tiles == 0) return;
+    if (render_mode == 0u)
+        hipLaunchKernelGGL(k_render<true>, dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
+                           ranges, reinterpret_cast<uint32_t*>(rgba));
+    else
+        hipLaunchKernelGGL(k_render<false>, dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
+                           ranges, reinterpret_cast<uint32_t*>(rgba));
+}
+
+} // namespace gs

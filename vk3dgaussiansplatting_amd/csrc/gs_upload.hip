@@ -1,0 +1,42 @@
+// gs_upload.hip -- one-off conversion of the reference's 336-byte AoS GaussianData records
+// (Engine/Graphics/ShaderStructs.h:59-70) to the SoA planes the per-frame kernels read with fully
+// coalesced loads.  Runs once per scene (Renderer::initForScene, Renderer.cpp:712-724), chunk by
+// chunk through a staging buffer so a 50 M-splat scene never needs a second full-size AoS copy in HBM.
+#include "gs_internal.h"
+
+namespace gs {
+
+// chunk: [count][84] floats starting at splat `first`; n = total splats (plane stride)
+__global__ __launch_bounds__(256) void k_aos_to_soa(const float* __restrict__ chunk, uint32_t first,
+                                                     uint32_t count, uint32_t n, SceneBuffers s) {
+    __shared__ float tile[64][85];   // 64 records, padded row to dodge bank conflicts
+    const uint32_t rec0 = blockIdx.x * 64u;
+    const uint32_t nrec = (count - rec0) < 64u ? (count - rec0) : 64u;
+    // coalesced read of nrec*84 consecutive floats
+    for (uint32_t k = threadIdx.x; k < nrec * 84u; k += 256u)
+        tile[k / 84u][k % 84u] = chunk[(size_t)rec0 * 84u + k];
+    __syncthreads();
+    // coalesced plane writes: lane = record
+    const uint32_t r = threadIdx.x & 63u, part = threadIdx.x >> 6;   // 4 waves split the 59 fields
+    if (r < nrec) {
+        const size_t g = (size_t)first + rec0 + r;
+        for (uint32_t fld = part; fld < 59u; fld += 4u) {
+            if (fld < 3u) s.pos[(size_t)fld * n + g] = tile[r][0 + fld];
+            else if (fld < 6u) s.scale[(size_t)(fld - 3u) * n + g] = tile[r][4 + (fld - 3u)];
+            else if (fld < 10u) s.rot[(size_t)(fld - 6u) * n + g] = tile[r][8 + (fld - 6u)];
+            else if (fld < 58u) {
+                const uint32_t k = fld - 10u, coeff = k / 3u, ch = k % 3u;
+                s.sh[(size_t)k * n + g] = tile[r][12 + coeff * 4u + ch];
+            } else s.opacity[g] = tile[r][12 + 3];
+        }
+    }
+}
+
+void launch_aos_to_soa(const float* chunk, uint32_t first, uint32_t count, uint32_t n,
+                       const SceneBuffers& s, hipStream_t stream) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(k_aos_to_soa, dim3((count + 63u) / 64u), dim3(256), 0, stream, chunk, first,
+                       count, n, s);
+}
+
+} // namespace gs
