@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- whole-frame throughput of the splat hot path on MI355X.
+
+A "step" is one frame (InitSortList -> 4-bit radix sort -> FindRanges -> RenderGaussians) of a
+synthetic gaussian cloud at a reference README shape, inputs resident in HBM, image left in HBM
+(the reference writes into the swapchain image; it never copies a frame to the host).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C|B|A|D] [--mode exact|fast]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; the frame is sharded by screen-tile
+rows and the RGBA8 strips are gathered to rank 0 over RCCL each step (strong scaling: the frame
+is fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a float4 copy)
+REF_MSPLATS = {"C": 5_834_784 / 28.499 / 1000.0, "B": 559_263 / 8.581 / 1000.0}   # BASELINE.md (RTX 3080 Ti, real .ply)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(aos, cfg, budget_s=20.0):
+    """The oracle (a scalar C port of the same four stages) timed on this box's host cores, on a
+    bounded sample of the SAME workload: every k-th gaussian of the cloud, same camera/resolution."""
+    import oracle
+    n_sample = min(aos.shape[0], 200_000)
+    stride = max(1, aos.shape[0] // n_sample)
+    sub = np.ascontiguousarray(aos[::stride][:n_sample])
+    w, h = cfg["width"], cfg["height"]
+    view, proj = oracle.camera_matrices(np.zeros(3, np.float32), 0.0, 0.0, w / h)
+    p = oracle.make_params(w, h, view, proj, (0, 0, 0))
+    times, t_start = [], time.time()
+    while len(times) < 5 and (time.time() - t_start < budget_s or not times):
+        _, e, t = oracle.frame(p, sub)
+        times.append(float(t[4]))
+    ms = float(np.median(times))
+    return {"value": round(sub.shape[0] / ms / 1000.0, 4), "unit": "Msplats/s", "cores": 1, "kind": "port",
+            "ms_per_frame": round(ms, 2), "host_cpus": os.cpu_count(),
+            "sample": f"every {stride}th gaussian of the workload cloud ({sub.shape[0]} splats, E={e}) at "
+                      f"{w}x{h}, same camera, {len(times)} frames, median, single thread (oracle/gs_oracle.c -O2)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--config", default="C", choices=["A", "B", "C", "D"])
+    ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import vk3dgaussiansplatting_amd as gs
+    from vk3dgaussiansplatting_amd import dist as gsdist
+    from vk3dgaussiansplatting_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.init_process_group(backend="nccl", device_id=device)
+    # one explicit HIP stream for the frame kernels AND the strip gather (torch orders RCCL after it)
+    torch.cuda.set_stream(torch.cuda.Stream(device=device))
+
+    cfg = dict(synth.CONFIGS[args.config])
+    w, h, n = cfg["width"], cfg["height"], cfg["n"]
+    t0 = time.time()
+    aos = synth.generate(n, w, h, cfg["mu"], cfg["seed"])
+    if rank == 0:
+        log(f"[bench] config {args.config}: {n} gaussians @ {w}x{h} generated in {time.time() - t0:.1f}s")
+
+    rm = gs.ResourceManager()
+    rm.setGaussians(aos)
+    scene = gs.Scene(rm, aspect_ratio=w / h)
+    cam = scene.getCamera()
+    cam.setPosition((0.0, 0.0, 0.0))
+    cam.setRotation(0.0, 0.0)
+    cam.recalculate()
+    mode = gs.GS_RENDER_EXACT if args.mode == "exact" else gs.GS_RENDER_FAST
+
+    def make(record):
+        r = gs.Renderer(w, h, device=local_rank, render_mode=mode, record_timings=record, warmup_frames=0)
+        r.init(rm)
+        r.initForScene(scene)
+        return r
+
+    r = make(0)   # the timed region runs un-instrumented: no events between kernels
+    sf = gsdist.ShardedFrame(w, h, rank, world, device=device)
+    rb, re = sf.band
+    r.setTileRows(rb, re)
+    # the library addresses the FULL frame; hand it the strip shifted up by the band's first row
+    strip_ptr = sf.strip.data_ptr() - rb * 16 * w * 4
+    r.setStream(torch.cuda.current_stream().cuda_stream)   # same stream as the RCCL gather
+
+    def step():
+        r.drawDevice(scene, strip_ptr, sync=False)
+        if world > 1:
+            sf.gather()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            tdist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t_begin
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        tdist.all_reduce(el, op=tdist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # instrumented pass (same process, same data, same K): the reference's five buckets + one event
+    # pair around every Scatter launch, on the stream the kernels run on
+    r.setStream(None)
+    r.cleanup()
+    ri = make(2)
+    ri.setTileRows(rb, re)
+    ri.setStream(torch.cuda.current_stream().cuda_stream)
+    buckets = np.zeros(5)
+    scat = 0.0
+    k_inst = max(10, min(args.steps, 100))
+    for i in range(5 + k_inst):
+        ri.drawDevice(scene, strip_ptr, sync=True)
+        if i >= 5:
+            t = ri.timings()
+            buckets += [t.init_sort_list_ms, t.radix_sort_ms, t.find_ranges_ms, t.render_ms, t.total_ms]
+            scat += t.scatter_ms_avg
+    buckets /= k_inst
+    scat /= k_inst
+    t = ri.timings()
+    e_rank = int(t.num_sort_elements)
+    passes = int(t.scatter_launches)
+    info = ri.sceneInfo()
+    ri.setStream(None)
+    ri.cleanup()
+
+    # per-rank numbers to rank 0
+    stats = torch.tensor([e_rank, scat, *buckets], dtype=torch.float64, device=device)
+    if world > 1:
+        allstats = [torch.zeros_like(stats) for _ in range(world)]
+        tdist.all_gather(allstats, stats)
+    else:
+        allstats = [stats]
+
+    if rank == 0:
+        e_total = int(sum(float(s[0]) for s in allstats))
+        value = n / ms_per_step / 1000.0            # Msplats/s, whole job
+        # roofline of the dominant kernel (k_scatter): algorithmic bytes per launch =
+        # 24 B per element (read 12 B key+payload, write 12 B; SURVEY 8(d): Scatter share of B_sort)
+        alg_bytes = 24.0 * e_rank
+        achieved = alg_bytes / (scat * 1e-3) / 1e9 if scat > 0 else 0.0
+        out = {
+            "metric": "Msplats/s + total frame ms (InitSortList/RadixSort/FindRanges/Render split)",
+            "value": round(value, 2), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": round(value / REF_MSPLATS[args.config], 3) if args.config in REF_MSPLATS else None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": {"A": "synthetic 100k @ 640x360", "B": "Train-7k shape: 559,263 gaussians @ 1280x720",
+                             "C": "Garden-30k shape: 5,834,784 gaussians @ 1920x1080",
+                             "D": "Garden-30k shape: 5,834,784 gaussians @ 3840x2160"}[args.config],
+                "num_gaussians": n, "width": w, "height": h, "sort_elements": e_total,
+                "capacity": int(info.capacity), "radix_passes": passes, "render_mode": args.mode,
+                "parallelism": f"tile-row shard x{world}" if world > 1 else "single GPU",
+                "baseline_note": "vs_baseline = Msplats/s over the reference README's RTX 3080 Ti figure for the "
+                                 "real scene of this shape (BASELINE.md); ours is a synthetic cloud with the same N and E",
+            },
+            "buckets_ms": {k: round(float(v), 4) for k, v in zip(
+                ["init_sort_list", "radix_sort", "find_ranges", "render", "total"], allstats[0][2:].tolist())},
+            "buckets_note": "rank 0, instrumented pass (hipEvents at the reference's 7 timestamp points); "
+                            "ms_per_step is the un-instrumented wall clock incl. the strip gather",
+            "roofline": {"bound": "hbm", "kernel": "k_scatter (radix Scatter, one launch per 4-bit pass)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scat, 5),
+                         "launches_per_frame": passes},
+        }
+        if world > 1:
+            out["per_rank_total_ms"] = [round(float(s[6]), 4) for s in allstats]
+            out["per_rank_sort_elements"] = [int(s[0]) for s in allstats]
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(aos, cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,7 +65,8 @@ typedef struct gs_config {
     float fov_y;              /* 3.1415f*0.5f FOV_Y (the covariance one, not the projection's) */
     uint32_t sort_algorithm;  /* GS_SORT_* */
     uint32_t render_mode;     /* GS_RENDER_* */
-    uint32_t record_timings;  /* 1 = hipEvents at the reference's 7 timestamp points (RECORD_GPU_TIMES, Renderer.h:35) */
+    uint32_t record_timings;  /* 1 = hipEvents at the reference's 7 timestamp points (RECORD_GPU_TIMES, Renderer.h:35);
+                                 2 = additionally one event pair around every Scatter launch (roofline measurement) */
 } gs_config;
 
 /* The five buckets of Renderer.cpp:471-475 (ms) + the sort element count ("Elements To Sort"
@@ -80,6 +81,8 @@ typedef struct gs_timings {
     uint32_t num_sort_elements;   /* min(counter, capacity) */
     uint32_t overflowed;          /* counter > capacity this frame */
     uint64_t emitted_elements;    /* un-truncated counter */
+    float scatter_ms_avg;         /* record_timings == 2: mean duration of one Scatter launch (the dominant kernel) */
+    uint32_t scatter_launches;    /* number of Scatter launches in the frame (= passes P) */
 } gs_timings;
 
 /* Scene-derived sizes: Renderer.cpp:696-701 (tiles), :725 (capacity), RadixSort.cpp:203-204 (bits). */

@@ -1,0 +1,37 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def has_gpu() -> bool:
+    return os.path.exists("/dev/kfd")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle
+    oracle.lib()
+    return oracle
+
+
+def default_camera(oracle, width, height, pos=(0.0, 0.0, 0.0), yaw=0.0, pitch=0.0):
+    view, proj = oracle.camera_matrices(np.asarray(pos, np.float32), yaw, pitch, width / height)
+    return view, proj, np.asarray(pos, np.float32)
+
+
+@pytest.fixture(scope="session")
+def small_cloud():
+    from vk3dgaussiansplatting_amd import synth
+    return synth.generate(3000, 320, 180, -3.2, seed=11)

@@ -1,0 +1,237 @@
+"""CPU tests of the oracle (the checker) against everything the reference pins: golden vectors
+produced by the reference's own glm/SMath code, its host formulas, its synthetic TestSortScene,
+and the structural invariants of SURVEY.md section 4."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, default_camera
+
+
+def _f32(bits):
+    return np.array(bits, dtype=np.uint32).view(np.float32)
+
+
+@pytest.fixture(scope="module")
+def ref_golden():
+    with open(os.path.join(GOLDEN, "ref_glm_smath.json")) as f:
+        return json.load(f)
+
+
+def test_camera_matrices_match_reference_glm(oracle_mod, ref_golden):
+    """view/proj bit-identical to glm::lookAt / glm::perspective run from /root/reference (Camera.cpp:7-48)."""
+    for cam in ref_golden["cameras"]:
+        pos = _f32(cam["pos"])
+        yaw, pitch, aspect = (float(_f32([cam[k]])[0]) for k in ("yaw", "pitch", "aspect"))
+        view, proj = oracle_mod.camera_matrices(pos, yaw, pitch, aspect)
+        assert np.array_equal(view.view(np.uint32), np.array(cam["view"], np.uint32)), cam["name"]
+        assert np.array_equal(proj.view(np.uint32), np.array(cam["proj"], np.uint32)), cam["name"]
+
+
+def test_morton_matches_reference_smath(oracle_mod, ref_golden):
+    for x, y, z, code in ref_golden["morton"]:
+        assert oracle_mod.morton(x, y, z) == code
+
+
+def test_synth_morton_codes_match_reference(oracle_mod, ref_golden):
+    from vk3dgaussiansplatting_amd import synth
+    m = np.array(ref_golden["morton"], dtype=np.uint32)
+    # positions that quantise exactly to the given lattice points
+    pos = m[:, :3].astype(np.float32)
+    pos = np.concatenate([pos, [[0, 0, 0], [1023, 1023, 1023]]]).astype(np.float32)
+    codes = synth.morton_codes(pos)[: m.shape[0]]
+    assert np.array_equal(codes, m[:, 3])
+
+
+def test_host_formulas(oracle_mod):
+    # P = ceil((32 + bits(T-1)) / 4)  (RadixSort.cpp:203-204), SURVEY section 2.2
+    for (w, h), passes in {(640, 360): 11, (1280, 720): 11, (1600, 900): 12, (1920, 1080): 12,
+                           (3840, 2160): 12}.items():
+        gw, gh = oracle_mod.grid(w, h)
+        assert oracle_mod.num_sort_bits(gw * gh) == passes * 4
+    # C = ceilPow2(N + 1024 T)  (Renderer.cpp:725), SURVEY section 8a
+    assert oracle_mod.capacity(100_000, 40 * 23) == 2**20
+    assert oracle_mod.capacity(559_263, 80 * 45) == 2**23
+    assert oracle_mod.capacity(5_834_784, 120 * 68) == 2**24
+    assert oracle_mod.capacity(5_834_784, 240 * 135) == 2**26
+
+
+def test_pinned_exp_accuracy(oracle_mod):
+    x = np.concatenate([np.linspace(-20, 0, 20001), -np.logspace(-8, 1.3, 2000)]).astype(np.float32)
+    got = oracle_mod.exp(x).astype(np.float64)
+    want = np.exp(x.astype(np.float64))
+    ulp = np.abs(got - want) / np.spacing(want.astype(np.float32)).astype(np.float64)
+    # polynomial 1.4 ulp + rounding of x*log2(e): within GLSL's (3 + 2|x|) ULP for exp()
+    assert np.all(ulp <= 3 + 2 * np.abs(x))
+    assert ulp[np.abs(x) < 1].max() < 2.0
+    assert oracle_mod.exp([0.0])[0] == 1.0
+
+
+def test_testsort_scene_known_answer(oracle_mod):
+    """Scenes/TestSortScene.cpp:16-33: 192 splats whose depth keys are (i+1)*1024 by construction."""
+    import vk3dgaussiansplatting_amd as gs
+    sc = gs.TestSortScene(aspect_ratio=1280 / 720)
+    # camera via the oracle, not the library (no GPU needed for this test)
+    view, proj, pos = default_camera(oracle_mod, 1280, 720)
+    sc.camera.recalculate = lambda: None
+    sc.init()
+    aos = sc.getResourceManager().getGaussians()
+    assert aos.shape == (192, 84)
+    p = oracle_mod.make_params(1280, 720, view, proj, pos)
+    s1 = oracle_mod.init_sort_list(p, aos)
+    vis = s1["splats"]["visible"].astype(bool)
+    keys = s1["splats"]["depth_key"][vis].astype(np.int64)
+    idx = np.nonzero(vis)[0]
+    assert vis[0] and idx.size >= 16                       # x = (i-8)*0.01 at z ~ 0.1: side cull takes the tail
+    assert np.all(np.diff(keys) > 0)                       # strictly increasing in i
+    assert np.all(np.abs(keys - (idx + 1) * 1024) <= 2)    # == (i+1)*1024 up to float rounding of zOffset
+
+
+def _pipeline(oracle_mod, aos, w, h, **kw):
+    view, proj, pos = default_camera(oracle_mod, w, h, **kw)
+    p = oracle_mod.make_params(w, h, view, proj, pos)
+    return p, oracle_mod.full_pipeline(p, aos)
+
+
+def test_literal_radix_model_equals_stable_sort(oracle_mod, small_cloud):
+    w, h = 320, 180
+    view, proj, pos = default_camera(oracle_mod, w, h)
+    p = oracle_mod.make_params(w, h, view, proj, pos)
+    a = oracle_mod.full_pipeline(p, small_cloud, literal_sort=False)
+    b = oracle_mod.full_pipeline(p, small_cloud, literal_sort=True)
+    e = a["e"]
+    assert e > 3000
+    for k in ("tile", "depth", "id"):
+        assert np.array_equal(a[k][:e], b[k][:e])
+    # unused tail keeps the 0xFFFFFFFF fill in the literal model (N9)
+    assert np.all(b["tile"][e:] == 0xFFFFFFFF)
+
+
+def test_sort_invariants(oracle_mod, small_cloud):
+    p, r = _pipeline(oracle_mod, small_cloud, 320, 180)
+    e = r["e"]
+    key = (r["tile"][:e].astype(np.uint64) << np.uint64(32)) | r["depth"][:e].astype(np.uint64)
+    assert np.all(key[1:] >= key[:-1])
+    s1 = r["stage1"]
+    # same multiset, and stability: equal keys keep emission order (ascending emission index)
+    ukey = (s1["tile"][:e].astype(np.uint64) << np.uint64(32)) | s1["depth"][:e].astype(np.uint64)
+    order = np.argsort(ukey, kind="stable")
+    assert np.array_equal(s1["id"][:e][order], r["id"][:e])
+
+
+def test_find_ranges_literal_equals_product_form(oracle_mod, small_cloud):
+    p, r = _pipeline(oracle_mod, small_cloud, 320, 180)
+    e, cap = r["e"], r["stage1"]["capacity"]
+    gw, gh = oracle_mod.grid(320, 180)
+    full = np.full(cap, 0xFFFFFFFF, np.uint32)
+    full[:e] = r["tile"][:e]
+    lit = oracle_mod.find_ranges(full, cap, gw * gh, literal=True)
+    assert np.array_equal(lit, r["ranges"])
+    lens = r["ranges"][:, 1].astype(np.int64) - r["ranges"][:, 0]
+    assert lens.sum() == e and np.all(lens >= 0)
+    nz = r["ranges"][lens > 0]
+    # ranges tile the sorted list exactly
+    order = np.argsort(nz[:, 0])
+    assert nz[order][0, 0] == 0 and nz[order][-1, 1] == e
+    assert np.array_equal(nz[order][1:, 0], nz[order][:-1, 1])
+
+
+def test_find_ranges_quirk_q1_when_full(oracle_mod):
+    tile = np.array([0, 0, 1, 1, 2, 2, 2, 2], np.uint32)
+    lit = oracle_mod.find_ranges(tile, 8, 3, literal=True)
+    ours = oracle_mod.find_ranges(tile, 8, 3, literal=False)
+    assert lit[2, 1] == 7 and ours[2, 1] == 8          # FindRanges.comp:65-70 drops the last element
+    assert np.array_equal(lit[:2], ours[:2])
+
+
+def test_overflow_truncates_like_reference(oracle_mod):
+    """InitSortList.comp:140-148: ids >= capacity are dropped; E' = min(counter, C)."""
+    from vk3dgaussiansplatting_amd import synth
+    aos = synth.generate(500, 320, 180, -0.5, seed=5)
+    view, proj, pos = default_camera(oracle_mod, 320, 180)
+    p = oracle_mod.make_params(320, 180, view, proj, pos)
+    full = oracle_mod.init_sort_list(p, aos)
+    assert full["counter"] > 2000
+    cap = 1024
+    trunc = oracle_mod.init_sort_list(p, aos, cap=cap)
+    assert trunc["counter"] == full["counter"]
+    for k in ("tile", "depth", "id"):
+        assert np.array_equal(trunc[k], full[k][:cap])
+
+
+def test_pinned_exp_image_within_one_step_of_libm(oracle_mod, small_cloud):
+    p, r = _pipeline(oracle_mod, small_cloud, 320, 180)
+    s1 = r["stage1"]
+    alt = oracle_mod.render(p, small_cloud, s1["color"], s1["cov"], r["id"], r["ranges"], libm_exp=True)
+    d = np.abs(alt.astype(np.int16) - r["image"].astype(np.int16))
+    assert d.max() <= 1
+    assert (d > 0).mean() < 1e-3
+
+
+def test_empty_view_is_black(oracle_mod, small_cloud):
+    # camera looking away from the cloud: everything near-culled, E = 0
+    p, r = _pipeline(oracle_mod, small_cloud, 320, 180, yaw=np.pi)
+    assert r["e"] == 0
+    assert np.all(r["image"][..., :3] == 0) and np.all(r["image"][..., 3] == 255)
+    assert np.all(r["ranges"] == 0)
+
+
+def test_sh_modes_differ_and_alpha_is_opacity(oracle_mod, small_cloud):
+    view, proj, pos = default_camera(oracle_mod, 320, 180)
+    cols = []
+    for mode in (0, 1, 2):
+        p = oracle_mod.make_params(320, 180, view, proj, pos, sh_mode=mode)
+        s1 = oracle_mod.init_sort_list(p, small_cloud)
+        vis = s1["splats"]["visible"].astype(bool)
+        assert np.array_equal(s1["color"][vis, 3], small_cloud[vis, 15])
+        assert np.all(s1["color"][vis, :3] >= 0)
+        cols.append(s1["color"][vis, :3])
+    assert not np.array_equal(cols[0], cols[1]) and not np.array_equal(cols[0], cols[2])
+    # mode 2 = 0.28209479 * dc + 0.5, clamped at 0 (Common.glsl:160-166)
+    vis_dc = small_cloud[vis, 12:15]
+    want = np.maximum(np.float32(0.2820947917738781) * vis_dc + np.float32(0.5), 0).astype(np.float32)
+    assert np.array_equal(cols[2], want)
+
+
+def test_row_band_emission_is_a_partition(oracle_mod, small_cloud):
+    """Multi-GPU extension: bands emit disjoint subsets whose union is the 1-GPU list."""
+    w, h = 320, 180
+    view, proj, pos = default_camera(oracle_mod, w, h)
+    gw, gh = oracle_mod.grid(w, h)
+    whole = oracle_mod.full_pipeline(oracle_mod.make_params(w, h, view, proj, pos), small_cloud)
+    img = np.zeros((h, w, 4), np.uint8)
+    total = 0
+    for rb, re in ((0, 5), (5, 9), (9, gh)):
+        p = oracle_mod.make_params(w, h, view, proj, pos, row_begin=rb, row_end=re)
+        part = oracle_mod.full_pipeline(p, small_cloud)
+        total += part["e"]
+        rows = slice(rb * 16, min(re * 16, h))
+        img[rows] = part["image"][rows]
+        # per-tile lists equal the 1-GPU ones
+        for t in range(rb * gw, re * gw):
+            a0, a1 = whole["ranges"][t]
+            b0, b1 = part["ranges"][t]
+            assert a1 - a0 == b1 - b0
+            assert np.array_equal(whole["id"][a0:a1], part["id"][b0:b1])
+    assert total == whole["e"]
+    assert np.array_equal(img, whole["image"])
+
+
+def test_golden_small_scene(oracle_mod):
+    """The committed fixture pins the oracle itself (any change to its arithmetic shows up here)."""
+    g = np.load(os.path.join(GOLDEN, "small_scene.npz"))
+    w, h = int(g["width"]), int(g["height"])
+    for mode in (0, 1, 2):
+        p = oracle_mod.make_params(w, h, g["view"], g["proj"], g["cam_pos"], sh_mode=mode)
+        r = oracle_mod.full_pipeline(p, g["aos"])
+        e = r["e"]
+        if mode == 0:
+            assert r["stage1"]["counter"] == int(g["counter"])
+            for k in ("tile", "depth", "id"):
+                assert np.array_equal(r[k][:e], g[k])
+            assert np.array_equal(r["ranges"], g["ranges"])
+            assert np.array_equal(r["stage1"]["cov"].view(np.uint32), g["cov"].view(np.uint32))
+        assert np.array_equal(r["stage1"]["color"].view(np.uint32), g[f"color_mode{mode}"].view(np.uint32))
+        assert np.array_equal(r["image"], g[f"image_mode{mode}"])

@@ -57,6 +57,8 @@ class GsTimings(C.Structure):
         ("num_sort_elements", C.c_uint32),
         ("overflowed", C.c_uint32),
         ("emitted_elements", C.c_uint64),
+        ("scatter_ms_avg", C.c_float),
+        ("scatter_launches", C.c_uint32),
     ]
 
 

@@ -23,6 +23,7 @@ struct gs_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[7] = {};
+    hipEvent_t scatter_ev[32] = {};   // record_timings == 2: a pair per pass (<= 16 passes)
     std::string last_error;
 
     // scene
@@ -158,7 +159,8 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     if (int r = check_launch(c, "InitSortList")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[2], st));
     // gpuSort->computeSort (RadixSort.cpp:207-653)
-    c->sorted_index = launch_radix_sort(c->sort, c->capacity, c->num_sort_bits, st);
+    c->sorted_index = launch_radix_sort(c->sort, c->capacity, c->num_sort_bits, st,
+                                        c->cfg.record_timings >= 2 ? c->scatter_ev : nullptr);
     if (int r = check_launch(c, "RadixSort")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[3], st));
     // computeRanges (Subrenderer.cpp:172-216)
@@ -186,6 +188,17 @@ int finish_frame(gs_ctx* c) {
         HIP_TRY(c, hipEventElapsedTime(&t.find_ranges_ms, c->ev[3], c->ev[4]));
         HIP_TRY(c, hipEventElapsedTime(&t.render_ms, c->ev[4], c->ev[5]));
         HIP_TRY(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[6]));
+    }
+    if (c->cfg.record_timings >= 2) {
+        const uint32_t passes = c->num_sort_bits / kRadixBits;
+        float sum = 0.0f;
+        for (uint32_t k = 0; k < passes; ++k) {
+            float ms = 0.0f;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->scatter_ev[2 * k], c->scatter_ev[2 * k + 1]));
+            sum += ms;
+        }
+        t.scatter_ms_avg = passes ? sum / (float)passes : 0.0f;
+        t.scatter_launches = passes;
     }
     t.num_sort_elements = sp.num_elems;
     t.overflowed = sp.overflow;
@@ -245,6 +258,13 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
             gs_destroy(c);
             return fail(nullptr, GS_ERR_HIP, msg);
         }
+    if (cfg.record_timings >= 2)
+        for (auto& ev : c->scatter_ev)
+            if ((e = hipEventCreate(&ev)) != hipSuccess) {
+                std::string msg = std::string("gs_create: ") + hipGetErrorString(e);
+                gs_destroy(c);
+                return fail(nullptr, GS_ERR_HIP, msg);
+            }
     *out = c;
     return GS_OK;
 }
@@ -256,6 +276,7 @@ int gs_destroy(gs_ctx* c) {
     free_resolution(c);
     free_scene(c);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : c->scatter_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return GS_OK;

@@ -98,8 +98,9 @@ void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParam
 void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb,
                  hipStream_t stream);
 // Sorts buffers [0] -> result index returned (0 or 1) after num_sort_bits/4 passes.
+// scatter_events: optional 2*passes events recorded right before / after every Scatter launch.
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
-                      hipStream_t stream);
+                      hipStream_t stream, hipEvent_t* scatter_events = nullptr);
 void launch_find_ranges(const uint32_t* sorted_tile, const SortParams* params, uint32_t capacity,
                         uint32_t* ranges, hipStream_t stream);
 void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,

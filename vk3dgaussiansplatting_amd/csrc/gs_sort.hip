@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kSortThreads) void k_scatter(
 }
 
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
-                      hipStream_t stream) {
+                      hipStream_t stream, hipEvent_t* scatter_events) {
     const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
     const uint32_t max_segments = (max_groups + kSegGroups - 1) / kSegGroups;
     const uint32_t passes = (num_sort_bits + kRadixBits - 1) / kRadixBits;
@@ -224,9 +224,11 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
         uint32_t* seg = sb.seg_sum + (size_t)pass * kBins * max_segments;
         hipLaunchKernelGGL(k_count, dim3(max_groups), dim3(kSortThreads), 0, stream, sb.params,
                            word, sb.table, seg, shift & 31u);
+        if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass], stream);
         hipLaunchKernelGGL(k_scatter, dim3(max_groups), dim3(kSortThreads), 0, stream, sb.params,
                            sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],
                            sb.table, seg, shift);
+        if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass + 1], stream);
         src = dst;                                                            // RadixSort.cpp:638-641
     }
     return src;

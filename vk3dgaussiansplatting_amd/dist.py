@@ -1,0 +1,81 @@
+"""Multi-GPU frames: shard by screen-tile rows, one process per GPU, one gather of RGBA8 strips.
+
+The reference is single-GPU (no collective anywhere).  Tiles are independent
+once each has its sorted list (RenderGaussians.comp:74-77 reads only its own range), so the frame
+shards naturally: the gaussian arrays are replicated, rank r emits/sorts/renders only the tile rows
+of its band (with GLOBAL tile ids, so keys, per-tile order and pixels equal the 1-GPU result) and
+the only exchange is one gather of equal-size image strips to rank 0 per frame -- over RCCL/xGMI
+when the process group's backend is "nccl", over gloo in the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Tuple
+
+import numpy as np
+
+
+def tile_row_partition(tiles_y: int, world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous bands of ceil(tiles_y / world_size) rows; trailing ranks may get fewer (or zero)
+    rows.  Strips are padded to the same height for the collective."""
+    per = (tiles_y + world_size - 1) // world_size
+    out = []
+    for r in range(world_size):
+        b = min(r * per, tiles_y)
+        e = min(b + per, tiles_y)
+        out.append((b, e))
+    return out
+
+
+def strip_rows(tiles_y: int, world_size: int, tile: int = 16) -> int:
+    """Pixel rows of one (padded) strip."""
+    return ((tiles_y + world_size - 1) // world_size) * tile
+
+
+class ShardedFrame:
+    """Band render + gather.  `render_band(row_begin, row_end, strip)` must write the band's pixel
+    rows into the first rows of `strip` ([strip_rows, W, 4] uint8, torch tensor on the rank's
+    device or CPU); it is the only thing that differs between the GPU path (Renderer.drawDevice
+    into the strip's storage) and the CPU test (an injected checker)."""
+
+    def __init__(self, width: int, height: int, rank: int, world_size: int, device="cpu", group=None):
+        import torch
+        self.torch = torch
+        self.width, self.height = width, height
+        self.rank, self.world = rank, world_size
+        self.tiles_y = (height + 15) // 16
+        self.bands = tile_row_partition(self.tiles_y, world_size)
+        self.rows = strip_rows(self.tiles_y, world_size)
+        self.group = group
+        self.device = device
+        self.strip = torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=device)
+        self.gathered = ([torch.zeros_like(self.strip) for _ in range(world_size)]
+                         if rank == 0 and world_size > 1 else None)
+
+    @property
+    def band(self) -> Tuple[int, int]:
+        return self.bands[self.rank]
+
+    def gather(self):
+        """All ranks call; rank 0 gets the list of strips."""
+        if self.world == 1:
+            return [self.strip]
+        import torch.distributed as dist
+        dist.gather(self.strip, self.gathered, dst=0, group=self.group)
+        return self.gathered
+
+    def assemble(self, strips) -> "np.ndarray":
+        """Rank 0: strips -> [H, W, 4] image (crops the padding of the last band)."""
+        img = self.torch.zeros((self.height, self.width, 4), dtype=self.torch.uint8, device=strips[0].device)
+        for r, (b, e) in enumerate(self.bands):
+            y0, y1 = b * 16, min(e * 16, self.height)
+            if y1 > y0:
+                img[y0:y1] = strips[r][: y1 - y0]
+        return img
+
+    def frame(self, render_band: Callable) -> "np.ndarray | None":
+        b, e = self.band
+        render_band(b, e, self.strip)
+        strips = self.gather()
+        if self.rank == 0:
+            return self.assemble(strips)
+        return None

@@ -234,13 +234,13 @@ class PlyScene(Scene):
 class _Context:
     """Owns one gs_ctx."""
 
-    def __init__(self, device: int = 0, render_mode: int = _lib.GS_RENDER_EXACT, record_timings: bool = True):
+    def __init__(self, device: int = 0, render_mode: int = _lib.GS_RENDER_EXACT, record_timings=True):
         L = _lib.lib()
         cfg = GsConfig()
         L.gs_default_config(C.byref(cfg))
         cfg.device_ordinal = device
         cfg.render_mode = render_mode
-        cfg.record_timings = 1 if record_timings else 0
+        cfg.record_timings = int(record_timings)   # 0 off, 1 buckets, 2 buckets + per-Scatter events
         self.cfg = cfg
         self.handle = C.c_void_p()
         rc = L.gs_create(C.byref(cfg), C.byref(self.handle))
