@@ -190,6 +190,13 @@ int gs_sort_host(gs_ctx* ctx, uint32_t* tile, uint32_t* depth, uint32_t* id, uin
 int gs_sort_bench(gs_ctx* ctx, uint32_t n, uint32_t num_tiles, uint32_t iters, uint64_t seed,
                   float* ms_per_sort, uint32_t* sorted_ok);
 
+/* Stream-bandwidth probe on the context's GPU (the "measured HBM roofline" denominator): kind 0 =
+ * read with 16-byte loads, 1 = device-to-device copy with 16-byte accesses, 2 = read with 4-byte
+ * loads, 3 = copy with 4-byte accesses.  `bytes` per buffer; `blocks` workgroups of 256 threads
+ * (0 = 2048).  Returns the mean over `iters` launches of bytes moved (read + written) per second. */
+int gs_membench(gs_ctx* ctx, int kind, size_t bytes, uint32_t blocks, uint32_t iters, float* gbytes_per_s,
+                float* ms_per_launch);
+
 #ifdef __cplusplus
 }
 #endif

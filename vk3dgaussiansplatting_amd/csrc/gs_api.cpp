@@ -104,9 +104,10 @@ int alloc_sort(gs_ctx* ctx, SortBuffers& s, uint32_t capacity) {
         HIP_TRY(ctx, hipMalloc((void**)&s.id[k], bytes));
     }
     const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
-    const uint32_t max_segments = (max_groups + kSegGroups - 1) / kSegGroups;
+    if (max_groups > (uint32_t)kSegments * 64u)
+        return fail(ctx, GS_ERR_INVALID, "sort list too large for the segment table (> 268M elements)");
     HIP_TRY(ctx, hipMalloc((void**)&s.table, (size_t)kBins * max_groups * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc((void**)&s.seg_sum, (size_t)16 * kBins * max_segments * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&s.seg_sum, (size_t)kBins * kSegments * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc((void**)&s.params, sizeof(SortParams)));
     HIP_TRY(ctx, hipMemset(s.params, 0, sizeof(SortParams)));
     return GS_OK;
@@ -604,6 +605,66 @@ int gs_sort_bench(gs_ctx* c, uint32_t n, uint32_t num_tiles, uint32_t iters, uin
     if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_sort_bench: ") + hipGetErrorString(e));
     *ms_per_sort = total_ms / (float)iters;
     if (sorted_ok) *sorted_ok = bad_host == 0 ? 1u : 0u;
+    return GS_OK;
+}
+
+// Tuning only (not declared in gsplat.h): times k_count alone with parts of it switched off.
+int gs_debug_count_bench(gs_ctx* c, uint32_t n, int ablate, uint32_t grid, uint32_t iters, float* us) {
+    if (!c || !us || n == 0 || iters == 0) return GS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    SortBuffers sb{};
+    int rc = alloc_sort(c, sb, n);
+    if (rc != GS_OK) { free_sort(sb); return rc; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    launch_fill_random_keys(sb.lo[0], sb.hi[0], sb.id[0], n, 8160, 1, c->stream);
+    launch_set_sort_params(sb.params, n, c->stream);
+    for (int w = 0; w < 3; ++w) launch_count_ablate(ablate, sb, n, grid, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+    for (uint32_t i = 0; i < iters; ++i) launch_count_ablate(ablate, sb, n, grid, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    free_sort(sb);
+    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_debug_count_bench: ") + hipGetErrorString(e));
+    *us = ms * 1e3f / (float)iters;
+    return GS_OK;
+}
+
+int gs_membench(gs_ctx* c, int kind, size_t bytes, uint32_t blocks, uint32_t iters, float* gbps, float* ms_out) {
+    if (!c || !gbps || bytes < 16 || iters == 0 || kind < 0 || kind > 3) return GS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    bytes &= ~(size_t)15;
+    if (blocks == 0) blocks = 2048;
+    void *src = nullptr, *dst = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&src, bytes);
+    if (e == hipSuccess) e = hipMalloc(&dst, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(src, 0x5A, bytes, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dst, 0, bytes, c->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) {
+        for (int w = 0; w < 3; ++w) launch_stream_probe(kind, src, dst, bytes, blocks, c->stream);
+        e = hipEventRecord(e0, c->stream);
+        for (uint32_t i = 0; i < iters; ++i) launch_stream_probe(kind, src, dst, bytes, blocks, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_membench: ") + hipGetErrorString(e));
+    const double moved = (double)bytes * ((kind & 1) ? 2.0 : 1.0) * iters;
+    *gbps = (float)(moved / (ms * 1e-3) / 1e9);
+    if (ms_out) *ms_out = ms / (float)iters;
     return GS_OK;
 }
 

@@ -14,12 +14,17 @@ constexpr int kBins = 1 << kRadixBits; // RS_BIN_COUNT
 
 // ---- radix-sort tiling -------------------------------------------------------------------
 // One workgroup (256 threads = 4 waves) owns kSortTile consecutive keys of the current pass.
-// The reference uses 64 keys per group (RS_WORK_GROUP_SIZE, RadixSort.h:38); a 4096-key tile
-// shrinks the histogram table 64x and makes every global access of a pass a >= 256-byte run.
+// The reference uses 64 keys per group (RS_WORK_GROUP_SIZE, RadixSort.h:38); a 3072-key tile
+// shrinks the histogram table 48x and makes every global access of a pass a >= 256-byte run.
+// 12 keys/thread, 3 workgroups/CU (36 KB LDS, <= 168 VGPRs) measured fastest on MI355X
+// (tools/run_variants.sh: 16 keys -> 85 us, 12 -> 72 us, 8 -> 72-80 us per Scatter at E = 13.1 M).
 constexpr int kSortThreads = 256;
-constexpr int kSortKeysPerThread = 16;
-constexpr int kSortTile = kSortThreads * kSortKeysPerThread; // 4096 keys
-constexpr int kSegGroups = 64;         // groups per reduce segment (one wave-load of the table)
+#ifndef GS_SORT_KPT
+#define GS_SORT_KPT 12
+#endif
+constexpr int kSortKeysPerThread = GS_SORT_KPT;
+constexpr int kSortTile = kSortThreads * kSortKeysPerThread; // 3072 keys
+constexpr int kSegments = 1024;        // reduce segments = persistent Count workgroups; each owns a contiguous run of groups
 
 // ---- InitSortList tiling -----------------------------------------------------------------
 constexpr int kProjThreads = 256;      // splats per workgroup in project + emit
@@ -47,7 +52,7 @@ struct FrameParams {
 struct SortParams {
     uint32_t num_elems;      // E' = min(counter, capacity)   (RadixSortIndirectSetup.comp:28)
     uint32_t num_groups;     // G  = ceil(E' / kSortTile)     (countSizeX)
-    uint32_t num_segments;   // S  = ceil(G / kSegGroups)     (reduceSizeX / 16)
+    uint32_t groups_per_seg; // K  = ceil(G / kSegments)      (groups per reduce segment, <= 64)
     uint32_t overflow;       // counter > capacity
     uint64_t counter;        // un-truncated atomic-counter equivalent
     uint32_t pad[2];
@@ -86,7 +91,7 @@ struct SplatScratch {
 struct SortBuffers {
     uint32_t *lo[2], *hi[2], *id[2]; // ping-pong: depth word, tile word, gaussian index; [capacity]
     uint32_t* table;                 // [16][G_max]  per-group digit counts (sumTable)
-    uint32_t* seg_sum;               // [passes][16][S_max]  per-segment digit counts (reduce buffer)
+    uint32_t* seg_sum;               // [16][kSegments]  per-segment digit counts, then their exclusive scan (reduce buffer)
     SortParams* params;
 };
 
@@ -107,6 +112,8 @@ void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint3
                    const uint32_t* ranges, uint8_t* rgba, uint32_t render_mode, hipStream_t stream);
 void launch_aos_to_soa(const float* chunk, uint32_t first, uint32_t count, uint32_t n,
                        const SceneBuffers& s, hipStream_t stream);
+void launch_stream_probe(int kind, const void* src, void* dst, size_t bytes, uint32_t blocks, hipStream_t stream);
+void launch_count_ablate(int ablate, const SortBuffers& sb, uint32_t capacity, uint32_t grid, hipStream_t stream);
 // helpers for the stand-alone sorter entry points
 void launch_set_sort_params(SortParams* params, uint32_t n, hipStream_t stream);
 void launch_fill_random_keys(uint32_t* lo, uint32_t* hi, uint32_t* id, uint32_t n,

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict
         params->counter = counter;
         params->num_elems = e;
         params->num_groups = (e + kSortTile - 1) / kSortTile;
-        params->num_segments = (params->num_groups + kSegGroups - 1) / kSegGroups;
+        params->groups_per_seg = (params->num_groups + kSegments - 1) / kSegments;
         params->overflow = counter > capacity ? 1u : 0u;
     }
 }

@@ -3,24 +3,25 @@
 //
 // Reference pipeline per 4-bit pass (RadixSort.cpp:309-642): five dependent dispatches
 //   Count -> Reduce -> Scan -> ScanAdd -> Scatter, 64 keys per workgroup, 16-byte uvec4 elements.
-// Here the same five stages run in TWO launches per pass over 4096-key tiles ("groups"):
+// Here the same five stages run in THREE launches per pass over 3072-key tiles ("groups"):
 //   k_count    Count  : per-group digit histogram -> table[bin][group]  (RadixSortCount.comp:40-91);
 //                       reads only the 4-byte key half the digit lives in (keys are SoA).
-//              Reduce : the group's 16 counts are added into seg_sum[bin][group/64] with 16
-//                       fire-and-forget device-scope integer atomics (RadixSortReduce.comp:34-72;
-//                       integer adds commute, so the result is deterministic).
-//   k_scatter  Scan   : prologue -- every workgroup derives its segment's exclusive base from the
-//                       (16 x S)-entry seg_sum array, bin-major (RadixSortScan.comp:29-71);
-//              ScanAdd: prologue -- exclusive prefix of the group's counts inside its 64-group
-//                       segment, read from the L2-resident table (RadixSortScanAdd.comp:34-66);
+//              Reduce : each of the 1024 persistent workgroups owns a CONTIGUOUS run of groups (one
+//                       reduce segment) and stores the run's 16 digit totals to seg_sum[bin][segment]
+//                       with plain stores (RadixSortReduce.comp:34-72; device atomics here cost
+//                       ~15 us per pass on MI355X, measured).
+//   k_scan     Scan   : one workgroup, exclusive scan of the 16 x 1024 segment totals in bin-major
+//                       order, in place (RadixSortScan.comp:29-71).
+//   k_scatter  ScanAdd: prologue -- exclusive prefix of the group's counts inside its segment,
+//                       read from the L2-resident table, plus the segment base
+//                       (RadixSortScanAdd.comp:34-66);
 //              Scatter: wave64 match-mask ranking (stable), LDS-staged local sort, run-wise
 //                       coalesced stores (RadixSortScatter.comp:58-171).
-// Folding Reduce/Scan/ScanAdd into the neighbours removes three dependent launches per pass
-// (36 per frame at 12 passes); each costs ~2 us of launch boundary on MI355X and the single-
-// workgroup Scan is the serial tail the reference's README.md:34 complains about.
+// Count and Scatter are persistent (a few workgroups per CU walk the groups and prefetch the next
+// group's keys while working on the current one).
 // Output is bit-identical to a stable sort by the low num_sort_bits of the key.
-// Launch grids are sized from the list CAPACITY; workgroups beyond the device-side element count
-// (SortParams, the IndirectSetup record) exit at once -- no host read-back inside a frame.
+// Launch grids are fixed; the device-side element count (SortParams, the IndirectSetup record)
+// bounds every loop -- no host read-back inside a frame.
 #include "gs_device_utils.h"
 #include "gs_internal.h"
 
@@ -33,201 +34,300 @@ constexpr int kSortWaves = kSortThreads / 64;
 // ---------------------------------------------------------------------------------------------
 // Count + Reduce
 // ---------------------------------------------------------------------------------------------
+#ifndef GS_SCATTER_GRID
+#define GS_SCATTER_GRID 768     // persistent workgroups of k_scatter (3 per CU: 48 KB LDS each)
+#endif
+
+// Count + Reduce.  Persistent workgroups walk the groups (tiles) with a stride of gridDim and
+// prefetch the next group's keys while counting the current one, so HBM never idles between the
+// load / count / store phases of a group.  16-byte coalesced loads (order inside the tile is
+// irrelevant for a histogram); per-thread counters packed 8 x 8 bit in two 64-bit registers,
+// widened to 16-bit fields and summed across the wave with xor-shuffles; no LDS atomics.
+static_assert(kSortKeysPerThread % 4 == 0 && kSortKeysPerThread <= 252, "packed 8-bit counters");
+constexpr int kCountVec = kSortKeysPerThread / 4;
+
+__device__ __forceinline__ void count_load(const uint32_t* __restrict__ word, uint32_t grp, uint32_t e,
+                                           int tid, uint4 (&v)[kCountVec]) {
+    const uint32_t tile_base = grp * kSortTile;
+    if (tile_base + kSortTile <= e) {
+        const uint4* w4 = reinterpret_cast<const uint4*>(word + tile_base);
+#pragma unroll
+        for (int r = 0; r < kCountVec; ++r) v[r] = w4[r * kSortThreads + tid];
+    } else {   // ragged last tile: element-wise, missing keys marked with an impossible pattern below
+#pragma unroll
+        for (int r = 0; r < kCountVec; ++r) {
+            const uint32_t i0 = tile_base + (uint32_t)(r * kSortThreads + tid) * 4u;
+            v[r].x = i0 + 0 < e ? word[i0 + 0] : 0u;
+            v[r].y = i0 + 1 < e ? word[i0 + 1] : 0u;
+            v[r].z = i0 + 2 < e ? word[i0 + 2] : 0u;
+            v[r].w = i0 + 3 < e ? word[i0 + 3] : 0u;
+        }
+    }
+}
+
+// ABLATE is a tuning-only switch (gs_debug_count_bench): bit 1 drops the table store, bit 2 the
+// counting itself.  The product always launches ABLATE = 0.
+template <int ABLATE>
 __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __restrict__ params,
                                                          const uint32_t* __restrict__ word,
                                                          uint32_t* __restrict__ table,
                                                          uint32_t* __restrict__ seg_sum,
                                                          uint32_t sh) {
-    __shared__ uint32_t s_cnt[kSortWaves][kBins];
-    const uint32_t e = params->num_elems, G = params->num_groups, S = params->num_segments;
-    const uint32_t grp = blockIdx.x;
-    if (grp >= G) return;
+    __shared__ uint32_t s_cnt[2][kSortWaves][kBins];
+    const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < kSortWaves * kBins) (&s_cnt[0][0])[tid] = 0;
-    __syncthreads();
-    const uint32_t base = grp * kSortTile + (uint32_t)wave * (kSortKeysPerThread * 64) + lane;
-    uint32_t w[kSortKeysPerThread];
+    // segment = blockIdx.x owns groups [seg*K, min(seg*K + K, G))
+    uint32_t grp = blockIdx.x * K;
+    const uint32_t grp_end = (grp + K < G) ? grp + K : G;
+    uint32_t seg_total = 0;     // threads 0..15: this segment's total of digit tid
+    uint4 nxt[kCountVec];
+    if (grp < grp_end) count_load(word, grp, e, tid, nxt);
+    for (int it = 0; grp < grp_end; ++grp, it ^= 1) {
+        uint4 v[kCountVec];
 #pragma unroll
-    for (int r = 0; r < kSortKeysPerThread; ++r) {
-        const uint32_t idx = base + r * 64;
-        w[r] = idx < e ? word[idx] : 0u;
-    }
+        for (int r = 0; r < kCountVec; ++r) v[r] = nxt[r];
+        if (grp + 1 < grp_end) count_load(word, grp + 1, e, tid, nxt);   // prefetch
+        const uint32_t tile_base = grp * kSortTile;
+        const bool full = tile_base + kSortTile <= e;
+        uint64_t c0 = 0, c1 = 0;   // digits 0-7 / 8-15, one byte each
+        if (ABLATE & 4) {
 #pragma unroll
-    for (int r = 0; r < kSortKeysPerThread; ++r) {
-        const uint32_t idx = base + r * 64;
-        if (idx < e) atomicAdd(&s_cnt[wave][digit_of(w[r], sh)], 1u);   // LDS, order-free
-    }
-    __syncthreads();
-    if (tid < kBins) {
-        uint32_t t = 0;
+            for (int r = 0; r < kCountVec; ++r) c0 += v[r].x ^ v[r].y ^ v[r].z ^ v[r].w;
+        } else
 #pragma unroll
-        for (int k = 0; k < kSortWaves; ++k) t += s_cnt[k][tid];
-        table[tid * G + grp] = t;                                  // RadixSortCount.comp:89, bin-major
-        if (t) atomicAdd(&seg_sum[tid * S + grp / kSegGroups], t); // Reduce
+        for (int r = 0; r < kCountVec; ++r) {
+            const uint32_t k[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t d = digit_of(k[q], sh);
+                const bool ok = full || tile_base + (uint32_t)(r * kSortThreads + tid) * 4u + q < e;
+                const uint64_t inc = ok ? 1ull << ((d & 7u) * 8u) : 0ull;
+                c0 += (d & 8u) ? 0ull : inc;
+                c1 += (d & 8u) ? inc : 0ull;
+            }
+        }
+        // widen to 16-bit fields: a[0] = digits 0,2,4,6; a[1] = 1,3,5,7; a[2] = 8,10,12,14; a[3] = 9,...,15
+        const uint64_t m = 0x00FF00FF00FF00FFull;
+        uint64_t a[4] = {c0 & m, (c0 >> 8) & m, c1 & m, (c1 >> 8) & m};
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t lo = __shfl_xor((uint32_t)a[q], off, 64);
+                const uint32_t hi = __shfl_xor((uint32_t)(a[q] >> 32), off, 64);
+                a[q] += ((uint64_t)hi << 32) | lo;
+            }
+        if (lane < kBins) {   // lane d extracts digit d
+            const uint64_t r = (lane & 8) ? ((lane & 1) ? a[3] : a[2]) : ((lane & 1) ? a[1] : a[0]);
+            s_cnt[it][wave][lane] = (uint32_t)(r >> (((lane & 7) >> 1) * 16)) & 0xFFFFu;
+        }
+        __syncthreads();   // s_cnt is double-buffered, so one barrier per group is enough
+        if (tid < kBins) {
+            uint32_t t = 0;
+#pragma unroll
+            for (int k = 0; k < kSortWaves; ++k) t += s_cnt[it][k][tid];
+            if (!(ABLATE & 2) || t == 0xFFFFFFFFu) table[tid * G + grp] = t; // RadixSortCount.comp:89, bin-major
+            seg_total += t;
+        }
     }
+    if (tid < kBins) seg_sum[tid * kSegments + blockIdx.x] = seg_total;   // Reduce (zero for empty segments)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Scan + ScanAdd (prologue) + Scatter
+// Scan: exclusive scan of seg_sum[16][1024] in bin-major order, in place; one workgroup of 1024
+// threads, thread t owns the 16 consecutive entries [16t, 16t+16) (four 16-byte loads).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSortThreads) void k_scatter(
+__global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ seg_sum) {
+    __shared__ uint32_t s_wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint4* p = reinterpret_cast<uint4*>(seg_sum) + tid * 4;
+    uint4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = p[q];
+    uint32_t x[16] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
+                      v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+    uint32_t run = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const uint32_t t = x[q]; x[q] = run; run += t; }
+    const uint32_t inc = wave_inclusive_scan(run);
+    if (lane == 63) s_wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t base = inc - run;
+    for (int w = 0; w < wave; ++w) base += s_wave_tot[w];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        p[q] = make_uint4(x[4 * q] + base, x[4 * q + 1] + base, x[4 * q + 2] + base, x[4 * q + 3] + base);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scan + ScanAdd (prologue) + Scatter.  Persistent workgroups, next group's keys prefetched into
+// registers while the current group is ranked, staged and stored.
+// ---------------------------------------------------------------------------------------------
+struct ScatterKeys {
+    uint32_t lo[kSortKeysPerThread], hi[kSortKeysPerThread], id[kSortKeysPerThread];
+};
+
+__device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
+                                             const uint32_t* __restrict__ in_hi,
+                                             const uint32_t* __restrict__ in_id, uint32_t base,
+                                             uint32_t e, ScatterKeys& k) {
+#pragma unroll
+    for (int r = 0; r < kSortKeysPerThread; ++r) {   // coalesced: 256 contiguous bytes per wave-instruction
+        const uint32_t idx = base + r * 64;
+        const bool ok = idx < e;
+        k.lo[r] = ok ? in_lo[idx] : 0xFFFFFFFFu;
+        k.hi[r] = ok ? in_hi[idx] : 0xFFFFFFFFu;
+        k.id[r] = ok ? in_id[idx] : 0u;
+    }
+}
+
+#ifndef GS_SCATTER_MINWAVES
+#define GS_SCATTER_MINWAVES 3
+#endif
+__global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
     const SortParams* __restrict__ params, const uint32_t* __restrict__ in_lo,
     const uint32_t* __restrict__ in_hi, const uint32_t* __restrict__ in_id,
     uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_hi, uint32_t* __restrict__ out_id,
-    const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_sum, uint32_t shift) {
+    const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base, uint32_t shift) {
     __shared__ uint32_t s_lo[kSortTile];
     __shared__ uint32_t s_hi[kSortTile];
     __shared__ uint32_t s_id[kSortTile];
     __shared__ uint32_t s_wcnt[kSortWaves][kBins];
     __shared__ uint32_t s_wbase[kSortWaves][kBins];
-    __shared__ uint32_t s_dtot[kBins];   // Scan: total keys per digit over the whole list
-    __shared__ uint32_t s_gpre[kBins];   // Scan+ScanAdd: keys of digit d in groups before this one
+    __shared__ uint32_t s_gpre[kBins];   // ScanAdd: global index of the first key of digit d of this group
     __shared__ int32_t s_gbase[kBins];
 
-    const uint32_t e = params->num_elems, G = params->num_groups, S = params->num_segments;
-    const uint32_t grp = blockIdx.x;
+    const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
+    uint32_t grp = blockIdx.x;
     if (grp >= G) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool use_hi = shift >= 32u;
     const uint32_t sh = shift & 31u;
-    const uint32_t tile_base = grp * kSortTile;
-    const uint32_t base = tile_base + (uint32_t)wave * (kSortKeysPerThread * 64) + lane;
+    const uint32_t wave_off = (uint32_t)wave * (kSortKeysPerThread * 64) + lane;
 
-    // ---- load (coalesced: each wave-instruction reads 256 contiguous bytes per array)
-    uint32_t lo[kSortKeysPerThread], hi[kSortKeysPerThread], id[kSortKeysPerThread];
-#pragma unroll
-    for (int r = 0; r < kSortKeysPerThread; ++r) {
-        const uint32_t idx = base + r * 64;
-        const bool ok = idx < e;
-        lo[r] = ok ? in_lo[idx] : 0xFFFFFFFFu;
-        hi[r] = ok ? in_hi[idx] : 0xFFFFFFFFu;
-        id[r] = ok ? in_id[idx] : 0u;
-    }
+    ScatterKeys nxt;
+    scatter_load(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, nxt);
 
-    // ---- Scan + ScanAdd: wave w owns digits 4w..4w+3
-    {
-        const uint32_t seg = grp / kSegGroups, j = grp - seg * kSegGroups;
+    for (; grp < G; grp += gridDim.x) {
+        ScatterKeys k = nxt;
+        if (grp + gridDim.x < G)
+            scatter_load(in_lo, in_hi, in_id, (grp + gridDim.x) * kSortTile + wave_off, e, nxt); // prefetch
+        const uint32_t tile_base = grp * kSortTile;
+        const uint32_t base = tile_base + wave_off;
+
+        // ---- ScanAdd: keys of digit d in all groups before this one = scanned segment base +
+        //      counts of the earlier groups of the same segment (wave w: digits 4w..4w+3)
+        {
+            const uint32_t seg = grp / K, j = grp - seg * K;   // j < K <= 64
 #pragma unroll
-        for (int q = 0; q < kBins / kSortWaves; ++q) {
-            const int d = wave * (kBins / kSortWaves) + q;
-            uint32_t tot = 0, pre = 0;
-            for (uint32_t s0 = 0; s0 < S; s0 += 64) {
-                const uint32_t s = s0 + lane;
-                const uint32_t v = s < S ? seg_sum[d * S + s] : 0u;
-                tot += v;
-                pre += s < seg ? v : 0u;
+            for (int q = 0; q < kBins / kSortWaves; ++q) {
+                const int d = wave * (kBins / kSortWaves) + q;
+                uint32_t pre = (uint32_t)lane < j ? table[d * G + seg * K + lane] : 0u;
+                pre = wave_reduce_add(pre);
+                if (lane == 0) s_gpre[d] = pre + seg_base[d * kSegments + seg];
             }
-            const uint32_t gi = seg * kSegGroups + lane;
-            pre += ((uint32_t)lane < j && gi < G) ? table[d * G + gi] : 0u;
-            tot = wave_reduce_add(tot);
-            pre = wave_reduce_add(pre);
-            if (lane == 0) { s_dtot[d] = tot; s_gpre[d] = pre; }
         }
-    }
 
-    // ---- stable rank inside the wave.  Per round: 4 ballots give every lane the mask of lanes
-    //      holding the same digit; lane d (d < 16) keeps the wave's running count of digit d.
-    uint32_t rank[kSortKeysPerThread];
-    uint32_t cntreg = 0;
+        // ---- stable rank inside the wave.  Per round: 4 ballots give every lane the mask of lanes
+        //      holding the same digit; lane d (d < 16) keeps the wave's running count of digit d.
+        uint32_t rank[kSortKeysPerThread];
+        uint32_t cntreg = 0;
 #pragma unroll
-    for (int r = 0; r < kSortKeysPerThread; ++r) {
-        const uint32_t idx = base + r * 64;
-        const bool ok = idx < e;
-        const uint32_t dg = digit_of(use_hi ? hi[r] : lo[r], sh);
-        uint64_t mask = __ballot(ok);
+        for (int r = 0; r < kSortKeysPerThread; ++r) {
+            const uint32_t idx = base + r * 64;
+            const bool ok = idx < e;
+            const uint32_t dg = digit_of(use_hi ? k.hi[r] : k.lo[r], sh);
+            uint64_t mask = __ballot(ok);
 #pragma unroll
-        for (int b = 0; b < kRadixBits; ++b) {
-            const bool bit = (dg >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            mask &= bit ? bal : ~bal;
+            for (int b = 0; b < kRadixBits; ++b) {
+                const bool bit = (dg >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                mask &= bit ? bal : ~bal;
+            }
+            mask = ok ? mask : 0ull;
+            const uint32_t in_round = mbcnt(mask);
+            const uint32_t n_round = (uint32_t)__popcll(mask);
+            const uint32_t before = (uint32_t)__shfl((int)cntreg, (int)dg, 64);
+            rank[r] = before + in_round;
+            // the first lane of every digit group sends the group's size to counter lane `dg`;
+            // everybody else sends to lane 63, which holds no counter
+            const bool leader = ok && in_round == 0u;
+            const int dest = leader ? (int)dg : 63;
+            const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)n_round);
+            cntreg += lane < kBins ? recv : 0u;
         }
-        mask = ok ? mask : 0ull;
-        const uint32_t in_round = mbcnt(mask);
-        const uint32_t n_round = (uint32_t)__popcll(mask);
-        const uint32_t before = (uint32_t)__shfl((int)cntreg, (int)dg, 64);
-        rank[r] = before + in_round;
-        // the first lane of every digit group sends the group's size to counter lane `dg`;
-        // everybody else sends to lane 63, which holds no counter
-        const bool leader = ok && in_round == 0u;
-        const int dest = leader ? (int)dg : 63;
-        const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)n_round);
-        cntreg += lane < kBins ? recv : 0u;
-    }
-    if (lane < kBins) s_wcnt[wave][lane] = cntreg;
-    __syncthreads();
+        if (lane < kBins) s_wcnt[wave][lane] = cntreg;
+        __syncthreads();
 
-    // ---- local digit starts, per-wave bases, global base (threads 0..15, one per digit)
-    if (tid < kBins) {
-        uint32_t c[kSortWaves];
-        uint32_t tot = 0;
+        // ---- local digit starts, per-wave bases, global base (threads 0..15, one per digit)
+        if (tid < kBins) {
+            uint32_t c[kSortWaves];
+            uint32_t tot = 0;
 #pragma unroll
-        for (int k = 0; k < kSortWaves; ++k) { c[k] = s_wcnt[k][tid]; tot += c[k]; }
-        uint32_t inc = tot, ginc = s_dtot[tid];
+            for (int w = 0; w < kSortWaves; ++w) { c[w] = s_wcnt[w][tid]; tot += c[w]; }
+            uint32_t inc = tot;
 #pragma unroll
-        for (int off = 1; off < kBins; off <<= 1) {
-            const uint32_t t = __shfl_up(inc, off, 64);
-            const uint32_t gt = __shfl_up(ginc, off, 64);
-            if (tid >= off) { inc += t; ginc += gt; }
+            for (int off = 1; off < kBins; off <<= 1) {
+                const uint32_t t = __shfl_up(inc, off, 64);
+                if (tid >= off) inc += t;
+            }
+            const uint32_t dstart = inc - tot;       // first local position of digit d
+            uint32_t run = dstart;
+#pragma unroll
+            for (int w = 0; w < kSortWaves; ++w) { s_wbase[w][tid] = run; run += c[w]; }
+            s_gbase[tid] = (int32_t)(s_gpre[tid] - dstart); // global = s_gbase[d] + local pos
         }
-        const uint32_t dstart = inc - tot;              // first local position of digit d
-        const uint32_t gstart = ginc - s_dtot[tid];     // first global index of digit d
-        uint32_t run = dstart;
-#pragma unroll
-        for (int k = 0; k < kSortWaves; ++k) { s_wbase[k][tid] = run; run += c[k]; }
-        s_gbase[tid] = (int32_t)(gstart + s_gpre[tid] - dstart); // global = s_gbase[d] + local pos
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- local sort into LDS
+        // ---- local sort into LDS
 #pragma unroll
-    for (int r = 0; r < kSortKeysPerThread; ++r) {
-        const uint32_t idx = base + r * 64;
-        if (idx < e) {
-            const uint32_t dg = digit_of(use_hi ? hi[r] : lo[r], sh);
-            const uint32_t p = s_wbase[wave][dg] + rank[r];
-            s_lo[p] = lo[r];
-            s_hi[p] = hi[r];
-            s_id[p] = id[r];
+        for (int r = 0; r < kSortKeysPerThread; ++r) {
+            const uint32_t idx = base + r * 64;
+            if (idx < e) {
+                const uint32_t dg = digit_of(use_hi ? k.hi[r] : k.lo[r], sh);
+                const uint32_t p = s_wbase[wave][dg] + rank[r];
+                s_lo[p] = k.lo[r];
+                s_hi[p] = k.hi[r];
+                s_id[p] = k.id[r];
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- run-wise coalesced stores: consecutive local positions of one digit are consecutive
-    //      global indices (RadixSortScatter.comp:153-168)
-    const uint32_t valid = (e - tile_base) < (uint32_t)kSortTile ? (e - tile_base) : (uint32_t)kSortTile;
+        // ---- run-wise coalesced stores: consecutive local positions of one digit are consecutive
+        //      global indices (RadixSortScatter.comp:153-168)
+        const uint32_t valid = (e - tile_base) < (uint32_t)kSortTile ? (e - tile_base) : (uint32_t)kSortTile;
 #pragma unroll
-    for (int r = 0; r < kSortKeysPerThread; ++r) {
-        const uint32_t p = (uint32_t)r * kSortThreads + tid;
-        if (p < valid) {
-            const uint32_t l = s_lo[p], h = s_hi[p];
-            const uint32_t d = digit_of(use_hi ? h : l, sh);
-            const uint32_t o = (uint32_t)(s_gbase[d] + (int32_t)p);
-            out_lo[o] = l;
-            out_hi[o] = h;
-            out_id[o] = s_id[p];
+        for (int r = 0; r < kSortKeysPerThread; ++r) {
+            const uint32_t p = (uint32_t)r * kSortThreads + tid;
+            if (p < valid) {
+                const uint32_t l = s_lo[p], h = s_hi[p];
+                const uint32_t d = digit_of(use_hi ? h : l, sh);
+                const uint32_t o = (uint32_t)(s_gbase[d] + (int32_t)p);
+                out_lo[o] = l;
+                out_hi[o] = h;
+                out_id[o] = s_id[p];
+            }
         }
+        __syncthreads();   // LDS is reused by the next group
     }
 }
 
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events) {
     const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
-    const uint32_t max_segments = (max_groups + kSegGroups - 1) / kSegGroups;
-    const uint32_t passes = (num_sort_bits + kRadixBits - 1) / kRadixBits;
-    // one zeroed seg_sum slice per pass (role of gpuClearBuffers, RadixSort.cpp:676-692)
-    (void)hipMemsetAsync(sb.seg_sum, 0, (size_t)passes * kBins * max_segments * sizeof(uint32_t), stream);
+    const uint32_t sgrid = max_groups < (uint32_t)GS_SCATTER_GRID ? max_groups : (uint32_t)GS_SCATTER_GRID;
     int src = 0;
     uint32_t pass = 0;
     for (uint32_t shift = 0; shift < num_sort_bits; shift += kRadixBits, ++pass) { // RadixSort.cpp:309
         const int dst = src ^ 1;
         const uint32_t* word = shift >= 32u ? sb.hi[src] : sb.lo[src];
-        uint32_t* seg = sb.seg_sum + (size_t)pass * kBins * max_segments;
-        hipLaunchKernelGGL(k_count, dim3(max_groups), dim3(kSortThreads), 0, stream, sb.params,
-                           word, sb.table, seg, shift & 31u);
+        hipLaunchKernelGGL(k_count<0>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
+                           word, sb.table, sb.seg_sum, shift & 31u);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, sb.seg_sum);
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass], stream);
-        hipLaunchKernelGGL(k_scatter, dim3(max_groups), dim3(kSortThreads), 0, stream, sb.params,
+        hipLaunchKernelGGL(k_scatter, dim3(sgrid), dim3(kSortThreads), 0, stream, sb.params,
                            sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],
-                           sb.table, seg, shift);
+                           sb.table, sb.seg_sum, shift);
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass + 1], stream);
         src = dst;                                                            // RadixSort.cpp:638-641
     }
@@ -241,7 +341,7 @@ __global__ void k_set_sort_params(SortParams* params, uint32_t n) {
     params->counter = n;
     params->num_elems = n;
     params->num_groups = (n + kSortTile - 1) / kSortTile;
-    params->num_segments = (params->num_groups + kSegGroups - 1) / kSegGroups;
+    params->groups_per_seg = (params->num_groups + kSegments - 1) / kSegments;
     params->overflow = 0;
 }
 
@@ -270,6 +370,15 @@ __global__ void k_check_sorted(const uint32_t* lo, const uint32_t* hi, uint32_t 
         local += a > b ? 1u : 0u;
     }
     if (local) atomicAdd(bad, local);
+}
+
+void launch_count_ablate(int ablate, const SortBuffers& sb, uint32_t capacity, uint32_t grid, hipStream_t stream) {
+    (void)capacity; (void)grid;
+    switch (ablate) {
+        case 0: hipLaunchKernelGGL(k_count<0>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u); break;
+        case 3: hipLaunchKernelGGL(k_count<2>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u); break;
+        default: hipLaunchKernelGGL(k_count<6>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u); break;
+    }
 }
 
 void launch_set_sort_params(SortParams* params, uint32_t n, hipStream_t stream) {

@@ -40,3 +40,38 @@ void launch_aos_to_soa(const float* chunk, uint32_t first, uint32_t count, uint3
 }
 
 } // namespace gs
+
+// ---------------------------------------------------------------------------------------------
+// Stream bandwidth probes: the "measured HBM roofline" denominator of north_star (device-to-device
+// copy on the same MI355X) and the small-buffer regime the per-pass sort kernels live in.
+// ---------------------------------------------------------------------------------------------
+namespace gs {
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_stream_copy(const T* __restrict__ src, T* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_stream_read(const T* __restrict__ src, uint32_t* __restrict__ sink, size_t n) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const T v = src[i];
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(T) / 4); ++k) acc ^= w[k];
+    }
+    if (acc == 0x9E3779B9u) sink[0] = acc;   // keeps the loads alive, practically never taken
+}
+
+void launch_stream_probe(int kind, const void* src, void* dst, size_t bytes, uint32_t blocks, hipStream_t stream) {
+    switch (kind) {
+        case 0: hipLaunchKernelGGL(k_stream_read<uint4>, dim3(blocks), dim3(256), 0, stream, (const uint4*)src, (uint32_t*)dst, bytes / 16); break;
+        case 1: hipLaunchKernelGGL(k_stream_copy<uint4>, dim3(blocks), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, bytes / 16); break;
+        case 2: hipLaunchKernelGGL(k_stream_read<uint32_t>, dim3(blocks), dim3(256), 0, stream, (const uint32_t*)src, (uint32_t*)dst, bytes / 4); break;
+        default: hipLaunchKernelGGL(k_stream_copy<uint32_t>, dim3(blocks), dim3(256), 0, stream, (const uint32_t*)src, (uint32_t*)dst, bytes / 4); break;
+    }
+}
+
+} // namespace gs
