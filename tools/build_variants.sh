@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../vk3dgaussiansplatting_amd/csrc"
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
   make clean >/dev/null
-  make -j8 EXTRA="$flags" LIBNAME=../../build_variants/lib_$name.so 2>&1 | grep -E "error|warning" || true
+  make -j8 EXTRA="$flags" LIBNAME=../../build_variants/lib_$name.so ../../build_variants/lib_$name.so 2>&1 | grep -E "error|warning" || true
 done
 make clean >/dev/null
 make -j8 2>&1 | grep -E "error|warning" || true

@@ -1,0 +1,106 @@
+// gsplat_bench -- C++ caller of the C-ABI that mirrors the reference's main loop
+// (Main.cpp:11-31 -> Engine::init, Engine/Engine.cpp:32-85): create, load the scene, set the
+// scene's benchmark camera, warm up, then average the five GPU timing buckets the way
+// Renderer.cpp:477-510 does, and print them.
+//
+//   gsplat_bench <scene.ply | --synthetic N> [--scene garden|train|bicycle|origin] [--res WxH]
+//                [--warmup F] [--frames F] [--fast] [--ppm out.ppm]
+#include "../include/gsplat.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static uint64_t sm(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static float uni(uint64_t& s) { return (float)((sm(s) >> 40) * (1.0 / 16777216.0)); }
+
+int main(int argc, char** argv) {
+    std::string ply, scene = "origin", ppm;
+    uint32_t n_syn = 0, w = 1280, h = 720, warmup = 100, frames = 1000;   // window 1280x720: Engine.cpp:35
+    bool fast = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "--synthetic" && i + 1 < argc) n_syn = (uint32_t)atol(argv[++i]);
+        else if (a == "--scene" && i + 1 < argc) scene = argv[++i];
+        else if (a == "--res" && i + 1 < argc) sscanf(argv[++i], "%ux%u", &w, &h);
+        else if (a == "--warmup" && i + 1 < argc) warmup = (uint32_t)atol(argv[++i]);
+        else if (a == "--frames" && i + 1 < argc) frames = (uint32_t)atol(argv[++i]);
+        else if (a == "--ppm" && i + 1 < argc) ppm = argv[++i];
+        else if (a == "--fast") fast = true;
+        else ply = a;
+    }
+    if (ply.empty() && !n_syn) { fprintf(stderr, "usage: gsplat_bench <scene.ply | --synthetic N> [...]\n"); return 2; }
+
+    gs_config cfg; gs_default_config(&cfg);
+    cfg.render_mode = fast ? GS_RENDER_FAST : GS_RENDER_EXACT;
+    gs_ctx* ctx = nullptr;
+    if (gs_create(&cfg, &ctx) != GS_OK) { fprintf(stderr, "[Log Error]: %s\n", gs_last_error(nullptr)); return 1; }
+
+    if (!ply.empty()) {                                     // Scene::init -> ResourceManager::loadGaussians
+        int rc = gs_load_ply(ctx, ply.c_str());
+        if (rc != GS_OK) { fprintf(stderr, "[Log Error]: %s (%d)\n", gs_ply_last_error(), rc); return 1; }
+    } else {                                                // simple cloud in front of an origin camera
+        std::vector<float> rec((size_t)n_syn * 84, 0.0f);
+        uint64_t s = 20240807;
+        const float aspect = (float)w / (float)h;
+        for (uint32_t i = 0; i < n_syn; ++i) {
+            float* g = &rec[(size_t)i * 84];
+            const float d = 0.5f + 19.5f * uni(s);
+            g[0] = d * aspect * (-1.5f + 3.0f * uni(s)); g[1] = d * (-1.5f + 3.0f * uni(s)); g[2] = d;
+            for (int a = 0; a < 3; ++a) g[4 + a] = std::exp(-4.0f + 1.2f * (uni(s) - 0.5f));
+            float q[4], l = 0; for (int a = 0; a < 4; ++a) { q[a] = uni(s) - 0.5f; l += q[a] * q[a]; }
+            l = 1.0f / std::sqrt(l + 1e-12f); for (int a = 0; a < 4; ++a) g[8 + a] = q[a] * l;
+            for (int c = 0; c < 3; ++c) g[12 + c] = -1.5f + 3.0f * uni(s);
+            g[15] = 1.0f / (1.0f + std::exp(2.0f - 6.0f * uni(s)));
+            for (int k = 16; k < 76; ++k) if ((k & 3) != 3) g[k] = 0.1f * (uni(s) - 0.5f);
+        }
+        if (gs_upload_gaussians(ctx, rec.data(), n_syn) != GS_OK) { fprintf(stderr, "[Log Error]: %s\n", gs_last_error(ctx)); return 1; }
+    }
+    if (gs_set_resolution(ctx, w, h) != GS_OK) { fprintf(stderr, "[Log Error]: %s\n", gs_last_error(ctx)); return 1; }
+
+    // "Camera for benchmarks" poses: GardenScene.cpp:11-12, TrainScene.cpp:11-12, BicycleScene.cpp:11-12
+    float pos[3] = {0, 0, 0}, yaw = 0, pitch = 0;
+    if (scene == "garden") { pos[0] = -0.620010f; pos[1] = 0.189628f; pos[2] = 2.271181f; yaw = 2.971590f; pitch = -1.074159f; }
+    else if (scene == "train") { pos[0] = -2.857887f; pos[1] = 0.188856f; pos[2] = 1.048745f; yaw = 1.361593f; pitch = 0.005841f; }
+    else if (scene == "bicycle") { pos[0] = 0.945927f; pos[1] = -0.294418f; pos[2] = -0.181088f; yaw = -1.108407f; pitch = -0.324159f; }
+    float view[16], proj[16];
+    gs_camera_matrices(pos, yaw, pitch, (float)w / (float)h, cfg.near_plane, cfg.far_plane, view, proj);
+
+    gs_scene_info info; gs_get_scene_info(ctx, &info);
+    printf("[Log]: Number of gaussians: %u   sort list capacity: %u   passes: %u\n", info.num_gaussians, info.capacity, info.num_sort_bits / 4);
+    double avg[5] = {0, 0, 0, 0, 0};
+    gs_timings t{};
+    for (uint32_t f = 0; f < warmup + frames; ++f) {        // Engine.cpp:45-78 / Renderer.cpp:477-488
+        int rc = gs_render_device(ctx, view, proj, pos, 0, nullptr);
+        if (rc < 0) { fprintf(stderr, "[Log Error]: %s\n", gs_last_error(ctx)); return 1; }
+        gs_get_timings(ctx, &t);
+        if (f >= warmup) {
+            const double k = 1.0 / (double)(f - warmup + 1);
+            const double v[5] = {t.init_sort_list_ms, t.radix_sort_ms, t.find_ranges_ms, t.render_ms, t.total_ms};
+            for (int b = 0; b < 5; ++b) avg[b] = (1.0 - k) * avg[b] + k * v[b];
+        }
+    }
+    printf("elements to sort: %u%s\n", t.num_sort_elements, t.overflowed ? " (overflowed, truncated)" : "");
+    printf("init sort list ms: %.3f\nsort ms: %.3f\nfind ranges ms: %.3f\nrender gaussians ms: %.3f\ntotal gpu time ms: %.3f\n",
+           avg[0], avg[1], avg[2], avg[3], avg[4]);
+    printf("Msplats/s: %.1f\n", info.num_gaussians / avg[4] / 1000.0);
+    if (!ppm.empty()) {
+        std::vector<uint8_t> img((size_t)w * h * 4);
+        gs_debug_read(ctx, GS_BUF_IMAGE, img.data(), img.size());
+        if (FILE* fp = fopen(ppm.c_str(), "wb")) {
+            fprintf(fp, "P6\n%u %u\n255\n", w, h);
+            for (size_t p = 0; p < (size_t)w * h; ++p) fwrite(&img[p * 4], 1, 3, fp);
+            fclose(fp);
+        }
+    }
+    gs_destroy(ctx);
+    return 0;
+}
