@@ -52,8 +52,12 @@ def assert_frame_equals_oracle(r, img, ref, exact_pixels=True):
     assert np.array_equal(r.debugRead(gs.BUF_SORTED_DEPTH), ref["depth"][:e])
     assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), ref["id"][:e])
     assert np.array_equal(r.debugRead(gs.BUF_RANGES), ref["ranges"])
-    assert np.array_equal(r.debugRead(gs.BUF_COLOR).view(np.uint32), ref["stage1"]["color"].view(np.uint32))
+    # covariance: every non-culled splat; colour: every splat that emits at least one element (the
+    # product skips the SH evaluation of splats no tile will ever read)
     assert np.array_equal(r.debugRead(gs.BUF_COV).view(np.uint32), ref["stage1"]["cov"].view(np.uint32))
+    emits = np.zeros(ref["stage1"]["color"].shape[0], bool)
+    emits[ref["id"][:e]] = True
+    assert np.array_equal(r.debugRead(gs.BUF_COLOR)[emits].view(np.uint32), ref["stage1"]["color"][emits].view(np.uint32))
     if exact_pixels:
         assert np.array_equal(img, ref["image"])
     else:
@@ -96,7 +100,9 @@ def test_golden_fixture(sh_mode):
         assert np.array_equal(r.debugRead(gs.BUF_UNSORTED_TILE), g["unsorted_tile"])
         assert np.array_equal(r.debugRead(gs.BUF_UNSORTED_DEPTH), g["unsorted_depth"])
         assert np.array_equal(r.debugRead(gs.BUF_UNSORTED_ID), g["unsorted_id"])
-    assert np.array_equal(r.debugRead(gs.BUF_COLOR).view(np.uint32), g[f"color_mode{sh_mode}"].view(np.uint32))
+    emits = np.zeros(g["aos"].shape[0], bool)
+    emits[g["id"]] = True
+    assert np.array_equal(r.debugRead(gs.BUF_COLOR)[emits].view(np.uint32), g[f"color_mode{sh_mode}"][emits].view(np.uint32))
     assert np.array_equal(img, g[f"image_mode{sh_mode}"])
     r.cleanup()
 

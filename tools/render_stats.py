@@ -1,0 +1,24 @@
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import vk3dgaussiansplatting_amd as gs
+from vk3dgaussiansplatting_amd import synth, _lib
+name = sys.argv[1] if len(sys.argv) > 1 else "C"
+aos, cfg = synth.generate_config(name)
+w, h = cfg["width"], cfg["height"]
+rm = gs.ResourceManager(); rm.setGaussians(aos)
+sc = gs.Scene(rm, aspect_ratio=w / h); cam = sc.getCamera(); cam.setPosition((0, 0, 0)); cam.setRotation(0, 0); cam.recalculate()
+r = gs.Renderer(w, h, warmup_frames=0); r.init(rm); r.initForScene(sc)
+r.drawDevice(sc)
+info = r.sceneInfo(); T = info.tiles_x * info.tiles_y
+out = np.zeros((T, 4), np.uint32)
+L = _lib.lib(); L.gs_debug_render_stats.argtypes = [C.c_void_p] * 5
+p = lambda a: a.ctypes.data_as(C.c_void_p)
+rc = L.gs_debug_render_stats(r._ctx.handle, p(cam.getViewMatrix()), p(cam.getProjectionMatrix()), p(cam.getPosition()), p(out))
+ln, vis, need, ticks = (out[:, i].astype(np.float64) for i in range(4))
+print("rc", rc, "tiles", T, "E", ln.sum())
+print("list length  mean %.0f max %.0f" % (ln.mean(), ln.max()))
+print("visited      mean %.0f max %.0f  total/E %.3f" % (vis.mean(), vis.max(), vis.sum() / ln.sum()))
+print("need exp     mean %.0f max %.0f  total/visited %.3f" % (need.mean(), need.max(), need.sum() / max(vis.sum(), 1)))
+print("ticks (100MHz?) mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (ticks.mean(), *np.percentile(ticks, [50, 90, 99]), ticks.max()))
+print("ticks per visited splat: %.1f" % (ticks.sum() / vis.sum()))

@@ -310,8 +310,12 @@ int gs_upload_gaussians(gs_ctx* c, const void* aos336, uint32_t n) {
     HIP_TRY(c, hipMalloc((void**)&c->scratch.tiles_touched, N * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void**)&c->scratch.extents, N * sizeof(uint2)));
     c->num_blocks = (n + kProjThreads - 1) / kProjThreads;
-    HIP_TRY(c, hipMalloc((void**)&c->scratch.block_sums, (size_t)c->num_blocks * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void**)&c->scratch.block_offsets, (size_t)c->num_blocks * sizeof(uint32_t)));
+    // k_scan_blocks reads/writes whole 16-byte groups up to 1024 * per entries: zero-padded
+    const size_t padded = (size_t)c->num_blocks + 8192;
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.block_sums, padded * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.block_offsets, padded * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->scratch.block_sums, 0, padded * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->scratch.block_offsets, 0, padded * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->scratch.raster, 0, N * sizeof(SplatRaster), c->stream));
 
     // AoS -> SoA on the device, through a bounded staging buffer
@@ -605,6 +609,24 @@ int gs_sort_bench(gs_ctx* c, uint32_t n, uint32_t num_tiles, uint32_t iters, uin
     if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_sort_bench: ") + hipGetErrorString(e));
     *ms_per_sort = total_ms / (float)iters;
     if (sorted_ok) *sorted_ok = bad_host == 0 ? 1u : 0u;
+    return GS_OK;
+}
+
+// Tuning only (not declared in gsplat.h): re-runs RenderGaussians of the last frame with per-tile
+// counters; out = uint32[tiles][4] {list length, splats visited, splats needing exp, clock ticks}.
+int gs_debug_render_stats(gs_ctx* c, const float* view, const float* proj, const float* cam_pos, uint32_t* out) {
+    if (!c || !out || !c->have_frame) return GS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const FrameParams fp = make_frame_params(c, view, proj, cam_pos, 0);
+    const size_t tiles = (size_t)c->grid_w * c->grid_h;
+    uint4* d = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d, tiles * sizeof(uint4)));
+    HIP_TRY(c, hipMemsetAsync(d, 0, tiles * sizeof(uint4), c->stream));
+    launch_render_stats(fp, c->scratch.raster, c->sort.id[c->sorted_index], c->ranges, c->framebuffer, d, c->stream);
+    hipError_t e = hipMemcpyAsync(out, d, tiles * sizeof(uint4), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_debug_render_stats: ") + hipGetErrorString(e));
     return GS_OK;
 }
 

@@ -114,6 +114,8 @@ void launch_aos_to_soa(const float* chunk, uint32_t first, uint32_t count, uint3
                        const SceneBuffers& s, hipStream_t stream);
 void launch_stream_probe(int kind, const void* src, void* dst, size_t bytes, uint32_t blocks, hipStream_t stream);
 void launch_count_ablate(int ablate, const SortBuffers& sb, uint32_t capacity, uint32_t grid, hipStream_t stream);
+void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
+                         const uint32_t* ranges, uint8_t* rgba, uint4* stats, hipStream_t stream);
 // helpers for the stand-alone sorter entry points
 void launch_set_sort_params(SortParams* params, uint32_t n, hipStream_t stream);
 void launch_fill_random_keys(uint32_t* lo, uint32_t* hi, uint32_t* id, uint32_t n,

@@ -208,51 +208,58 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
                 const int max_x = clampi(tx == 2147483647 ? tx : tx + 1, 0, gw);
                 const int max_y = clampi(ty == 2147483647 ? ty : ty + 1, 0, gh);
 
-                // colour, InitSortList.comp:124-126 + Common.glsl:141-170
-                const float ddx = px - fp.cam_pos[0], ddy = py - fp.cam_pos[1], ddz = pz - fp.cam_pos[2];
-                const float len = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
-                float basis[16];
-                sh_eval4(ddx / len, ddy / len, ddz / len, basis);
-                float res[3] = {0.0f, 0.0f, 0.0f};
-                const float* shp = scene.sh + g;
-                if (fp.sh_mode == 0u) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            res[c] = res[c] + shp[(size_t)(i * 3 + c) * n] * basis[i];
-                } else if (fp.sh_mode == 1u) {
-#pragma unroll
-                    for (int i = 1; i < 16; ++i)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            res[c] = res[c] + shp[(size_t)(i * 3 + c) * n] * basis[i];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) res[c] = res[c] - 0.5f;
-                } else if (fp.sh_mode == 2u) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) res[c] = res[c] + shp[(size_t)c * n] * basis[0];
-                }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    res[c] = res[c] + 0.5f;
-                    res[c] = maxf(res[c], 0.0f);
-                }
-
-                // :126-127 stored for every non-culled splat, even with zero tiles (N6)
-                float4* rp = reinterpret_cast<float4*>(sc.raster + g);
-                rp[0] = make_float4(sx, sy, cov[0], cov[1]);
-                rp[1] = make_float4(cov[2], res[0], res[1], res[2]);
-                rp[2] = make_float4(scene.opacity[g], 0.0f, 0.0f, 0.0f);
-
                 // tile-row band of this context (multi-GPU); identity for [0, grid_h)
                 int y0 = min_y > (int)fp.row_begin ? min_y : (int)fp.row_begin;
                 int y1 = max_y < (int)fp.row_end ? max_y : (int)fp.row_end;
                 if (y1 < y0) y1 = y0;
                 count = (uint32_t)(max_x - min_x) * (uint32_t)(y1 - y0);   // :130
-                sc.depth_key[g] = depth_key;
-                sc.extents[g] = make_uint2((uint32_t)min_x | ((uint32_t)y0 << 16),
-                                           (uint32_t)max_x | ((uint32_t)y1 << 16));
+
+                // :126-127.  The reference stores colour + covariance for every non-culled splat (N6).
+                // Colour is only ever read by RenderGaussians through the sorted list, so for a splat
+                // that emits no element here (off-screen inside the 1.3 NDC cull margin, or outside this
+                // context's tile-row band) the 192-byte SH read and the colour evaluation are skipped:
+                // unobservable in keys, ranges and pixels (SURVEY "F" list).
+                float4* rp = reinterpret_cast<float4*>(sc.raster + g);
+                rp[0] = make_float4(sx, sy, cov[0], cov[1]);
+                if (count != 0u) {
+                    // colour, InitSortList.comp:124-126 + Common.glsl:141-170
+                    const float ddx = px - fp.cam_pos[0], ddy = py - fp.cam_pos[1], ddz = pz - fp.cam_pos[2];
+                    const float len = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+                    float basis[16];
+                    sh_eval4(ddx / len, ddy / len, ddz / len, basis);
+                    float res[3] = {0.0f, 0.0f, 0.0f};
+                    const float* shp = scene.sh + g;
+                    if (fp.sh_mode == 0u) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                res[c] = res[c] + shp[(size_t)(i * 3 + c) * n] * basis[i];
+                    } else if (fp.sh_mode == 1u) {
+#pragma unroll
+                        for (int i = 1; i < 16; ++i)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                res[c] = res[c] + shp[(size_t)(i * 3 + c) * n] * basis[i];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) res[c] = res[c] - 0.5f;
+                    } else if (fp.sh_mode == 2u) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) res[c] = res[c] + shp[(size_t)c * n] * basis[0];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        res[c] = res[c] + 0.5f;
+                        res[c] = maxf(res[c], 0.0f);
+                    }
+                    rp[1] = make_float4(cov[2], res[0], res[1], res[2]);
+                    rp[2] = make_float4(scene.opacity[g], 0.0f, 0.0f, 0.0f);
+                    sc.depth_key[g] = depth_key;
+                    sc.extents[g] = make_uint2((uint32_t)min_x | ((uint32_t)y0 << 16),
+                                               (uint32_t)max_x | ((uint32_t)y1 << 16));
+                } else {
+                    reinterpret_cast<float*>(rp + 1)[0] = cov[2];
+                }
             }
         }
         sc.tiles_touched[g] = count;
@@ -271,7 +278,9 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
 }
 
 // One workgroup of 1024 threads: exclusive scan of block_sums (u64 running total so an overflowing
-// scene is still counted correctly), then the IndirectSetup record.
+// scene is still counted correctly), then the IndirectSetup record.  Thread t owns the `per`
+// consecutive entries [t*per, t*per+per) (16-byte loads; the arrays are zero-padded to 1024*per
+// entries at upload): one pass to sum, one block scan, one pass to write -- no row-by-row carry chain.
 __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict__ block_sums,
                                                        uint32_t* __restrict__ block_offsets,
                                                        uint32_t num_blocks, uint32_t capacity,
@@ -279,24 +288,33 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict
     __shared__ uint64_t s_wave_tot[16];
     __shared__ uint64_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    // rows of 1024 consecutive entries: coalesced loads, carry propagated row to row
-    for (uint32_t base = 0; base < num_blocks; base += 1024) {
-        const uint32_t i = base + tid;
-        const uint64_t v = i < num_blocks ? block_sums[i] : 0u;
-        const uint64_t inc = wave_inclusive_scan64(v);
-        if (lane == 63) s_wave_tot[wave] = inc;
-        __syncthreads();
-        uint64_t wave_base = 0;
-        for (int w = 0; w < wave; ++w) wave_base += s_wave_tot[w];
-        const uint64_t carry = s_carry;
-        const uint64_t excl = carry + wave_base + inc - v;
-        if (i < num_blocks) block_offsets[i] = (uint32_t)(excl > 0xFFFFFFFFull ? 0xFFFFFFFFull : excl);
-        __syncthreads();
-        if (tid == 1023) s_carry = excl + v;
-        __syncthreads();
+    const uint32_t per = (((num_blocks + 1023u) / 1024u) + 3u) & ~3u;
+    const uint4* in4 = reinterpret_cast<const uint4*>(block_sums + (size_t)tid * per);
+    uint4* out4 = reinterpret_cast<uint4*>(block_offsets + (size_t)tid * per);
+    uint64_t sum = 0;
+#pragma unroll 4
+    for (uint32_t i = 0; i < per / 4; ++i) {
+        const uint4 v = in4[i];
+        sum += (uint64_t)v.x + v.y + v.z + v.w;
     }
+    const uint64_t inc = wave_inclusive_scan64(sum);
+    if (lane == 63) s_wave_tot[wave] = inc;
+    __syncthreads();
+    uint64_t run = inc - sum;
+    for (int w = 0; w < wave; ++w) run += s_wave_tot[w];
+    if (tid == 1023) s_carry = run + sum;
+    auto sat = [](uint64_t x) { return (uint32_t)(x > 0xFFFFFFFFull ? 0xFFFFFFFFull : x); };
+#pragma unroll 4
+    for (uint32_t i = 0; i < per / 4; ++i) {
+        const uint4 v = in4[i];
+        uint4 o;
+        o.x = sat(run); run += v.x;
+        o.y = sat(run); run += v.y;
+        o.z = sat(run); run += v.z;
+        o.w = sat(run); run += v.w;
+        out4[i] = o;
+    }
+    __syncthreads();
     if (tid == 0) {
         const uint64_t counter = s_carry;
         const uint32_t e = counter < capacity ? (uint32_t)counter : capacity; // IndirectSetup.comp:28

@@ -77,12 +77,14 @@ __device__ __forceinline__ Fetched fetch_splat(const SplatRaster* __restrict__ r
     return f;
 }
 
-template <bool EXACT>
+// STATS is a tuning-only instantiation (gs_debug_render_stats): per tile {list length, splats
+// visited, splats with any pixel needing exp, clock ticks}.  The product launches STATS = false.
+template <bool EXACT, bool STATS = false>
 __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
                                                 const SplatRaster* __restrict__ raster,
                                                 const uint32_t* __restrict__ sorted_id,
                                                 const uint32_t* __restrict__ ranges,
-                                                uint32_t* __restrict__ rgba) {
+                                                uint32_t* __restrict__ rgba, uint4* __restrict__ stats = nullptr) {
     // LDS image of the current batch: {sx, sy, inv.x, inv.y}, {inv.z, r, g, b}, {a, -, -, -}
     __shared__ float4 s_batch[64][3];
 
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
     const uint32_t py = ty * kTile + (uint32_t)(lane >> 2);
     const uint32_t px0 = tx * kTile + (uint32_t)(lane & 3) * 4u;
     const float fpy = (float)py;                                       // integer pixel coords (R1)
+    const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
     float fpx[4];
     float col[4][3];
     float T[4];
@@ -109,10 +112,15 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
         done[k] = !(px0 + k < fp.width && py < fp.height);             // never stored (:147)
     }
 
+    uint32_t st_visited = 0, st_need = 0;
+    const uint64_t st_t0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
     Fetched nxt = fetch_splat(raster, sorted_id, start + lane, end);
     for (uint32_t i = start; i < end; i += 64) {                       // :81
-        const uint32_t n = (end - i) < 64u ? (end - i) : 64u;
-        if (nxt.valid) {                                               // :86-108
+        // :86-108 per-splat setup, one splat per lane
+        bool keep = false;
+        float4 r0, r1, r2;
+        if (nxt.valid) {
+            const float sx = nxt.a.x, sy = nxt.a.y;
             const float cx = nxt.a.z, cy = nxt.a.w, cz = nxt.b.x;
             float alpha0 = nxt.c.x;
             const float det = cx * cz - cy * cy;                       // :96
@@ -125,9 +133,38 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
             } else {
                 alpha0 = 0.0f;                                         // :104
             }
-            s_batch[lane][0] = make_float4(nxt.a.x, nxt.a.y, ix, iy);
-            s_batch[lane][1] = make_float4(iz, nxt.b.y, nxt.b.z, nxt.b.w);
-            s_batch[lane][2] = make_float4(alpha0, 0.f, 0.f, 0.f);
+            // Skip threshold: alpha = a*exp(f) < 1/255 (the `continue` of :127) is certain once
+            // f < ln(1/(255 a)) - margin; the margin (0.01) dwarfs the errors of the fast log and of
+            // the pinned exp (<= 2e-6 relative), so the test below never changes a result.  a <= 0 or
+            // NaN gives +inf / NaN, i.e. "always skip" / "never skip", both exact.
+            const float fthr = __logf(1.0f / (255.0f * alpha0)) - 0.01f;
+            r0 = make_float4(sx, sy, ix, iy);
+            r1 = make_float4(iz, nxt.b.y, nxt.b.z, nxt.b.w);
+            r2 = make_float4(alpha0, fthr, 0.f, 0.f);
+            // Whole-tile rejection (the reference assigns tiles by a 3-sigma bounding box, so most
+            // list entries touch no pixel of the tile): for a positive-definite covariance
+            // f(p) <= -d^2 / (2 lambda_max) with d the distance from the splat centre to the tile's
+            // pixel rectangle.  If that bound, widened by a generous estimate of the fp32 error of
+            // the per-pixel f, is below the skip threshold, every pixel would `continue`: dropping
+            // the splat here is unobservable.
+            const float dxr = fmaxf(fmaxf(tile_x0 - sx, sx - (tile_x0 + 15.0f)), 0.0f);
+            const float dyr = fmaxf(fmaxf(tile_y0 - sy, sy - (tile_y0 + 15.0f)), 0.0f);
+            const float mid = 0.5f * (cx + cz);
+            const float lam_max = mid + sqrtf(fmaxf(mid * mid - det, 0.0f));
+            const float bound = -0.5f * (dxr * dxr + dyr * dyr) / lam_max;
+            const float far_x = dxr + 16.0f, far_y = dyr + 16.0f;   // >= |ex|, |ey| of every pixel
+            const float tol = 0.01f + 4e-6f * (fabsf(ix) * far_x * far_x + fabsf(iz) * far_y * far_y +
+                                               2.0f * fabsf(iy) * far_x * far_y);
+            const bool reject = det > 0.0f && lam_max > 0.0f && (bound + tol < fthr);
+            keep = !reject;
+        }
+        const uint64_t kmask = __ballot(keep);
+        const uint32_t n = (uint32_t)__popcll(kmask);
+        if (keep) {
+            const uint32_t slot = mbcnt(kmask);                        // order-preserving compaction
+            s_batch[slot][0] = r0;
+            s_batch[slot][1] = r1;
+            s_batch[slot][2] = r2;
         }
         __syncthreads();                                               // :109 (single wave)
         nxt = fetch_splat(raster, sorted_id, i + 64 + lane, end);      // prefetch next batch
@@ -135,21 +172,19 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
         for (uint32_t j = 0; j < n; ++j) {                             // :112
             const float4 g0 = s_batch[j][0];
             const float4 g1 = s_batch[j][1];
-            const float ga = s_batch[j][2].x;
+            const float2 g2 = *reinterpret_cast<const float2*>(&s_batch[j][2]);
+            const float ga = g2.x, fthr = g2.y;
             float ey = g0.y - fpy;                                     // :119
             ey = -ey;                                                  // :120
-            float f[4], alpha[4];
-            bool act[4];
-            bool any_act = false;
+            float f[4];
+            bool need[4];
+            bool any_need = false;
             if constexpr (EXACT) {
                 const float c_term = g1.x * ey * ey;                   // gCovInv.z * y * y
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float ex = g0.x - fpx[k];
                     f[k] = -0.5f * (g0.z * ex * ex + c_term) - g0.w * ex * ey;  // :123
-                    alpha[k] = ga * exp_pinned(f[k]);                           // :124
-                    act[k] = !done[k] && !(f[k] > 0.0f || alpha[k] < 1.0f / 255.0f); // :127
-                    any_act |= act[k];
                 }
             } else {
                 const float c_term = g1.x * ey * ey;
@@ -159,36 +194,46 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
                     const float ex = g0.x - fpx[k];
                     const float q = __builtin_fmaf(g0.z * ex, ex, c_term);
                     f[k] = __builtin_fmaf(-0.5f, q, -(b_term * ex));
-                    alpha[k] = ga * __builtin_amdgcn_exp2f(f[k] * 0x1.715476p+0f);
-                    act[k] = !done[k] && !(f[k] > 0.0f || alpha[k] < 1.0f / 255.0f);
-                    any_act |= act[k];
                 }
             }
-            if (__any(any_act)) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float wgt = T[k] * alpha[k];                 // :131
-                    if constexpr (EXACT) {
-                        col[k][0] = act[k] ? col[k][0] + wgt * g1.y : col[k][0];
-                        col[k][1] = act[k] ? col[k][1] + wgt * g1.z : col[k][1];
-                        col[k][2] = act[k] ? col[k][2] + wgt * g1.w : col[k][2];
-                    } else {
-                        const float w0 = act[k] ? wgt : 0.0f;
-                        col[k][0] = __builtin_fmaf(w0, g1.y, col[k][0]);
-                        col[k][1] = __builtin_fmaf(w0, g1.z, col[k][1]);
-                        col[k][2] = __builtin_fmaf(w0, g1.w, col[k][2]);
-                    }
-                    const float next_t = T[k] * (1.0f - alpha[k]);     // :133
-                    const bool fin = act[k] && next_t < 0.0001f;       // :136-140, colour already added
-                    done[k] = done[k] || fin;
-                    T[k] = (act[k] && !fin) ? next_t : T[k];           // :142
-                }
-                if (__all(done[0] && done[1] && done[2] && done[3])) goto finish; // whole-tile early-out
+            for (int k = 0; k < 4; ++k) {
+                need[k] = !done[k] && !(f[k] > 0.0f) && !(f[k] < fthr);
+                any_need |= need[k];
             }
+            if (STATS) ++st_visited;
+            if (!__any(any_need)) continue;                            // nobody can pass :127
+            if (STATS) ++st_need;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!__any(need[k])) continue;
+                float alpha;
+                if constexpr (EXACT) alpha = ga * exp_pinned(f[k]);    // :124
+                else alpha = ga * __builtin_amdgcn_exp2f(f[k] * 0x1.715476p+0f);
+                const bool act = need[k] && !(alpha < 1.0f / 255.0f);  // :127
+                const float wgt = T[k] * alpha;                        // :131
+                if constexpr (EXACT) {
+                    col[k][0] = act ? col[k][0] + wgt * g1.y : col[k][0];
+                    col[k][1] = act ? col[k][1] + wgt * g1.z : col[k][1];
+                    col[k][2] = act ? col[k][2] + wgt * g1.w : col[k][2];
+                } else {
+                    const float w0 = act ? wgt : 0.0f;
+                    col[k][0] = __builtin_fmaf(w0, g1.y, col[k][0]);
+                    col[k][1] = __builtin_fmaf(w0, g1.z, col[k][1]);
+                    col[k][2] = __builtin_fmaf(w0, g1.w, col[k][2]);
+                }
+                const float next_t = T[k] * (1.0f - alpha);            // :133
+                const bool fin = act && next_t < 0.0001f;              // :136-140, colour already added
+                done[k] = done[k] || fin;
+                T[k] = (act && !fin) ? next_t : T[k];                  // :142
+            }
+            if (__all(done[0] && done[1] && done[2] && done[3])) goto finish; // whole-tile early-out
         }
         __syncthreads();                                               // :84
     }
 finish:
+    if (STATS && lane == 0)
+        stats[tile_index] = make_uint4(end - start, st_visited, st_need, (uint32_t)(__builtin_amdgcn_s_memtime() - st_t0));
     // :147-151 clamp + RGBA8 UNORM store, A = 255
     uint32_t packed[4];
 #pragma unroll
@@ -221,17 +266,26 @@ void launch_find_ranges(const uint32_t* sorted_tile, const SortParams* params, u
     hipLaunchKernelGGL(k_find_ranges, dim3(blocks), dim3(256), 0, stream, sorted_tile, params, ranges);
 }
 
+void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
+                         const uint32_t* ranges, uint8_t* rgba, uint4* stats, hipStream_t stream) {
+    const uint32_t rows = fp.row_end > fp.row_begin ? fp.row_end - fp.row_begin : 0u;
+    const uint32_t tiles = rows * fp.grid_w;
+    if (tiles == 0) return;
+    hipLaunchKernelGGL((k_render<true, true>), dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
+                       ranges, reinterpret_cast<uint32_t*>(rgba), stats);
+}
+
 void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
                    const uint32_t* ranges, uint8_t* rgba, uint32_t render_mode, hipStream_t stream) {
     const uint32_t rows = fp.row_end > fp.row_begin ? fp.row_end - fp.row_begin : 0u;
     const uint32_t tiles = rows * fp.grid_w;
     if (tiles == 0) return;
     if (render_mode == 0u)
-        hipLaunchKernelGGL(k_render<true>, dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
-                           ranges, reinterpret_cast<uint32_t*>(rgba));
+        hipLaunchKernelGGL((k_render<true, false>), dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
+                           ranges, reinterpret_cast<uint32_t*>(rgba), (uint4*)nullptr);
     else
-        hipLaunchKernelGGL(k_render<false>, dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
-                           ranges, reinterpret_cast<uint32_t*>(rgba));
+        hipLaunchKernelGGL((k_render<false, false>), dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
+                           ranges, reinterpret_cast<uint32_t*>(rgba), (uint4*)nullptr);
 }
 
 } // namespace gs
