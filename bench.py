@@ -174,6 +174,16 @@ def main():
         # 24 B per element (read 12 B key+payload, write 12 B; SURVEY 8(d): Scatter share of B_sort)
         alg_bytes = 24.0 * e_rank
         achieved = alg_bytes / (scat * 1e-3) / 1e9 if scat > 0 else 0.0
+        # HBM bytes per Scatter launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE
+        # doubled per MI355X_MICROARCH.md; summary committed under profiles/), when measured at this E
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_scatter.json")) as f:
+                pmc = json.load(f)
+            if pmc["elements"] == e_rank:
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "Msplats/s + total frame ms (InitSortList/RadixSort/FindRanges/Render split)",
             "value": round(value, 2), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
@@ -197,7 +207,7 @@ def main():
                             "ms_per_step is the un-instrumented wall clock incl. the strip gather",
             "roofline": {"bound": "hbm", "kernel": "k_scatter (radix Scatter, one launch per 4-bit pass)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scat, 5),
                          "launches_per_frame": passes},
         }
