@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--config", default="C", choices=["A", "B", "C", "D"])
+    ap.add_argument("--config", default="C", choices=["A", "B", "C", "D", "E"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -194,7 +194,8 @@ def main():
             "config": {
                 "workload": {"A": "synthetic 100k @ 640x360", "B": "Train-7k shape: 559,263 gaussians @ 1280x720",
                              "C": "Garden-30k shape: 5,834,784 gaussians @ 1920x1080",
-                             "D": "Garden-30k shape: 5,834,784 gaussians @ 3840x2160"}[args.config],
+                             "D": "Garden-30k shape: 5,834,784 gaussians @ 3840x2160",
+                             "E": "stress: 50,000,000 synthetic gaussians @ 1920x1080"}[args.config],
                 "num_gaussians": n, "width": w, "height": h, "sort_elements": e_total,
                 "capacity": int(info.capacity), "radix_passes": passes, "render_mode": args.mode,
                 "parallelism": f"tile-row shard x{world}" if world > 1 else "single GPU",
