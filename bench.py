@@ -58,7 +58,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--config", default="C", choices=["A", "B", "C", "D", "E"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--sort", default="radix4", choices=["radix4", "bucket"],
+                    help="radix4 = the contractual nine-stage sort (default); bucket = GS_SORT_TILE_BUCKET")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra pass with the other sort back-end")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank rehearsal on ONE GPU: every rank uses cuda:0 and the strip gather goes "
+                         "through gloo on the host (RCCL needs one GPU per rank)")
     args = ap.parse_args()
 
     import torch
@@ -71,11 +77,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as tdist
-        tdist.init_process_group(backend="nccl", device_id=device)
+        if args.rehearse:
+            tdist.init_process_group(backend="gloo")
+        else:
+            tdist.init_process_group(backend="nccl", device_id=device)
     # one explicit HIP stream for the frame kernels AND the strip gather (torch orders RCCL after it)
     torch.cuda.set_stream(torch.cuda.Stream(device=device))
 
@@ -95,14 +106,17 @@ def main():
     cam.recalculate()
     mode = gs.GS_RENDER_EXACT if args.mode == "exact" else gs.GS_RENDER_FAST
 
-    def make(record):
-        r = gs.Renderer(w, h, device=local_rank, render_mode=mode, record_timings=record, warmup_frames=0)
+    sort_ids = {"radix4": gs.GS_SORT_RADIX4, "bucket": gs.GS_SORT_TILE_BUCKET}
+
+    def make(record, sort=None):
+        r = gs.Renderer(w, h, device=local_rank, render_mode=mode, record_timings=record, warmup_frames=0,
+                        sort_algorithm=sort_ids[sort or args.sort])
         r.init(rm)
         r.initForScene(scene)
         return r
 
     r = make(0)   # the timed region runs un-instrumented: no events between kernels
-    sf = gsdist.ShardedFrame(w, h, rank, world, device=device)
+    sf = gsdist.ShardedFrame(w, h, rank, world, device=device, host_gather=args.rehearse)
     rb, re = sf.band
     r.setTileRows(rb, re)
     # the library addresses the FULL frame; hand it the strip shifted up by the band's first row
@@ -128,7 +142,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t_begin
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else device)
     if world > 1:
         tdist.all_reduce(el, op=tdist.ReduceOp.MAX)
     elapsed = float(el.item())
@@ -159,8 +173,30 @@ def main():
     ri.setStream(None)
     ri.cleanup()
 
+    # extra pass: the same frame with the other sort back-end (identical output), for the record
+    alt = None
+    if not args.no_alt:
+        other = "bucket" if args.sort == "radix4" else "radix4"
+        ra = make(0, other)
+        ra.setTileRows(rb, re)
+        ra.setStream(torch.cuda.current_stream().cuda_stream)
+        for _ in range(10):
+            ra.drawDevice(scene, strip_ptr, sync=False)
+        barrier()
+        t_a = time.perf_counter()
+        for _ in range(args.steps):
+            ra.drawDevice(scene, strip_ptr, sync=False)
+            if world > 1:
+                sf.gather()
+        barrier()
+        alt_ms = (time.perf_counter() - t_a) / args.steps * 1e3
+        ra.setStream(None)
+        ra.cleanup()
+        alt = {"sort_algorithm": other, "ms_per_step": round(alt_ms, 4), "value": round(n / alt_ms / 1000.0, 2),
+               "note": "GS_SORT_TILE_BUCKET = tile-word radix passes + per-tile LDS depth sort; bit-identical output"}
+
     # per-rank numbers to rank 0
-    stats = torch.tensor([e_rank, scat, *buckets], dtype=torch.float64, device=device)
+    stats = torch.tensor([e_rank, scat, *buckets], dtype=torch.float64, device="cpu" if args.rehearse else device)
     if world > 1:
         allstats = [torch.zeros_like(stats) for _ in range(world)]
         tdist.all_gather(allstats, stats)
@@ -198,6 +234,7 @@ def main():
                              "E": "stress: 50,000,000 synthetic gaussians @ 1920x1080"}[args.config],
                 "num_gaussians": n, "width": w, "height": h, "sort_elements": e_total,
                 "capacity": int(info.capacity), "radix_passes": passes, "render_mode": args.mode,
+                "sort_algorithm": args.sort,
                 "parallelism": f"tile-row shard x{world}" if world > 1 else "single GPU",
                 "baseline_note": "vs_baseline = Msplats/s over the reference README's RTX 3080 Ti figure for the "
                                  "real scene of this shape (BASELINE.md); ours is a synthetic cloud with the same N and E",
@@ -212,6 +249,8 @@ def main():
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scat, 5),
                          "launches_per_frame": passes},
         }
+        if alt is not None:
+            out["alt"] = alt
         if world > 1:
             out["per_rank_total_ms"] = [round(float(s[6]), 4) for s in allstats]
             out["per_rank_sort_elements"] = [int(s[0]) for s in allstats]

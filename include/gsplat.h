@@ -45,7 +45,9 @@ extern "C" {
 
 /* sort back-ends (the GpuSort seam, Engine/Graphics/Sort/GpuSort.h:8-22, selected at compile
  * time in the reference by GPU_SORT_ALGORITHM, Renderer.h:33) */
-#define GS_SORT_RADIX4 0u       /* the contractual nine-stage 4-bit LSD radix sort */
+#define GS_SORT_RADIX4 0u       /* the contractual nine-stage 4-bit LSD radix sort over all key bits (default) */
+#define GS_SORT_TILE_BUCKET 1u  /* alternative back-end, identical output: the global 4-bit passes sort by the tile word
+                                   only, then every tile's run is depth-sorted inside LDS (csrc/gs_tilesort.hip) */
 
 /* render arithmetic */
 #define GS_RENDER_EXACT 0u      /* bit-identical to the CPU oracle (no contraction, pinned exp) */

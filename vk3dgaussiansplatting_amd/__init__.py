@@ -6,7 +6,8 @@ the host-side mirror of the reference's Renderer/Camera/ResourceManager/GpuSort 
 the synthetic cloud generator used by tests and bench, and the multi-GPU tile-row sharding.
 """
 from . import _lib
-from ._lib import (GS_OK, GS_WARN_OVERFLOW, GS_RENDER_EXACT, GS_RENDER_FAST, GsplatLibraryMissing,
+from ._lib import (GS_OK, GS_WARN_OVERFLOW, GS_RENDER_EXACT, GS_RENDER_FAST, GS_SORT_RADIX4,
+                   GS_SORT_TILE_BUCKET, GsplatLibraryMissing,
                    BUF_SORTED_TILE, BUF_SORTED_DEPTH, BUF_SORTED_ID, BUF_RANGES, BUF_COLOR, BUF_COV,
                    BUF_COUNT, BUF_UNSORTED_TILE, BUF_UNSORTED_DEPTH, BUF_UNSORTED_ID, BUF_IMAGE)
 from .renderer import (Camera, GpuSort, GsplatError, PlyScene, RadixSort, Renderer, ResourceManager,

@@ -25,6 +25,7 @@ GS_ERR_NO_DEVICE = -6
 GS_RENDER_EXACT = 0
 GS_RENDER_FAST = 1
 GS_SORT_RADIX4 = 0
+GS_SORT_TILE_BUCKET = 1
 
 (BUF_SORTED_TILE, BUF_SORTED_DEPTH, BUF_SORTED_ID, BUF_RANGES, BUF_COLOR, BUF_COV, BUF_COUNT,
  BUF_UNSORTED_TILE, BUF_UNSORTED_DEPTH, BUF_UNSORTED_ID, BUF_IMAGE) = range(11)

@@ -24,6 +24,7 @@ struct gs_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[7] = {};
     hipEvent_t scatter_ev[32] = {};   // record_timings == 2: a pair per pass (<= 16 passes)
+    hipEvent_t alt_ev[2] = {};        // GS_SORT_TILE_BUCKET: after FindRanges / after the per-tile sort
     std::string last_error;
 
     // scene
@@ -160,13 +161,24 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     if (int r = check_launch(c, "InitSortList")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[2], st));
     // gpuSort->computeSort (RadixSort.cpp:207-653)
+    const bool bucket = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET;
     c->sorted_index = launch_radix_sort(c->sort, c->capacity, c->num_sort_bits, st,
-                                        c->cfg.record_timings >= 2 ? c->scatter_ev : nullptr);
+                                        c->cfg.record_timings >= 2 ? c->scatter_ev : nullptr,
+                                        bucket ? 32u : 0u);
     if (int r = check_launch(c, "RadixSort")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[3], st));
     // computeRanges (Subrenderer.cpp:172-216)
     launch_find_ranges(c->sort.hi[c->sorted_index], c->sort.params, c->capacity, c->ranges, st);
     if (int r = check_launch(c, "FindRanges")) return r;
+    if (bucket) {
+        // second half of the alternative sorter: per-tile depth sort (needs the ranges)
+        const int si = c->sorted_index;
+        if (tm) HIP_TRY(c, hipEventRecord(c->alt_ev[0], st));
+        launch_tile_sort(c->ranges, c->row_begin * c->grid_w, (c->row_end - c->row_begin) * c->grid_w,
+                         c->sort.lo[si], c->sort.id[si], c->sort.lo[si ^ 1], c->sort.id[si ^ 1], st);
+        if (int r = check_launch(c, "TileSort")) return r;
+        if (tm) HIP_TRY(c, hipEventRecord(c->alt_ev[1], st));
+    }
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[4], st));
     // computeRenderGaussians (Subrenderer.cpp:218-346)
     launch_render(fp, c->scratch.raster, c->sort.id[c->sorted_index], c->ranges,
@@ -189,9 +201,18 @@ int finish_frame(gs_ctx* c) {
         HIP_TRY(c, hipEventElapsedTime(&t.find_ranges_ms, c->ev[3], c->ev[4]));
         HIP_TRY(c, hipEventElapsedTime(&t.render_ms, c->ev[4], c->ev[5]));
         HIP_TRY(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[6]));
+        if (c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET) {
+            // the per-tile sort runs behind FindRanges: book it under RadixSort, not FindRanges
+            float ranges_ms = 0.0f, tile_ms = 0.0f;
+            HIP_TRY(c, hipEventElapsedTime(&ranges_ms, c->ev[3], c->alt_ev[0]));
+            HIP_TRY(c, hipEventElapsedTime(&tile_ms, c->alt_ev[0], c->alt_ev[1]));
+            t.find_ranges_ms = ranges_ms;
+            t.radix_sort_ms += tile_ms;
+        }
     }
     if (c->cfg.record_timings >= 2) {
-        const uint32_t passes = c->num_sort_bits / kRadixBits;
+        const uint32_t first_bit = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET ? 32u : 0u;
+        const uint32_t passes = (c->num_sort_bits - first_bit) / kRadixBits;
         float sum = 0.0f;
         for (uint32_t k = 0; k < passes; ++k) {
             float ms = 0.0f;
@@ -233,7 +254,7 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
     gs_config cfg;
     if (cfg_in) cfg = *cfg_in; else gs_default_config(&cfg);
     if (cfg.tile_size != 16) return fail(nullptr, GS_ERR_INVALID, "gs_create: only tile_size 16 is supported");
-    if (cfg.sort_algorithm != GS_SORT_RADIX4) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown sort_algorithm");
+    if (cfg.sort_algorithm > GS_SORT_TILE_BUCKET) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown sort_algorithm");
     if (cfg.render_mode > GS_RENDER_FAST) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown render_mode");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -259,6 +280,16 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
             gs_destroy(c);
             return fail(nullptr, GS_ERR_HIP, msg);
         }
+    for (auto& ev : c->alt_ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) {
+            std::string msg = std::string("gs_create: ") + hipGetErrorString(e);
+            gs_destroy(c);
+            return fail(nullptr, GS_ERR_HIP, msg);
+        }
+    if (cfg.sort_algorithm == GS_SORT_TILE_BUCKET && init_tile_sort() != 0) {
+        gs_destroy(c);
+        return fail(nullptr, GS_ERR_HIP, "gs_create: cannot reserve 160 KB of LDS for the per-tile sort");
+    }
     if (cfg.record_timings >= 2)
         for (auto& ev : c->scatter_ev)
             if ((e = hipEventCreate(&ev)) != hipSuccess) {
@@ -278,6 +309,7 @@ int gs_destroy(gs_ctx* c) {
     free_scene(c);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : c->scatter_ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : c->alt_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return GS_OK;

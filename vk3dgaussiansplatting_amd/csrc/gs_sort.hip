@@ -313,12 +313,12 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
 }
 
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
-                      hipStream_t stream, hipEvent_t* scatter_events) {
+                      hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit) {
     const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
     const uint32_t sgrid = max_groups < (uint32_t)GS_SCATTER_GRID ? max_groups : (uint32_t)GS_SCATTER_GRID;
     int src = 0;
     uint32_t pass = 0;
-    for (uint32_t shift = 0; shift < num_sort_bits; shift += kRadixBits, ++pass) { // RadixSort.cpp:309
+    for (uint32_t shift = first_bit; shift < num_sort_bits; shift += kRadixBits, ++pass) { // RadixSort.cpp:309
         const int dst = src ^ 1;
         const uint32_t* word = shift >= 32u ? sb.hi[src] : sb.lo[src];
         hipLaunchKernelGGL(k_count<0>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,

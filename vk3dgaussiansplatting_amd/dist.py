@@ -37,7 +37,8 @@ class ShardedFrame:
     device or CPU); it is the only thing that differs between the GPU path (Renderer.drawDevice
     into the strip's storage) and the CPU test (an injected checker)."""
 
-    def __init__(self, width: int, height: int, rank: int, world_size: int, device="cpu", group=None):
+    def __init__(self, width: int, height: int, rank: int, world_size: int, device="cpu", group=None,
+                 host_gather: bool = False):
         import torch
         self.torch = torch
         self.width, self.height = width, height
@@ -48,7 +49,10 @@ class ShardedFrame:
         self.group = group
         self.device = device
         self.strip = torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=device)
-        self.gathered = ([torch.zeros_like(self.strip) for _ in range(world_size)]
+        # host_gather: rehearsal of the N > 1 path on one GPU (gloo has no device gather)
+        self.host_gather = host_gather
+        gdev = "cpu" if host_gather else device
+        self.gathered = ([torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=gdev) for _ in range(world_size)]
                          if rank == 0 and world_size > 1 else None)
 
     @property
@@ -60,7 +64,8 @@ class ShardedFrame:
         if self.world == 1:
             return [self.strip]
         import torch.distributed as dist
-        dist.gather(self.strip, self.gathered, dst=0, group=self.group)
+        src = self.strip.cpu() if self.host_gather else self.strip
+        dist.gather(src, self.gathered, dst=0, group=self.group)
         return self.gathered
 
     def assemble(self, strips) -> "np.ndarray":
