@@ -167,14 +167,15 @@ def test_empty_view_and_single_splat(oracle_mod, small_cloud):
     r.cleanup()
 
 
-def test_overflow_truncates_like_reference(oracle_mod):
+@pytest.mark.parametrize("sort", [gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET])
+def test_overflow_truncates_like_reference(oracle_mod, sort):
     """E > C: elements past the capacity are dropped (InitSortList.comp:140-148), status is a warning."""
     w, h = 320, 180
     gw, gh = oracle_mod.grid(w, h)
     n = 4000
     aos = synth.generate(n, w, h, 2.0, seed=9)            # huge splats: every one covers many tiles
     sc = make_scene(aos, w, h)
-    r = make_renderer(sc, w, h)
+    r = make_renderer(sc, w, h, sort=sort)
     img = r.draw(sc)
     cap = r.sceneInfo().capacity
     assert cap == oracle_mod.capacity(n, gw * gh)
@@ -336,6 +337,111 @@ def test_tile_bucket_sorter_tile_rows_and_config_a(oracle_mod):
     assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), band["id"][:e])
     assert np.array_equal(r.debugRead(gs.BUF_SORTED_DEPTH), band["depth"][:e])
     assert np.array_equal(img[80:176], band["image"][80:176])
+    r.cleanup()
+
+
+@pytest.mark.parametrize("scene_cls,w,h", [(gs.TestSortScene, 1280, 720), (gs.SimpleTestGaussiansScene, 640, 360)])
+def test_reference_synthetic_scenes(oracle_mod, scene_cls, w, h):
+    """The reference's own two synthetic scenes (Scenes/TestSortScene.cpp, SimpleTestGaussiansScene.cpp),
+    camera poses included, through the mirror of its Scene/Renderer interface."""
+    sc = scene_cls(aspect_ratio=w / h)
+    sc.init()
+    r = make_renderer(sc, w, h)
+    img = r.draw(sc)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    assert ref["e"] > 0 and img[..., :3].max() > 0
+    assert_frame_equals_oracle(r, img, ref)
+    if scene_cls is gs.TestSortScene:
+        # depth keys are (i+1)*1024 by construction; the sorted list must be ordered by them per tile
+        depth = r.debugRead(gs.BUF_SORTED_DEPTH).astype(np.int64)
+        tile = r.debugRead(gs.BUF_SORTED_TILE)
+        ids = r.debugRead(gs.BUF_SORTED_ID).astype(np.int64)
+        assert np.all(np.abs(depth - (ids + 1) * 1024) <= 2)
+        same = tile[1:] == tile[:-1]
+        assert np.all(depth[1:][same] >= depth[:-1][same])
+    r.cleanup()
+
+
+@pytest.mark.parametrize("name", ["garden", "train", "bicycle"])
+def test_reference_benchmark_camera_poses(oracle_mod, name):
+    """The 'Camera for benchmarks' poses of GardenScene / TrainScene / BicycleScene.cpp with a synthetic
+    cloud moved in front of each camera (the .ply files are not shipped): rotated view matrices."""
+    w, h = 480, 270
+    pos, yaw, pitch = gs.PlyScene.POSES[name]
+    cloud = synth.generate(20_000, w, h, -3.0, seed=hash(name) % 1000)
+    cam = gs.Camera(w / h)
+    cam.setPosition(pos)
+    cam.setRotation(yaw, pitch)
+    cam.recalculate()
+    view = cam.getViewMatrix().reshape(4, 4).T.astype(np.float64)        # row-major 4x4
+    inv = np.linalg.inv(view)
+    # the generator places splats at +z in front of an origin camera looking down +z, whose view space
+    # is (x -> -x, z -> -z); map them into this camera's view space, then to world
+    p = cloud[:, 0:3].astype(np.float64) * np.array([-1.0, 1.0, -1.0])
+    world = (inv[:3, :3] @ p.T).T + inv[:3, 3]
+    cloud[:, 0:3] = world.astype(np.float32)
+    sc = make_scene(cloud, w, h, pos=pos, yaw=yaw, pitch=pitch)
+    r = make_renderer(sc, w, h)
+    img = r.draw(sc)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    assert ref["e"] > 10_000
+    assert_frame_equals_oracle(r, img, ref)
+    r.cleanup()
+
+
+def test_ply_end_to_end(oracle_mod, tmp_path):
+    """.ply -> gs_load_ply semantics (ResourceManager::loadGaussians) -> frame, against the oracle run on
+    the records the converter produced."""
+    from test_library import PLY_PROPS, _write_ply
+    rng = np.random.default_rng(5)
+    n, w, h = 5000, 320, 180
+    table = np.zeros((n, len(PLY_PROPS)), np.float32)
+    col = {p: i for i, p in enumerate(PLY_PROPS)}
+    d = rng.uniform(1, 10, n)
+    table[:, col["x"]] = -(d * rng.uniform(-1.5, 1.5, n) * w / h)       # loader flips x and y
+    table[:, col["y"]] = -(d * rng.uniform(-1, 1, n))
+    table[:, col["z"]] = d
+    for a in range(3):
+        table[:, col[f"scale_{a}"]] = rng.normal(-3.0, 0.5, n)
+    for a in range(4):
+        table[:, col[f"rot_{a}"]] = rng.normal(size=n)
+    table[:, col["opacity"]] = rng.uniform(-2, 4, n)
+    for c in range(3):
+        table[:, col[f"f_dc_{c}"]] = rng.uniform(-1.5, 1.5, n)
+    for k in range(45):
+        table[:, col[f"f_rest_{k}"]] = rng.normal(0, 0.1, n)
+    path = str(tmp_path / "scene.ply")
+    _write_ply(path, table)
+    rm = gs.ResourceManager()
+    rm.loadGaussians(path)
+    assert rm.getGaussians().shape == (n, 84)
+    sc = gs.Scene(rm, aspect_ratio=w / h)
+    sc.getCamera().setPosition((0, 0, 0)); sc.getCamera().setRotation(0.0, 0.0); sc.getCamera().recalculate()
+    r = make_renderer(sc, w, h)
+    img = r.draw(sc)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    assert ref["e"] > 3000
+    assert_frame_equals_oracle(r, img, ref)
+    r.cleanup()
+
+
+def test_api_call_order_and_reuse(small_cloud):
+    """Errors are status codes, never aborts; a context survives re-upload and resolution changes."""
+    rm = gs.ResourceManager()
+    r = gs.Renderer(64, 64, warmup_frames=0)
+    r.init(rm)
+    with pytest.raises(gs.GsplatError) as ei:
+        r.initForScene(None)                                   # no gaussians yet
+    assert ei.value.code == _lib.GS_ERR_NO_SCENE
+    sc = make_scene(small_cloud, 320, 180)
+    r.resourceManager = sc.getResourceManager()
+    images = []
+    for (w, h) in [(320, 180), (64, 48), (320, 180)]:
+        r.width, r.height = w, h
+        r.initForScene(sc)
+        sc.getCamera().setAspectRatio(w / h); sc.getCamera().recalculate()
+        images.append(r.draw(sc).copy())
+    assert np.array_equal(images[0], images[2])
     r.cleanup()
 
 

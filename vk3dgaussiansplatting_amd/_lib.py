@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgsplat_hip.so")
+LIB_PATH = os.environ.get("GS_LIB_OVERRIDE") or os.path.join(CSRC, "libgsplat_hip.so")   # override: tuning builds only
 
 GS_OK = 0
 GS_WARN_OVERFLOW = 1

@@ -335,14 +335,22 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
                                                         uint32_t* __restrict__ out_id) {
     __shared__ uint32_t s_incl[kProjThreads];   // inclusive scan of tile counts
     __shared__ uint32_t s_wave_tot[kProjThreads / 64];
+    __shared__ uint2 s_ext[kProjThreads];
+    __shared__ uint32_t s_depth[kProjThreads];
     const uint32_t n = fp.num_gaussians;
-    const uint32_t total = sc.block_sums[blockIdx.x];
-    if (total == 0) return;
-    const uint32_t base = sc.block_offsets[blockIdx.x];
-    if (base >= fp.capacity) return;             // whole block dropped (overflow, :143)
     const int tid = threadIdx.x;
     const uint32_t g = blockIdx.x * kProjThreads + tid;
+    // every global read of the workgroup is issued up front (one memory latency instead of a chain);
+    // extents/depth of splats that emit nothing are stale or uninitialised and never used
+    const uint32_t total = sc.block_sums[blockIdx.x];
+    const uint32_t base = sc.block_offsets[blockIdx.x];
     const uint32_t cnt = g < n ? sc.tiles_touched[g] : 0u;
+    const uint2 my_ext = g < n ? sc.extents[g] : make_uint2(0u, 0u);
+    const uint32_t my_depth = g < n ? sc.depth_key[g] : 0u;
+    if (total == 0) return;
+    if (base >= fp.capacity) return;             // whole block dropped (overflow, :143)
+    s_ext[tid] = my_ext;
+    s_depth[tid] = my_depth;
     const uint32_t inc = wave_inclusive_scan(cnt);
     if (lane_id() == 63) s_wave_tot[wave_id()] = inc;
     __syncthreads();
@@ -363,8 +371,7 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
         const int s = lo;
         const uint32_t excl = s > 0 ? s_incl[s - 1] : 0u;
         const uint32_t id_local = j - excl;
-        const uint32_t gi = g0 + (uint32_t)s;
-        const uint2 ext = sc.extents[gi];
+        const uint2 ext = s_ext[s];
         const uint32_t min_x = ext.x & 0xFFFFu, y0 = ext.x >> 16, max_x = ext.y & 0xFFFFu;
         const uint32_t wdt = max_x - min_x;
         const uint32_t ry = id_local / wdt;
@@ -373,8 +380,8 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
         const uint64_t out = (uint64_t)base + j;
         if (out < fp.capacity) {                                          // :143
             out_hi[out] = tile_key;
-            out_lo[out] = sc.depth_key[gi];
-            out_id[out] = gi;
+            out_lo[out] = s_depth[s];
+            out_id[out] = g0 + (uint32_t)s;
         }
     }
 }

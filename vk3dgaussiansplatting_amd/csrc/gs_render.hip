@@ -79,7 +79,10 @@ __device__ __forceinline__ Fetched fetch_splat(const SplatRaster* __restrict__ r
 
 // STATS is a tuning-only instantiation (gs_debug_render_stats): per tile {list length, splats
 // visited, splats with any pixel needing exp, clock ticks}.  The product launches STATS = false.
-template <bool EXACT, bool STATS = false>
+// PX = pixels per lane: 4 -> one wave per tile (16 rows x 4 lanes), 2 -> two waves per tile (each
+// 8 rows x 8 lanes), 1 -> four waves per tile (each 4 rows x 16 lanes).  Waves of one tile are
+// independent workgroups: each gathers, culls (against its own pixel rectangle) and blends on its own.
+template <bool EXACT, int PX, bool STATS = false>
 __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
                                                 const SplatRaster* __restrict__ raster,
                                                 const uint32_t* __restrict__ sorted_id,
@@ -88,24 +91,29 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
     // LDS image of the current batch: {sx, sy, inv.x, inv.y}, {inv.z, r, g, b}, {a, -, -, -}
     __shared__ float4 s_batch[64][3];
 
+    constexpr int WPT = 4 / PX;            // waves per tile
+    constexpr int ROWS = kTile / WPT;      // pixel rows per wave
+    constexpr int LPR = 64 / ROWS;         // lanes per row
+    static_assert(LPR * PX == kTile, "lane layout");
     const int lane = threadIdx.x;
-    const uint32_t tile_in_band = blockIdx.x;
+    const uint32_t tile_in_band = blockIdx.x / WPT;
+    const uint32_t sub = blockIdx.x % WPT;
     const uint32_t ty = fp.row_begin + tile_in_band / fp.grid_w;
     const uint32_t tx = tile_in_band % fp.grid_w;
     const uint32_t tile_index = ty * fp.grid_w + tx;                   // :74-76
     const uint32_t start = ranges[tile_index * 2 + 0];                 // :77
     const uint32_t end = ranges[tile_index * 2 + 1];
 
-    const uint32_t py = ty * kTile + (uint32_t)(lane >> 2);
-    const uint32_t px0 = tx * kTile + (uint32_t)(lane & 3) * 4u;
+    const uint32_t py = ty * kTile + sub * ROWS + (uint32_t)(lane / LPR);
+    const uint32_t px0 = tx * kTile + (uint32_t)(lane % LPR) * PX;
     const float fpy = (float)py;                                       // integer pixel coords (R1)
-    const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
-    float fpx[4];
-    float col[4][3];
-    float T[4];
-    bool done[4];
+    const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile + sub * ROWS);
+    float fpx[PX];
+    float col[PX][3];
+    float T[PX];
+    bool done[PX];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < PX; ++k) {
         fpx[k] = (float)(px0 + k);
         col[k][0] = col[k][1] = col[k][2] = 0.0f;
         T[k] = 1.0f;
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
             // the per-pixel f, is below the skip threshold, every pixel would `continue`: dropping
             // the splat here is unobservable.
             const float dxr = fmaxf(fmaxf(tile_x0 - sx, sx - (tile_x0 + 15.0f)), 0.0f);
-            const float dyr = fmaxf(fmaxf(tile_y0 - sy, sy - (tile_y0 + 15.0f)), 0.0f);
+            const float dyr = fmaxf(fmaxf(tile_y0 - sy, sy - (tile_y0 + (float)(ROWS - 1))), 0.0f);
             const float mid = 0.5f * (cx + cz);
             const float lam_max = mid + sqrtf(fmaxf(mid * mid - det, 0.0f));
             const float bound = -0.5f * (dxr * dxr + dyr * dyr) / lam_max;
@@ -176,13 +184,13 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
             const float ga = g2.x, fthr = g2.y;
             float ey = g0.y - fpy;                                     // :119
             ey = -ey;                                                  // :120
-            float f[4];
-            bool need[4];
+            float f[PX];
+            bool need[PX];
             bool any_need = false;
             if constexpr (EXACT) {
                 const float c_term = g1.x * ey * ey;                   // gCovInv.z * y * y
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < PX; ++k) {
                     const float ex = g0.x - fpx[k];
                     f[k] = -0.5f * (g0.z * ex * ex + c_term) - g0.w * ex * ey;  // :123
                 }
@@ -190,14 +198,14 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
                 const float c_term = g1.x * ey * ey;
                 const float b_term = g0.w * ey;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < PX; ++k) {
                     const float ex = g0.x - fpx[k];
                     const float q = __builtin_fmaf(g0.z * ex, ex, c_term);
                     f[k] = __builtin_fmaf(-0.5f, q, -(b_term * ex));
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < PX; ++k) {
                 need[k] = !done[k] && !(f[k] > 0.0f) && !(f[k] < fthr);
                 any_need |= need[k];
             }
@@ -205,8 +213,8 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
             if (!__any(any_need)) continue;                            // nobody can pass :127
             if (STATS) ++st_need;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!__any(need[k])) continue;
+            for (int k = 0; k < PX; ++k) {
+                if (PX > 1 && !__any(need[k])) continue;
                 float alpha;
                 if constexpr (EXACT) alpha = ga * exp_pinned(f[k]);    // :124
                 else alpha = ga * __builtin_amdgcn_exp2f(f[k] * 0x1.715476p+0f);
@@ -227,7 +235,10 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
                 done[k] = done[k] || fin;
                 T[k] = (act && !fin) ? next_t : T[k];                  // :142
             }
-            if (__all(done[0] && done[1] && done[2] && done[3])) goto finish; // whole-tile early-out
+            bool all_done = true;
+#pragma unroll
+            for (int k = 0; k < PX; ++k) all_done = all_done && done[k];
+            if (__all(all_done)) goto finish;                          // whole-(sub)tile early-out
         }
         __syncthreads();                                               // :84
     }
@@ -235,9 +246,9 @@ finish:
     if (STATS && lane == 0)
         stats[tile_index] = make_uint4(end - start, st_visited, st_need, (uint32_t)(__builtin_amdgcn_s_memtime() - st_t0));
     // :147-151 clamp + RGBA8 UNORM store, A = 255
-    uint32_t packed[4];
+    uint32_t packed[PX];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < PX; ++k) {
         uint32_t v = 0xFF000000u;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -248,15 +259,22 @@ finish:
     }
     if (py < fp.height) {
         uint32_t* row = rgba + (size_t)py * fp.width;
-        if ((fp.width & 3u) == 0u && px0 + 3 < fp.width) {
-            *reinterpret_cast<uint4*>(row + px0) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        const bool vec_ok = (fp.width % PX) == 0u && px0 + (PX - 1) < fp.width;
+        if (PX == 4 && vec_ok) {
+            *reinterpret_cast<uint4*>(row + px0) = make_uint4(packed[0], packed[PX > 1 ? 1 : 0], packed[PX > 2 ? 2 : 0], packed[PX > 3 ? 3 : 0]);
+        } else if (PX == 2 && vec_ok) {
+            *reinterpret_cast<uint2*>(row + px0) = make_uint2(packed[0], packed[PX > 1 ? 1 : 0]);
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < PX; ++k)
                 if (px0 + k < fp.width) row[px0 + k] = packed[k];
         }
     }
 }
+
+#ifndef GS_RENDER_PX
+#define GS_RENDER_PX 4
+#endif
 
 void launch_find_ranges(const uint32_t* sorted_tile, const SortParams* params, uint32_t capacity,
                         uint32_t* ranges, hipStream_t stream) {
@@ -271,7 +289,7 @@ void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const
     const uint32_t rows = fp.row_end > fp.row_begin ? fp.row_end - fp.row_begin : 0u;
     const uint32_t tiles = rows * fp.grid_w;
     if (tiles == 0) return;
-    hipLaunchKernelGGL((k_render<true, true>), dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
+    hipLaunchKernelGGL((k_render<true, 4, true>), dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
                        ranges, reinterpret_cast<uint32_t*>(rgba), stats);
 }
 
@@ -280,11 +298,13 @@ void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint3
     const uint32_t rows = fp.row_end > fp.row_begin ? fp.row_end - fp.row_begin : 0u;
     const uint32_t tiles = rows * fp.grid_w;
     if (tiles == 0) return;
+    constexpr int PX = GS_RENDER_PX;
+    const uint32_t grid = tiles * (4 / PX);
     if (render_mode == 0u)
-        hipLaunchKernelGGL((k_render<true, false>), dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
+        hipLaunchKernelGGL((k_render<true, PX, false>), dim3(grid), dim3(64), 0, stream, fp, raster, sorted_id,
                            ranges, reinterpret_cast<uint32_t*>(rgba), (uint4*)nullptr);
     else
-        hipLaunchKernelGGL((k_render<false, false>), dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
+        hipLaunchKernelGGL((k_render<false, PX, false>), dim3(grid), dim3(64), 0, stream, fp, raster, sorted_id,
                            ranges, reinterpret_cast<uint32_t*>(rgba), (uint4*)nullptr);
 }
 
