@@ -18,7 +18,10 @@ constexpr int kBins = 1 << kRadixBits; // RS_BIN_COUNT
 // shrinks the histogram table 48x and makes every global access of a pass a >= 256-byte run.
 // 12 keys/thread, 3 workgroups/CU (36 KB LDS, <= 168 VGPRs) measured fastest on MI355X
 // (tools/run_variants.sh: 16 keys -> 85 us, 12 -> 72 us, 8 -> 72-80 us per Scatter at E = 13.1 M).
-constexpr int kSortThreads = 256;
+#ifndef GS_SORT_THREADS
+#define GS_SORT_THREADS 256
+#endif
+constexpr int kSortThreads = GS_SORT_THREADS;
 #ifndef GS_SORT_KPT
 #define GS_SORT_KPT 12
 #endif

@@ -181,6 +181,14 @@ __device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
     }
 }
 
+// GS_SCATTER_ABLATE: timing-only builds (tools/build_variants.sh), never shipped.  bit 0: stores go to
+// the tile's own range (no scatter pattern); bit 1: no global stores; bit 2: no ranking.
+// Measured at E = 13.1 M (MI355X): full 71.7 us; identity stores 55.4; no stores 44.5; no ranking +
+// identity stores 48.7; neither 18.3.  An XCD-contiguous walk of the groups (so that neighbouring
+// runs meet in one L2) measured 74.5 us -- slower, not kept.
+#ifndef GS_SCATTER_ABLATE
+#define GS_SCATTER_ABLATE 0
+#endif
 #ifndef GS_SCATTER_MINWAVES
 #define GS_SCATTER_MINWAVES 3
 #endif
@@ -255,6 +263,9 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
             const int dest = leader ? (int)dg : 63;
             const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)n_round);
             cntreg += lane < kBins ? recv : 0u;
+#if GS_SCATTER_ABLATE & 4
+            rank[r] = (uint32_t)(wave * kSortKeysPerThread + r) * 64u + lane;   // linear position
+#endif
         }
         if (lane < kBins) s_wcnt[wave][lane] = cntreg;
         __syncthreads();
@@ -285,7 +296,11 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
             const uint32_t idx = base + r * 64;
             if (idx < e) {
                 const uint32_t dg = digit_of(use_hi ? k.hi[r] : k.lo[r], sh);
+#if GS_SCATTER_ABLATE & 4
+                const uint32_t p = rank[r];
+#else
                 const uint32_t p = s_wbase[wave][dg] + rank[r];
+#endif
                 s_lo[p] = k.lo[r];
                 s_hi[p] = k.hi[r];
                 s_id[p] = k.id[r];
@@ -302,10 +317,18 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
             if (p < valid) {
                 const uint32_t l = s_lo[p], h = s_hi[p];
                 const uint32_t d = digit_of(use_hi ? h : l, sh);
+#if GS_SCATTER_ABLATE & 5
+                const uint32_t o = tile_base + p + (d & 0u);
+#else
                 const uint32_t o = (uint32_t)(s_gbase[d] + (int32_t)p);
+#endif
+#if GS_SCATTER_ABLATE & 2
+                if (l == 0x12345678u && h == 0x9abcdef0u) out_lo[o] = l;   // keeps the pipeline alive, ~never taken
+#else
                 out_lo[o] = l;
                 out_hi[o] = h;
                 out_id[o] = s_id[p];
+#endif
             }
         }
         __syncthreads();   // LDS is reused by the next group
