@@ -20,6 +20,18 @@ def ref_golden():
         return json.load(f)
 
 
+def test_committed_fixture_is_what_the_reference_code_produces():
+    """Where the reference is mounted (authoring container) and oracle/_ref/ref_fixtures was built from its
+    glm + SMath.h, its output must equal the committed vectors byte for byte."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_fixtures")
+    if not (os.path.isdir("/root/reference/vkGaussianSplatting") and os.path.exists(exe)):
+        pytest.skip("reference not mounted here; the committed fixture is used as is")
+    out = subprocess.run([exe], check=True, capture_output=True).stdout
+    assert out == open(os.path.join(GOLDEN, "ref_glm_smath.json"), "rb").read()
+
+
 def test_camera_matrices_match_reference_glm(oracle_mod, ref_golden):
     """view/proj bit-identical to glm::lookAt / glm::perspective run from /root/reference (Camera.cpp:7-48)."""
     for cam in ref_golden["cameras"]:

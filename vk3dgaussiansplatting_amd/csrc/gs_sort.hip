@@ -317,7 +317,9 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
             if (p < valid) {
                 const uint32_t l = s_lo[p], h = s_hi[p];
                 const uint32_t d = digit_of(use_hi ? h : l, sh);
-#if GS_SCATTER_ABLATE & 5
+#if GS_SCATTER_ABLATE & 8
+                const uint32_t o = tile_base + p + 13u + (d & 0u) < e ? tile_base + p + 13u : p;   // contiguous but misaligned
+#elif GS_SCATTER_ABLATE & 5
                 const uint32_t o = tile_base + p + (d & 0u);
 #else
                 const uint32_t o = (uint32_t)(s_gbase[d] + (int32_t)p);
