@@ -194,7 +194,8 @@ int gs_sort_bench(gs_ctx* ctx, uint32_t n, uint32_t num_tiles, uint32_t iters, u
 
 /* Stream-bandwidth probe on the context's GPU (the "measured HBM roofline" denominator): kind 0 =
  * read with 16-byte loads, 1 = device-to-device copy with 16-byte accesses, 2 = read with 4-byte
- * loads, 3 = copy with 4-byte accesses.  `bytes` per buffer; `blocks` workgroups of 256 threads
+ * loads, 3 = copy with 4-byte accesses, 4..7 = copy in the radix-scatter write pattern (three arrays,
+ * tiles of 3072 / 6144 / 12288 / 49152 dwords written as 16 runs each).  `bytes` per buffer; `blocks` workgroups of 256 threads
  * (0 = 2048).  Returns the mean over `iters` launches of bytes moved (read + written) per second. */
 int gs_membench(gs_ctx* ctx, int kind, size_t bytes, uint32_t blocks, uint32_t iters, float* gbytes_per_s,
                 float* ms_per_launch);

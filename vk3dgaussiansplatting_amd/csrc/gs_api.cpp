@@ -690,14 +690,14 @@ int gs_debug_count_bench(gs_ctx* c, uint32_t n, int ablate, uint32_t grid, uint3
 }
 
 int gs_membench(gs_ctx* c, int kind, size_t bytes, uint32_t blocks, uint32_t iters, float* gbps, float* ms_out) {
-    if (!c || !gbps || bytes < 16 || iters == 0 || kind < 0 || kind > 3) return GS_ERR_INVALID;
+    if (!c || !gbps || bytes < 16 || iters == 0 || kind < 0 || kind > 9) return GS_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     bytes &= ~(size_t)15;
     if (blocks == 0) blocks = 2048;
     void *src = nullptr, *dst = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipError_t e = hipMalloc(&src, bytes);
-    if (e == hipSuccess) e = hipMalloc(&dst, bytes);
+    hipError_t e = hipMalloc(&src, bytes + 65536);     // slack: the skewed scatter probes write a little past `bytes`
+    if (e == hipSuccess) e = hipMalloc(&dst, bytes + 65536);
     if (e == hipSuccess) e = hipMemsetAsync(src, 0x5A, bytes, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(dst, 0, bytes, c->stream);
     if (e == hipSuccess) e = hipEventCreate(&e0);
@@ -716,7 +716,7 @@ int gs_membench(gs_ctx* c, int kind, size_t bytes, uint32_t blocks, uint32_t ite
     if (src) (void)hipFree(src);
     if (dst) (void)hipFree(dst);
     if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_membench: ") + hipGetErrorString(e));
-    const double moved = (double)bytes * ((kind & 1) ? 2.0 : 1.0) * iters;
+    const double moved = (double)bytes * ((kind & 1) || kind >= 4 ? 2.0 : 1.0) * iters;
     *gbps = (float)(moved / (ms * 1e-3) / 1e9);
     if (ms_out) *ms_out = ms / (float)iters;
     return GS_OK;

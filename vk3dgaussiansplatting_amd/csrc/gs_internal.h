@@ -27,7 +27,10 @@ constexpr int kSortThreads = GS_SORT_THREADS;
 #endif
 constexpr int kSortKeysPerThread = GS_SORT_KPT;
 constexpr int kSortTile = kSortThreads * kSortKeysPerThread; // 3072 keys
-constexpr int kSegments = 1024;        // reduce segments = persistent Count workgroups; each owns a contiguous run of groups
+#ifndef GS_SEGMENTS
+#define GS_SEGMENTS 1024
+#endif
+constexpr int kSegments = GS_SEGMENTS;        // reduce segments = persistent Count workgroups; each owns a contiguous run of groups
 
 // ---- InitSortList tiling -----------------------------------------------------------------
 constexpr int kProjThreads = 256;      // splats per workgroup in project + emit

@@ -134,28 +134,31 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// Scan: exclusive scan of seg_sum[16][1024] in bin-major order, in place; one workgroup of 1024
-// threads, thread t owns the 16 consecutive entries [16t, 16t+16) (four 16-byte loads).
+// Scan: exclusive scan of seg_sum[16][kSegments] in bin-major order, in place; one workgroup of 1024
+// threads, thread t owns 16*kSegments/1024 consecutive entries (16-byte loads).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ seg_sum) {
+    constexpr int PER = kBins * kSegments / 1024;      // consecutive entries per thread
+    static_assert(PER % 4 == 0 && PER >= 4, "k_scan: 16-byte loads");
     __shared__ uint32_t s_wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint4* p = reinterpret_cast<uint4*>(seg_sum) + tid * 4;
-    uint4 v[4];
+    uint4* p = reinterpret_cast<uint4*>(seg_sum) + tid * (PER / 4);
+    uint4 v[PER / 4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = p[q];
-    uint32_t x[16] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
-                      v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+    for (int q = 0; q < PER / 4; ++q) v[q] = p[q];
+    uint32_t x[PER];
+#pragma unroll
+    for (int q = 0; q < PER / 4; ++q) { x[4 * q] = v[q].x; x[4 * q + 1] = v[q].y; x[4 * q + 2] = v[q].z; x[4 * q + 3] = v[q].w; }
     uint32_t run = 0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { const uint32_t t = x[q]; x[q] = run; run += t; }
+    for (int q = 0; q < PER; ++q) { const uint32_t t = x[q]; x[q] = run; run += t; }
     const uint32_t inc = wave_inclusive_scan(run);
     if (lane == 63) s_wave_tot[wave] = inc;
     __syncthreads();
     uint32_t base = inc - run;
     for (int w = 0; w < wave; ++w) base += s_wave_tot[w];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < PER / 4; ++q)
         p[q] = make_uint4(x[4 * q] + base, x[4 * q + 1] + base, x[4 * q + 2] + base, x[4 * q + 3] + base);
 }
 
@@ -189,6 +192,9 @@ __device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
 #ifndef GS_SCATTER_ABLATE
 #define GS_SCATTER_ABLATE 0
 #endif
+#ifndef GS_SCATTER_PREFETCH
+#define GS_SCATTER_PREFETCH 1   // keep the next group's keys in registers while working on the current one
+#endif
 #ifndef GS_SCATTER_MINWAVES
 #define GS_SCATTER_MINWAVES 3
 #endif
@@ -213,13 +219,20 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
     const uint32_t sh = shift & 31u;
     const uint32_t wave_off = (uint32_t)wave * (kSortKeysPerThread * 64) + lane;
 
+#if GS_SCATTER_PREFETCH
     ScatterKeys nxt;
     scatter_load(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, nxt);
+#endif
 
     for (; grp < G; grp += gridDim.x) {
+#if GS_SCATTER_PREFETCH
         ScatterKeys k = nxt;
         if (grp + gridDim.x < G)
             scatter_load(in_lo, in_hi, in_id, (grp + gridDim.x) * kSortTile + wave_off, e, nxt); // prefetch
+#else
+        ScatterKeys k;
+        scatter_load(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, k);
+#endif
         const uint32_t tile_base = grp * kSortTile;
         const uint32_t base = tile_base + wave_off;
 
