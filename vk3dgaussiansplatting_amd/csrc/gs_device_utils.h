@@ -21,6 +21,18 @@ __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
     return v; // every lane holds the sum
 }
 
+// Sum over the wave with six DPP adds (row_shr 1/2/4/8, row_bcast 15/31); the total lands in lane 63
+// only (other lanes hold partial sums).  Pure VALU: no LDS crossbar traffic, unlike __shfl_xor.
+__device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+    return v;
+}
+
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     const int lane = lane_id();
 #pragma unroll

@@ -161,9 +161,14 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
                                                            const SceneBuffers scene,
                                                            const SplatScratch sc) {
     __shared__ uint32_t s_wave_sum[kProjThreads / 64];
+    // The 48-byte raster records of the workgroup's 256 splats are staged here and written out as one
+    // contiguous 12 KB block of full cache lines: per-lane 16-byte stores at a 48-byte stride reached HBM
+    // as 32-byte partial writes (WRITE_SIZE 355 MB per frame against 219 MB of payload, config C).
+    __shared__ float4 s_raster[kProjThreads * 3];
     const uint32_t n = fp.num_gaussians;
     const uint32_t g = blockIdx.x * kProjThreads + threadIdx.x;
     uint32_t count = 0;
+    float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0;   // culled splats: zero record
 
     if (g < n) {
         const float px = scene.pos[g], py = scene.pos[(size_t)n + g], pz = scene.pos[2 * (size_t)n + g];
@@ -219,8 +224,8 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
                 // that emits no element here (off-screen inside the 1.3 NDC cull margin, or outside this
                 // context's tile-row band) the 192-byte SH read and the colour evaluation are skipped:
                 // unobservable in keys, ranges and pixels (SURVEY "F" list).
-                float4* rp = reinterpret_cast<float4*>(sc.raster + g);
-                rp[0] = make_float4(sx, sy, cov[0], cov[1]);
+                rec0 = make_float4(sx, sy, cov[0], cov[1]);
+                rec1.x = cov[2];
                 if (count != 0u) {
                     // colour, InitSortList.comp:124-126 + Common.glsl:141-170
                     const float ddx = px - fp.cam_pos[0], ddy = py - fp.cam_pos[1], ddz = pz - fp.cam_pos[2];
@@ -252,23 +257,34 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
                         res[c] = res[c] + 0.5f;
                         res[c] = maxf(res[c], 0.0f);
                     }
-                    rp[1] = make_float4(cov[2], res[0], res[1], res[2]);
-                    rp[2] = make_float4(scene.opacity[g], 0.0f, 0.0f, 0.0f);
+                    rec1 = make_float4(cov[2], res[0], res[1], res[2]);
+                    rec2 = make_float4(scene.opacity[g], 0.0f, 0.0f, 0.0f);
                     sc.depth_key[g] = depth_key;
                     sc.extents[g] = make_uint2((uint32_t)min_x | ((uint32_t)y0 << 16),
                                                (uint32_t)max_x | ((uint32_t)y1 << 16));
-                } else {
-                    reinterpret_cast<float*>(rp + 1)[0] = cov[2];
                 }
             }
         }
         sc.tiles_touched[g] = count;
     }
 
+    s_raster[threadIdx.x * 3 + 0] = rec0;
+    s_raster[threadIdx.x * 3 + 1] = rec1;
+    s_raster[threadIdx.x * 3 + 2] = rec2;
     // per-workgroup total -> block_sums (input of the scan that replaces the atomic counter)
     const uint32_t wsum = wave_reduce_add(count);
     if (lane_id() == 0) s_wave_sum[wave_id()] = wsum;
     __syncthreads();
+    {
+        const uint32_t first = blockIdx.x * kProjThreads;
+        const uint32_t valid = (n - first) < (uint32_t)kProjThreads ? (n - first) : (uint32_t)kProjThreads;
+        float4* out = reinterpret_cast<float4*>(sc.raster + first);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const uint32_t i = q * kProjThreads + threadIdx.x;
+            if (i < valid * 3u) out[i] = s_raster[i];
+        }
+    }
     if (threadIdx.x == 0) {
         uint32_t t = 0;
 #pragma unroll

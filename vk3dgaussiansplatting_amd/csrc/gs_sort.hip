@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
                                                          uint32_t* __restrict__ table,
                                                          uint32_t* __restrict__ seg_sum,
                                                          uint32_t sh) {
-    __shared__ uint32_t s_cnt[2][kSortWaves][kBins];
+    __shared__ uint32_t s_pack[2][kSortWaves][8];   // per-wave packed totals (two 16-bit counters per word)
     const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // segment = blockIdx.x owns groups [seg*K, min(seg*K + K, G))
@@ -106,26 +106,28 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
                 c1 += (d & 8u) ? inc : 0ull;
             }
         }
-        // widen to 16-bit fields: a[0] = digits 0,2,4,6; a[1] = 1,3,5,7; a[2] = 8,10,12,14; a[3] = 9,...,15
+        // widen to 16-bit fields (a wave total is at most 64 * kSortKeysPerThread < 65536):
+        // word 0/1 = digits {0,2} / {4,6}, word 2/3 = {1,3} / {5,7}, words 4..7 the same for digits 8..15
         const uint64_t m = 0x00FF00FF00FF00FFull;
-        uint64_t a[4] = {c0 & m, (c0 >> 8) & m, c1 & m, (c1 >> 8) & m};
+        const uint64_t a[4] = {c0 & m, (c0 >> 8) & m, c1 & m, (c1 >> 8) & m};
+        uint32_t w[8];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t lo = __shfl_xor((uint32_t)a[q], off, 64);
-                const uint32_t hi = __shfl_xor((uint32_t)(a[q] >> 32), off, 64);
-                a[q] += ((uint64_t)hi << 32) | lo;
-            }
-        if (lane < kBins) {   // lane d extracts digit d
-            const uint64_t r = (lane & 8) ? ((lane & 1) ? a[3] : a[2]) : ((lane & 1) ? a[1] : a[0]);
-            s_cnt[it][wave][lane] = (uint32_t)(r >> (((lane & 7) >> 1) * 16)) & 0xFFFFu;
+        for (int q = 0; q < 4; ++q) {
+            w[2 * q] = wave_sum_to_lane63((uint32_t)a[q]);
+            w[2 * q + 1] = wave_sum_to_lane63((uint32_t)(a[q] >> 32));
         }
-        __syncthreads();   // s_cnt is double-buffered, so one barrier per group is enough
+        if (lane == 63) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s_pack[it][wave][q] = w[q];
+        }
+        __syncthreads();   // s_pack is double-buffered, so one barrier per group is enough
         if (tid < kBins) {
+            // digit d sits in u64 a[(d >> 3) * 2 + (d & 1)], 16-bit field (d & 7) >> 1
+            const int word = ((tid >> 3) * 2 + (tid & 1)) * 2 + (((tid & 7) >> 1) >> 1);
+            const int half = ((tid & 7) >> 1) & 1;
             uint32_t t = 0;
 #pragma unroll
-            for (int k = 0; k < kSortWaves; ++k) t += s_cnt[it][k][tid];
+            for (int k = 0; k < kSortWaves; ++k) t += (s_pack[it][k][word] >> (16 * half)) & 0xFFFFu;
             if (!(ABLATE & 2) || t == 0xFFFFFFFFu) table[tid * G + grp] = t; // RadixSortCount.comp:89, bin-major
             seg_total += t;
         }
