@@ -21,8 +21,9 @@ __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
     return v; // every lane holds the sum
 }
 
-// Sum over the wave with six DPP adds (row_shr 1/2/4/8, row_bcast 15/31); the total lands in lane 63
-// only (other lanes hold partial sums).  Pure VALU: no LDS crossbar traffic, unlike __shfl_xor.
+// Inclusive prefix sum over the wave with six DPP adds (row_shr 1/2/4/8, row_bcast 15/31): lane l gets
+// x_0 + ... + x_l, so lane 63 holds the wave total.  Pure VALU (no LDS crossbar traffic, unlike
+// __shfl_up / __shfl_xor).  Every lane of the wave must be active at the call.
 __device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
@@ -33,14 +34,8 @@ __device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v) {
     return v;
 }
 
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
-    return v;
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {   // all 64 lanes active
+    return wave_sum_to_lane63(v);
 }
 
 __device__ __forceinline__ uint64_t wave_inclusive_scan64(uint64_t v) {

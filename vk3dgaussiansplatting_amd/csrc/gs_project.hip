@@ -272,8 +272,8 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
     s_raster[threadIdx.x * 3 + 1] = rec1;
     s_raster[threadIdx.x * 3 + 2] = rec2;
     // per-workgroup total -> block_sums (input of the scan that replaces the atomic counter)
-    const uint32_t wsum = wave_reduce_add(count);
-    if (lane_id() == 0) s_wave_sum[wave_id()] = wsum;
+    const uint32_t wsum = wave_sum_to_lane63(count);
+    if (lane_id() == 63) s_wave_sum[wave_id()] = wsum;
     __syncthreads();
     {
         const uint32_t first = blockIdx.x * kProjThreads;

@@ -55,6 +55,27 @@ __device__ __forceinline__ float exp_pinned(float x) {
     return __builtin_ldexpf(p, (int)n);
 }
 
+// The same pinned exp on two values at once: v_pk_mul / v_pk_add / v_pk_fma are IEEE per component, so
+// each component goes through exactly the operation sequence of exp_pinned().
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f exp_pinned2(v2f x) {
+    v2f t = x * (v2f){0x1.715476p+0f, 0x1.715476p+0f};
+    t.x = t.x > -126.0f ? t.x : -126.0f;
+    t.y = t.y > -126.0f ? t.y : -126.0f;
+    t.x = t.x < 126.0f ? t.x : 126.0f;
+    t.y = t.y < 126.0f ? t.y : 126.0f;
+    const v2f n = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
+    const v2f r = t - n;
+    v2f p = {0x1.42059ap-13f, 0x1.42059ap-13f};
+    p = __builtin_elementwise_fma(p, r, (v2f){0x1.5f3e12p-10f, 0x1.5f3e12p-10f});
+    p = __builtin_elementwise_fma(p, r, (v2f){0x1.3b2d40p-7f, 0x1.3b2d40p-7f});
+    p = __builtin_elementwise_fma(p, r, (v2f){0x1.c6aeeap-5f, 0x1.c6aeeap-5f});
+    p = __builtin_elementwise_fma(p, r, (v2f){0x1.ebfbdcp-3f, 0x1.ebfbdcp-3f});
+    p = __builtin_elementwise_fma(p, r, (v2f){0x1.62e430p-1f, 0x1.62e430p-1f});
+    p = __builtin_elementwise_fma(p, r, (v2f){1.0f, 1.0f});
+    return (v2f){__builtin_ldexpf(p.x, (int)n.x), __builtin_ldexpf(p.y, (int)n.y)};
+}
+
 struct Fetched {
     float4 a, b, c;   // raw SplatRaster
     bool valid;
@@ -187,7 +208,21 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
             float f[PX];
             bool need[PX];
             bool any_need = false;
-            if constexpr (EXACT) {
+            if constexpr (EXACT && PX == 4) {
+                // two pixels per instruction (v_pk_mul_f32 / v_pk_add_f32 are IEEE per component, so the
+                // operand order and every rounding are those of the scalar expression of :123)
+                const float c_term = g1.x * ey * ey;
+                const v2f sxv = {g0.x, g0.x}, ixv = {g0.z, g0.z}, iyv = {g0.w, g0.w};
+                const v2f eyv = {ey, ey}, cv = {c_term, c_term}, mh = {-0.5f, -0.5f};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const v2f pxv = {fpx[2 * q], fpx[2 * q + 1]};
+                    const v2f ex = sxv - pxv;
+                    const v2f ff = mh * (ixv * ex * ex + cv) - iyv * ex * eyv;
+                    f[2 * q] = ff.x;
+                    f[2 * q + 1] = ff.y;
+                }
+            } else if constexpr (EXACT) {
                 const float c_term = g1.x * ey * ey;                   // gCovInv.z * y * y
 #pragma unroll
                 for (int k = 0; k < PX; ++k) {
@@ -212,6 +247,35 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
             if (STATS) ++st_visited;
             if (!__any(any_need)) continue;                            // nobody can pass :127
             if (STATS) ++st_need;
+            if constexpr (EXACT && PX == 4) {
+                // blend two pixels per instruction where the ISA has a packed form
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int k0 = 2 * q, k1 = 2 * q + 1;
+                    if (!__any(need[k0] || need[k1])) continue;
+                    const v2f alpha = (v2f){ga, ga} * exp_pinned2((v2f){f[k0], f[k1]});      // :124
+                    const bool act0 = need[k0] && !(alpha.x < 1.0f / 255.0f);                // :127
+                    const bool act1 = need[k1] && !(alpha.y < 1.0f / 255.0f);
+                    const v2f Tv = {T[k0], T[k1]};
+                    const v2f wgt = Tv * alpha;                                              // :131
+                    const v2f cr = (v2f){col[k0][0], col[k1][0]} + wgt * (v2f){g1.y, g1.y};
+                    const v2f cg = (v2f){col[k0][1], col[k1][1]} + wgt * (v2f){g1.z, g1.z};
+                    const v2f cb = (v2f){col[k0][2], col[k1][2]} + wgt * (v2f){g1.w, g1.w};
+                    col[k0][0] = act0 ? cr.x : col[k0][0];
+                    col[k1][0] = act1 ? cr.y : col[k1][0];
+                    col[k0][1] = act0 ? cg.x : col[k0][1];
+                    col[k1][1] = act1 ? cg.y : col[k1][1];
+                    col[k0][2] = act0 ? cb.x : col[k0][2];
+                    col[k1][2] = act1 ? cb.y : col[k1][2];
+                    const v2f next_t = Tv * ((v2f){1.0f, 1.0f} - alpha);                     // :133
+                    const bool fin0 = act0 && next_t.x < 0.0001f;                            // :136-140
+                    const bool fin1 = act1 && next_t.y < 0.0001f;
+                    done[k0] = done[k0] || fin0;
+                    done[k1] = done[k1] || fin1;
+                    T[k0] = (act0 && !fin0) ? next_t.x : T[k0];                              // :142
+                    T[k1] = (act1 && !fin1) ? next_t.y : T[k1];
+                }
+            } else
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
                 if (PX > 1 && !__any(need[k])) continue;

@@ -246,8 +246,8 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
             for (int q = 0; q < kBins / kSortWaves; ++q) {
                 const int d = wave * (kBins / kSortWaves) + q;
                 uint32_t pre = (uint32_t)lane < j ? table[d * G + seg * K + lane] : 0u;
-                pre = wave_reduce_add(pre);
-                if (lane == 0) s_gpre[d] = pre + seg_base[d * kSegments + seg];
+                pre = wave_sum_to_lane63(pre);
+                if (lane == 63) s_gpre[d] = pre + seg_base[d * kSegments + seg];
             }
         }
 
