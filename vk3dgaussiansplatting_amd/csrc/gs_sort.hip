@@ -42,7 +42,7 @@ constexpr int kSortWaves = kSortThreads / 64;
 // prefetch the next group's keys while counting the current one, so HBM never idles between the
 // load / count / store phases of a group.  16-byte coalesced loads (order inside the tile is
 // irrelevant for a histogram); per-thread counters packed 8 x 8 bit in two 64-bit registers,
-// widened to 16-bit fields and summed across the wave with xor-shuffles; no LDS atomics.
+// widened to 16-bit fields and summed across the wave with six DPP adds per word; no LDS atomics.
 static_assert(kSortKeysPerThread % 4 == 0 && kSortKeysPerThread <= 252, "packed 8-bit counters");
 constexpr int kCountVec = kSortKeysPerThread / 4;
 
