@@ -19,6 +19,16 @@ def has_gpu() -> bool:
     return os.path.exists("/dev/kfd")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The in-tree .so normally travels with the snapshot; if it is missing (fresh checkout) build it with
+    hipcc for gfx950 -- never fall back to anything else."""
+    from vk3dgaussiansplatting_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     import oracle
