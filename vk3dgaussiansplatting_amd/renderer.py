@@ -231,6 +231,14 @@ class PlyScene(Scene):
         self.resourceManager.loadGaussians(self.plyPath)
 
 
+def savePpm(path: str, rgba: np.ndarray):
+    """Frame sink replacing the swapchain present (Subrenderer.cpp:292-345): binary PPM, RGB only."""
+    img = np.ascontiguousarray(rgba[..., :3], dtype=np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(img.tobytes())
+
+
 class _Context:
     """Owns one gs_ctx."""
 
