@@ -26,18 +26,33 @@ __global__ __launch_bounds__(256) void k_find_ranges(const uint32_t* __restrict_
                                                       const SortParams* __restrict__ params,
                                                       uint32_t* __restrict__ ranges) {
     const uint32_t e = params->num_elems;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < e; i += gridDim.x * blockDim.x) {
-        const uint32_t t = tile[i];
-        if (i == 0) {
-            ranges[t * 2 + 0] = 0;                      // FindRanges.comp:59-64
+    // four consecutive elements per thread (one 16-byte load) + the element in front of them
+    const uint32_t quads = (e + 3u) / 4u;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
+        const uint32_t i0 = q * 4u;
+        uint32_t t[4];
+        if (i0 + 3u < e) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tile + i0);
+            t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
         } else {
-            const uint32_t p = tile[i - 1];
-            if (p != t) {                               // :48-58
-                ranges[p * 2 + 1] = i;
-                ranges[t * 2 + 0] = i;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = i0 + k < e ? tile[i0 + k] : 0u;
+        }
+        uint32_t prev = i0 > 0 ? tile[i0 - 1] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + k;
+            if (i < e) {
+                if (i == 0) {
+                    ranges[t[k] * 2 + 0] = 0;               // FindRanges.comp:59-64
+                } else if (prev != t[k]) {                  // :48-58
+                    ranges[prev * 2 + 1] = i;
+                    ranges[t[k] * 2 + 0] = i;
+                }
+                if (i == e - 1) ranges[t[k] * 2 + 1] = e;   // end of the last tile = E
+                prev = t[k];
             }
         }
-        if (i == e - 1) ranges[t * 2 + 1] = e;          // end of the last tile = E
     }
 }
 
@@ -345,8 +360,8 @@ finish:
 
 void launch_find_ranges(const uint32_t* sorted_tile, const SortParams* params, uint32_t capacity,
                         uint32_t* ranges, hipStream_t stream) {
-    uint32_t blocks = (capacity + 255u) / 256u;
-    if (blocks > 4096u) blocks = 4096u;
+    uint32_t blocks = (capacity / 4u + 255u) / 256u;
+    if (blocks > 2048u) blocks = 2048u;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_find_ranges, dim3(blocks), dim3(256), 0, stream, sorted_tile, params, ranges);
 }
