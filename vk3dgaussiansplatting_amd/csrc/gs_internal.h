@@ -14,19 +14,20 @@ constexpr int kBins = 1 << kRadixBits; // RS_BIN_COUNT
 
 // ---- radix-sort tiling -------------------------------------------------------------------
 // One workgroup (256 threads = 4 waves) owns kSortTile consecutive keys of the current pass.
-// The reference uses 64 keys per group (RS_WORK_GROUP_SIZE, RadixSort.h:38); a 3072-key tile
-// shrinks the histogram table 48x and makes every global access of a pass a >= 256-byte run.
-// 12 keys/thread, 3 workgroups/CU (36 KB LDS, <= 168 VGPRs) measured fastest on MI355X
-// (tools/run_variants.sh: 16 keys -> 85 us, 12 -> 72 us, 8 -> 72-80 us per Scatter at E = 13.1 M).
+// The reference uses 64 keys per group (RS_WORK_GROUP_SIZE, RadixSort.h:38); a 2048-key tile
+// shrinks the histogram table 32x and makes every global access of a pass a >= 256-byte run.
+// 8 keys/thread with 4 workgroups/CU (24.6 KB LDS, <= 128 VGPRs, grid 1024) and 12 keys/thread with
+// 3/CU (grid 768) are within 3 % of each other on MI355X; 8 keys wins in whole frames at every
+// README shape (config C sort 1.078 vs 1.107 ms, D 2.68 vs 2.83 ms); 16 keys/thread is 20 % slower.
 #ifndef GS_SORT_THREADS
 #define GS_SORT_THREADS 256
 #endif
 constexpr int kSortThreads = GS_SORT_THREADS;
 #ifndef GS_SORT_KPT
-#define GS_SORT_KPT 12
+#define GS_SORT_KPT 8
 #endif
 constexpr int kSortKeysPerThread = GS_SORT_KPT;
-constexpr int kSortTile = kSortThreads * kSortKeysPerThread; // 3072 keys
+constexpr int kSortTile = kSortThreads * kSortKeysPerThread; // 2048 keys
 #ifndef GS_SEGMENTS
 #define GS_SEGMENTS 1024
 #endif

@@ -3,7 +3,7 @@
 //
 // Reference pipeline per 4-bit pass (RadixSort.cpp:309-642): five dependent dispatches
 //   Count -> Reduce -> Scan -> ScanAdd -> Scatter, 64 keys per workgroup, 16-byte uvec4 elements.
-// Here the same five stages run in THREE launches per pass over 3072-key tiles ("groups"):
+// Here the same five stages run in THREE launches per pass over 2048-key tiles ("groups"):
 //   k_count    Count  : per-group digit histogram -> table[bin][group]  (RadixSortCount.comp:40-91);
 //                       reads only the 4-byte key half the digit lives in (keys are SoA).
 //              Reduce : each of the 1024 persistent workgroups owns a CONTIGUOUS run of groups (one
@@ -35,7 +35,7 @@ constexpr int kSortWaves = kSortThreads / 64;
 // Count + Reduce
 // ---------------------------------------------------------------------------------------------
 #ifndef GS_SCATTER_GRID
-#define GS_SCATTER_GRID 768     // persistent workgroups of k_scatter (3 per CU: 48 KB LDS each)
+#define GS_SCATTER_GRID 1024    // persistent workgroups of k_scatter (4 per CU: 24.6 KB LDS each)
 #endif
 
 // Count + Reduce.  Persistent workgroups walk the groups (tiles) with a stride of gridDim and
@@ -198,7 +198,7 @@ __device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
 #define GS_SCATTER_PREFETCH 1   // keep the next group's keys in registers while working on the current one
 #endif
 #ifndef GS_SCATTER_MINWAVES
-#define GS_SCATTER_MINWAVES 3
+#define GS_SCATTER_MINWAVES 4
 #endif
 __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
     const SortParams* __restrict__ params, const uint32_t* __restrict__ in_lo,
