@@ -52,6 +52,11 @@ def cpu_baseline(aos, cfg, budget_s=20.0):
 
 
 def main():
+    # stdout carries exactly ONE JSON line: anything a library prints there meanwhile (gloo/RCCL banners)
+    # is sent to stderr by pointing fd 1 at fd 2 until the result is ready
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -256,7 +261,8 @@ def main():
             out["per_rank_sort_elements"] = [int(s[0]) for s in allstats]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(aos, cfg)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         tdist.barrier()
         tdist.destroy_process_group()
