@@ -21,7 +21,7 @@ CONFIGS = {
     "B": dict(n=559_263, width=1280, height=720, mu=-3.48486, seed=20240807 + 1),
     "C": dict(n=5_834_784, width=1920, height=1080, mu=-4.65381, seed=20240807 + 2),
     "D": dict(n=5_834_784, width=3840, height=2160, mu=-4.65381, seed=20240807 + 2),
-    "E": dict(n=50_000_000, width=1920, height=1080, mu=-6.0, seed=20240807 + 4),
+    "E": dict(n=50_000_000, width=1920, height=1080, mu=-5.55, seed=20240807 + 4),
 }
 
 
