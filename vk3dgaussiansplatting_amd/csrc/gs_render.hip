@@ -188,21 +188,31 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
             r0 = make_float4(sx, sy, ix, iy);
             r1 = make_float4(iz, nxt.b.y, nxt.b.z, nxt.b.w);
             r2 = make_float4(alpha0, fthr, 0.f, 0.f);
-            // Whole-tile rejection (the reference assigns tiles by a 3-sigma bounding box, so most
-            // list entries touch no pixel of the tile): for a positive-definite covariance
-            // f(p) <= -d^2 / (2 lambda_max) with d the distance from the splat centre to the tile's
-            // pixel rectangle.  If that bound, widened by a generous estimate of the fp32 error of
-            // the per-pixel f, is below the skip threshold, every pixel would `continue`: dropping
-            // the splat here is unobservable.
-            const float dxr = fmaxf(fmaxf(tile_x0 - sx, sx - (tile_x0 + 15.0f)), 0.0f);
-            const float dyr = fmaxf(fmaxf(tile_y0 - sy, sy - (tile_y0 + (float)(ROWS - 1))), 0.0f);
-            const float mid = 0.5f * (cx + cz);
-            const float lam_max = mid + sqrtf(fmaxf(mid * mid - det, 0.0f));
-            const float bound = -0.5f * (dxr * dxr + dyr * dyr) / lam_max;
-            const float far_x = dxr + 16.0f, far_y = dyr + 16.0f;   // >= |ex|, |ey| of every pixel
-            const float tol = 0.01f + 4e-6f * (fabsf(ix) * far_x * far_x + fabsf(iz) * far_y * far_y +
-                                               2.0f * fabsf(iy) * far_x * far_y);
-            const bool reject = det > 0.0f && lam_max > 0.0f && (bound + tol < fthr);
+            // Whole-tile rejection (the reference assigns tiles by a 3-sigma bounding box, so many list
+            // entries touch no pixel of the tile).  With u = sx - px, v = py - sy the shader's exponent is
+            // f = -q/2, q(u,v) = ix u^2 + 2 iy u v + iz v^2 (positive definite for a valid covariance).
+            // Over the wave's pixel rectangle q is minimal either at the centre (inside: keep) or on one
+            // of the four edges, where it is a 1-D parabola with a closed-form clamped minimiser.  If
+            // -q_min/2, widened by a generous bound on the fp32 error of the per-pixel f, is below the
+            // skip threshold, every pixel would `continue` (:127): dropping the splat is unobservable.
+            const float u0 = sx - (tile_x0 + 15.0f), u1 = sx - tile_x0;                 // u range (u0 <= u1)
+            const float v0 = tile_y0 - sy, v1 = tile_y0 + (float)(ROWS - 1) - sy;       // v range
+            bool reject = false;
+            if (det > 0.0f && ix > 0.0f && iz > 0.0f && !(u0 <= 0.0f && u1 >= 0.0f && v0 <= 0.0f && v1 >= 0.0f)) {
+                auto edge_u = [&](float ue) {   // min over v in [v0,v1] of q(ue, v)
+                    const float vs = fminf(fmaxf(-iy * ue / iz, v0), v1);
+                    return ix * ue * ue + 2.0f * iy * ue * vs + iz * vs * vs;
+                };
+                auto edge_v = [&](float ve) {   // min over u in [u0,u1] of q(u, ve)
+                    const float us = fminf(fmaxf(-iy * ve / ix, u0), u1);
+                    return ix * us * us + 2.0f * iy * us * ve + iz * ve * ve;
+                };
+                const float qmin = fminf(fminf(edge_u(u0), edge_u(u1)), fminf(edge_v(v0), edge_v(v1)));
+                const float far_x = fmaxf(fabsf(u0), fabsf(u1)), far_y = fmaxf(fabsf(v0), fabsf(v1));
+                const float mag = fabsf(ix) * far_x * far_x + fabsf(iz) * far_y * far_y + 2.0f * fabsf(iy) * far_x * far_y;
+                const float tol = 0.01f + 8e-6f * mag;      // >> rounding of qmin here and of f in the pixel loop
+                reject = (-0.5f * qmin + tol < fthr);
+            }
             keep = !reject;
         }
         const uint64_t kmask = __ballot(keep);
