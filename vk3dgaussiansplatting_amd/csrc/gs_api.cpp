@@ -25,6 +25,8 @@ struct gs_ctx {
     hipEvent_t ev[7] = {};
     hipEvent_t scatter_ev[32] = {};   // record_timings == 2: a pair per pass (<= 16 passes)
     hipEvent_t alt_ev[2] = {};        // GS_SORT_TILE_BUCKET: after FindRanges / after the per-tile sort
+    hipStream_t helper_stream = nullptr;   // GS_SORT_TILE_BUCKET: big size classes run beside the small ones
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     std::string last_error;
 
     // scene
@@ -175,7 +177,8 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
         const int si = c->sorted_index;
         if (tm) HIP_TRY(c, hipEventRecord(c->alt_ev[0], st));
         launch_tile_sort(c->ranges, c->row_begin * c->grid_w, (c->row_end - c->row_begin) * c->grid_w,
-                         c->sort.lo[si], c->sort.id[si], c->sort.lo[si ^ 1], c->sort.id[si ^ 1], st);
+                         c->sort.lo[si], c->sort.id[si], c->sort.lo[si ^ 1], c->sort.id[si ^ 1], st,
+                         c->helper_stream, c->fork_ev, c->join_ev);
         if (int r = check_launch(c, "TileSort")) return r;
         if (tm) HIP_TRY(c, hipEventRecord(c->alt_ev[1], st));
     }
@@ -286,9 +289,19 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
             gs_destroy(c);
             return fail(nullptr, GS_ERR_HIP, msg);
         }
-    if (cfg.sort_algorithm == GS_SORT_TILE_BUCKET && init_tile_sort() != 0) {
-        gs_destroy(c);
-        return fail(nullptr, GS_ERR_HIP, "gs_create: cannot reserve 160 KB of LDS for the per-tile sort");
+    if (cfg.sort_algorithm == GS_SORT_TILE_BUCKET) {
+        if (init_tile_sort() != 0) {
+            gs_destroy(c);
+            return fail(nullptr, GS_ERR_HIP, "gs_create: cannot reserve 160 KB of LDS for the per-tile sort");
+        }
+        e = hipStreamCreateWithFlags(&c->helper_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            std::string msg = std::string("gs_create: ") + hipGetErrorString(e);
+            gs_destroy(c);
+            return fail(nullptr, GS_ERR_HIP, msg);
+        }
     }
     if (cfg.record_timings >= 2)
         for (auto& ev : c->scatter_ev)
@@ -310,6 +323,9 @@ int gs_destroy(gs_ctx* c) {
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : c->scatter_ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : c->alt_ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->join_ev) (void)hipEventDestroy(c->join_ev);
+    if (c->helper_stream) { (void)hipStreamSynchronize(c->helper_stream); (void)hipStreamDestroy(c->helper_stream); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return GS_OK;

@@ -117,7 +117,8 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
 // GS_SORT_TILE_BUCKET: per-tile depth sort of tiles [tile0, tile0 + num_tiles) (gs_tilesort.hip)
 int init_tile_sort();
 void launch_tile_sort(const uint32_t* ranges, uint32_t tile0, uint32_t num_tiles, uint32_t* lo, uint32_t* id,
-                      uint32_t* lo_alt, uint32_t* id_alt, hipStream_t stream);
+                      uint32_t* lo_alt, uint32_t* id_alt, hipStream_t stream, hipStream_t helper = nullptr,
+                      hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 void launch_find_ranges(const uint32_t* sorted_tile, const SortParams* params, uint32_t capacity,
                         uint32_t* ranges, hipStream_t stream);
 void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,

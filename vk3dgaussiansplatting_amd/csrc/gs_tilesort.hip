@@ -275,14 +275,28 @@ int init_tile_sort() {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// The size classes touch disjoint tiles, so the rare big ones (few workgroups, whole-CU LDS) run on a
+// helper stream beside the two small classes that hold most of the work: fork after FindRanges, join
+// before RenderGaussians.
 void launch_tile_sort(const uint32_t* ranges, uint32_t tile0, uint32_t num_tiles, uint32_t* lo, uint32_t* id,
-                      uint32_t* lo_alt, uint32_t* id_alt, hipStream_t stream) {
+                      uint32_t* lo_alt, uint32_t* id_alt, hipStream_t stream, hipStream_t helper,
+                      hipEvent_t fork, hipEvent_t join) {
     if (num_tiles == 0) return;
-#define X(KERNEL, THREADS, NMAX)                                                                 \
-    hipLaunchKernelGGL(KERNEL, dim3(num_tiles), dim3(THREADS), ts_lds_bytes(NMAX), stream, ranges, lo, id, tile0);
-    TS_KERNELS(X)
-#undef X
-    hipLaunchKernelGGL(k_tile_sort_global, dim3(num_tiles), dim3(1024), 0, stream, ranges, lo, id, lo_alt, id_alt, tile0);
+    const bool split = helper != nullptr && fork != nullptr && join != nullptr;
+    hipStream_t big = split ? helper : stream;
+    if (split) {
+        (void)hipEventRecord(fork, stream);
+        (void)hipStreamWaitEvent(helper, fork, 0);
+    }
+    hipLaunchKernelGGL((k_tile_sort_lds<512, 8, 2048u, 4096u>), dim3(num_tiles), dim3(512), ts_lds_bytes(4096u), big, ranges, lo, id, tile0);
+    hipLaunchKernelGGL((k_tile_sort_lds<1024, 0, 4096u, kTsBigMax>), dim3(num_tiles), dim3(1024), ts_lds_bytes(kTsBigMax), big, ranges, lo, id, tile0);
+    hipLaunchKernelGGL(k_tile_sort_global, dim3(num_tiles), dim3(1024), 0, big, ranges, lo, id, lo_alt, id_alt, tile0);
+    hipLaunchKernelGGL((k_tile_sort_lds<256, 8, 1024u, 2048u>), dim3(num_tiles), dim3(256), ts_lds_bytes(2048u), stream, ranges, lo, id, tile0);
+    hipLaunchKernelGGL((k_tile_sort_lds<256, 4, 1u, 1024u>), dim3(num_tiles), dim3(256), ts_lds_bytes(1024u), stream, ranges, lo, id, tile0);
+    if (split) {
+        (void)hipEventRecord(join, helper);
+        (void)hipStreamWaitEvent(stream, join, 0);
+    }
 }
 
 } // namespace gs
