@@ -505,9 +505,12 @@ def test_api_call_order_and_reuse(small_cloud):
     r.cleanup()
 
 
-def test_sort_stress_sortedness():
-    """Sorter alone at 20 M random keys (device-generated): sortedness checked on the device."""
+@pytest.mark.parametrize("n", [20_000_000, 150_000_000])
+def test_sort_stress_sortedness(n):
+    """Sorter alone on device-generated random keys: sortedness checked on the device.  150 M elements
+    exceed 64 groups per reduce segment (the looped ScanAdd prologue)."""
     rs = gs.RadixSort()
-    ms, ok = rs.bench(20_000_000, 8160, iters=2, seed=3)
+    ms, ok = rs.bench(n, 8160, iters=2, seed=3)
     assert ok and ms > 0
+    print(f"n={n}: {ms:.3f} ms per sort, {n / ms / 1e3:.0f} M elements/s")
     rs.cleanup()

@@ -107,8 +107,6 @@ int alloc_sort(gs_ctx* ctx, SortBuffers& s, uint32_t capacity) {
         HIP_TRY(ctx, hipMalloc((void**)&s.id[k], bytes));
     }
     const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
-    if (max_groups > (uint32_t)kSegments * 64u)
-        return fail(ctx, GS_ERR_INVALID, "sort list too large for the segment table (> 268M elements)");
     HIP_TRY(ctx, hipMalloc((void**)&s.table, (size_t)kBins * max_groups * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc((void**)&s.seg_sum, (size_t)kBins * kSegments * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc((void**)&s.params, sizeof(SortParams)));

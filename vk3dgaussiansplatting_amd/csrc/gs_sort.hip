@@ -241,11 +241,13 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
         // ---- ScanAdd: keys of digit d in all groups before this one = scanned segment base +
         //      counts of the earlier groups of the same segment (wave w: digits 4w..4w+3)
         {
-            const uint32_t seg = grp / K, j = grp - seg * K;   // j < K <= 64
+            const uint32_t seg = grp / K, j = grp - seg * K;   // j < K (K <= 64 up to 134 M elements)
 #pragma unroll
             for (int q = 0; q < kBins / kSortWaves; ++q) {
                 const int d = wave * (kBins / kSortWaves) + q;
-                uint32_t pre = (uint32_t)lane < j ? table[d * G + seg * K + lane] : 0u;
+                uint32_t pre = 0;
+                for (uint32_t l0 = 0; l0 < j; l0 += 64)
+                    pre += l0 + (uint32_t)lane < j ? table[d * G + seg * K + l0 + lane] : 0u;
                 pre = wave_sum_to_lane63(pre);
                 if (lane == 63) s_gpre[d] = pre + seg_base[d * kSegments + seg];
             }
