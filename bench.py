@@ -208,6 +208,21 @@ def main():
     else:
         allstats = [stats]
 
+    # measured device-to-device stream copy on this GPU (north_star: "measured HBM roofline")
+    copy_gbps = None
+    if rank == 0:
+        try:
+            import ctypes as C
+            from vk3dgaussiansplatting_amd import _lib
+            probe = C.c_void_p()
+            if _lib.lib().gs_create(None, C.byref(probe)) == 0:
+                g_, ms_ = C.c_float(), C.c_float()
+                if _lib.lib().gs_membench(probe, 1, 1 << 30, 2048, 10, C.byref(g_), C.byref(ms_)) == 0:
+                    copy_gbps = float(g_.value)
+                _lib.lib().gs_destroy(probe)
+        except Exception as ex:  # noqa: BLE001 -- the probe is informational
+            log(f"[bench] stream-copy probe failed: {ex}")
+
     if rank == 0:
         e_total = int(sum(float(s[0]) for s in allstats))
         value = n / ms_per_step / 1000.0            # Msplats/s, whole job
@@ -252,7 +267,9 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scat, 5),
-                         "launches_per_frame": passes},
+                         "launches_per_frame": passes,
+                         "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
+                         "frac_of_measured_copy": round(achieved / copy_gbps, 4) if copy_gbps else None},
         }
         if alt is not None:
             out["alt"] = alt
