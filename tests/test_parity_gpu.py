@@ -305,6 +305,62 @@ def test_config_b_full_size_keys_and_ranges(oracle_mod):
         r.cleanup()
 
 
+def test_config_d_4k_keys_and_ranges(oracle_mod):
+    """BASELINE config D shape (Garden-30k @ 3840x2160, 32,400 tiles, E = 33 M): keys/ranges bit-exact for the
+    contractual sorter; the alternative sorter must give the same bytes."""
+    aos, cfg = synth.generate_config("D")
+    w, h = cfg["width"], cfg["height"]
+    sc = make_scene(aos, w, h)
+    cam = sc.getCamera()
+    p = oracle_mod.make_params(w, h, cam.getViewMatrix(), cam.getProjectionMatrix(), cam.getPosition())
+    s1 = oracle_mod.init_sort_list(p, aos)
+    e = s1["counter"]
+    ot, od, oi = oracle_mod.sort_stable(s1["tile"], s1["depth"], s1["id"], e)
+    oranges = oracle_mod.find_ranges(ot, e, 240 * 135)
+    outs = []
+    for sort in (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET):
+        r = make_renderer(sc, w, h, sort=sort)
+        img = r.draw(sc)
+        assert r.sceneInfo().capacity == 2**26 and r.sceneInfo().num_sort_bits == 48
+        assert r.timings().num_sort_elements == e and r.timings().overflowed == 0
+        assert np.array_equal(r.debugRead(gs.BUF_SORTED_TILE), ot[:e])
+        assert np.array_equal(r.debugRead(gs.BUF_SORTED_DEPTH), od[:e])
+        assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), oi[:e])
+        assert np.array_equal(r.debugRead(gs.BUF_RANGES), oranges)
+        outs.append(img.copy())
+        r.cleanup()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_c_abi_call_order_status_codes(small_cloud):
+    """Straight through ctypes: wrong call order is reported, never fatal."""
+    import ctypes as C
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.gs_create(None, C.byref(h)) == 0
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    pos = np.zeros(3, np.float32)
+    out = np.zeros((64, 64, 4), np.uint8)
+    pp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert L.gs_render(h, pp(ident), pp(ident), pp(pos), 0, pp(out)) == _lib.GS_ERR_NO_SCENE
+    assert L.gs_set_resolution(h, 64, 64) == _lib.GS_ERR_NO_SCENE
+    assert L.gs_upload_gaussians(h, pp(small_cloud), small_cloud.shape[0]) == 0
+    assert L.gs_render(h, pp(ident), pp(ident), pp(pos), 0, pp(out)) == _lib.GS_ERR_NO_SCENE   # no resolution yet
+    assert b"gs_set_resolution" in L.gs_last_error(h)
+    assert L.gs_set_resolution(h, 0, 64) == _lib.GS_ERR_INVALID
+    assert L.gs_set_resolution(h, 64, 64) == 0
+    assert L.gs_set_tile_rows(h, 3, 2) == _lib.GS_ERR_INVALID
+    assert L.gs_set_tile_rows(h, 0, 5) == _lib.GS_ERR_INVALID       # only 4 tile rows
+    assert L.gs_render(h, pp(ident), pp(ident), pp(pos), 3, pp(out)) == _lib.GS_ERR_INVALID   # sh_mode
+    assert L.gs_render(h, pp(ident), pp(ident), pp(pos), 0, None) == _lib.GS_ERR_INVALID
+    assert L.gs_render(h, pp(ident), pp(ident), pp(pos), 0, pp(out)) >= 0
+    buf = np.zeros(1 << 20, np.uint8)
+    assert L.gs_debug_read(h, 99, pp(buf), 16) == _lib.GS_ERR_INVALID
+    assert L.gs_debug_read(h, _lib.BUF_RANGES, pp(buf), buf.nbytes) == _lib.GS_ERR_INVALID   # larger than the buffer
+    assert L.gs_debug_read(h, _lib.BUF_RANGES, pp(buf), 16 * 2 * 4) == 0
+    assert L.gs_destroy(h) == 0
+
+
 def test_cpp_driver_runs(tmp_path):
     """tools/gsplat_bench.cpp: the C++ caller that mirrors the reference's main loop, over the same C-ABI."""
     import subprocess
