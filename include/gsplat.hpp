@@ -1,0 +1,92 @@
+// gsplat.hpp -- header-only C++17 convenience layer over the C-ABI of gsplat.h, shaped like the
+// reference's Renderer (Engine/Graphics/Renderer.h:154-161: init / initForScene / draw / cleanup) so
+// that a maintainer of the reference can swap the class in.  No state beyond the
+// gs_ctx handle; errors surface as status codes + lastError(), never as exceptions or aborts
+// (the reference logs and continues, Engine/Dev/Log.cpp:40-43).
+#pragma once
+
+#include "gsplat.h"
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace gsplat {
+
+struct Timings : gs_timings {};   // init_sort_list_ms, radix_sort_ms, find_ranges_ms, render_ms, total_ms
+
+class Renderer {
+public:
+    // Renderer.h:142-143
+    static constexpr uint32_t WAIT_ELAPSED_WARMUP_FRAMES_FOR_AVG = 1000;
+    static constexpr uint32_t WAIT_ELAPSED_FRAMES_FOR_AVG = 1000;
+
+    Renderer(uint32_t width, uint32_t height) : width_(width), height_(height) {}
+    Renderer(const Renderer&) = delete;
+    Renderer& operator=(const Renderer&) = delete;
+    ~Renderer() { cleanup(); }
+
+    // Renderer::init (Renderer.cpp:688-694).  cfg == nullptr: the reference's constants.
+    int init(const gs_config* cfg = nullptr) {
+        cleanup();
+        const int rc = gs_create(cfg, &ctx_);
+        if (rc != GS_OK) error_ = gs_last_error(nullptr);
+        return rc;
+    }
+
+    // Renderer::initForScene (Renderer.cpp:712-756): records = ResourceManager::getGaussians(), 336 B each.
+    int initForScene(const void* gaussianRecords, uint32_t numGaussians) {
+        int rc = gs_upload_gaussians(ctx_, gaussianRecords, numGaussians);
+        if (rc == GS_OK) rc = gs_set_resolution(ctx_, width_, height_);
+        if (rc != GS_OK) error_ = gs_last_error(ctx_);
+        elapsedFrames_ = 0;
+        for (double& a : avg_) a = 0.0;
+        return rc;
+    }
+    int initForScenePly(const std::string& path) {   // ResourceManager::loadGaussians + initForScene
+        int rc = gs_load_ply(ctx_, path.c_str());
+        if (rc == GS_OK) rc = gs_set_resolution(ctx_, width_, height_);
+        if (rc != GS_OK) error_ = rc == GS_ERR_IO || rc == GS_ERR_FORMAT ? gs_ply_last_error() : gs_last_error(ctx_);
+        return rc;
+    }
+
+    // Renderer::draw (Renderer.cpp:297-515).  view/proj: column-major float[16] (glm::mat4 memory);
+    // shMode 0/1/2 (Camera.h:7-12); rgbaOut: height*width*4 bytes, top row first.
+    int draw(const float* view, const float* proj, const float* camPos, uint32_t shMode, uint8_t* rgbaOut) {
+        const int rc = gs_render(ctx_, view, proj, camPos, shMode, rgbaOut);
+        if (rc < 0) { error_ = gs_last_error(ctx_); return rc; }
+        gs_get_timings(ctx_, &last_);
+        if (elapsedFrames_ >= WAIT_ELAPSED_WARMUP_FRAMES_FOR_AVG) {       // Renderer.cpp:477-488
+            const double t = 1.0 / double(elapsedFrames_ - WAIT_ELAPSED_WARMUP_FRAMES_FOR_AVG + 1);
+            const double v[5] = {last_.init_sort_list_ms, last_.radix_sort_ms, last_.find_ranges_ms,
+                                 last_.render_ms, last_.total_ms};
+            for (int i = 0; i < 5; ++i) avg_[i] = (1.0 - t) * avg_[i] + t * v[i];
+        }
+        ++elapsedFrames_;
+        return rc;
+    }
+
+    // Renderer::cleanup (Renderer.cpp:230-270)
+    void cleanup() {
+        if (ctx_) { gs_destroy(ctx_); ctx_ = nullptr; }
+    }
+
+    const gs_timings& lastTimings() const { return last_; }
+    // avgInitSortListMs, avgSortMs, avgFindRangesMs, avgRenderGaussiansMs, avgTotalGpuTimeMs (Renderer.h)
+    const double* averages() const { return avg_; }
+    const std::string& lastError() const { return error_; }
+    gs_ctx* handle() const { return ctx_; }
+
+    static uint32_t getCeilPowTwo(uint32_t x) { uint32_t n = 1; while (n < x) n *= 2; return n; }   // Renderer.cpp:703-710
+    uint32_t getNumTiles() const { return ((width_ + 15) / 16) * ((height_ + 15) / 16); }            // Renderer.cpp:696-701
+
+private:
+    gs_ctx* ctx_ = nullptr;
+    uint32_t width_, height_;
+    gs_timings last_{};
+    double avg_[5] = {0, 0, 0, 0, 0};
+    uint64_t elapsedFrames_ = 0;
+    std::string error_;
+};
+
+}  // namespace gsplat

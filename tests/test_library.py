@@ -40,6 +40,20 @@ def test_product_never_imports_oracle():
                 assert "libgs_oracle" not in line, (f, line)
 
 
+def test_cpp_wrapper_header_compiles(tmp_path):
+    """include/gsplat.hpp (header-only mirror of the reference's Renderer) must compile as plain C++17
+    against the C header alone and link with the library."""
+    import subprocess
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "gsplat.hpp"\nint main() { gsplat::Renderer r(64, 64); int rc = r.init();'
+                   ' return (rc == GS_OK || rc == GS_ERR_NO_DEVICE) ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-lgsplat_hip", f"-Wl,-rpath,{libdir}"], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+
+
 @pytest.mark.skipif(has_gpu(), reason="only meaningful on a GPU-less host")
 def test_create_fails_loudly_without_gpu():
     with pytest.raises(gs.GsplatError) as ei:
