@@ -124,20 +124,46 @@ def main():
     sf = gsdist.ShardedFrame(w, h, rank, world, device=device, host_gather=args.rehearse)
     rb, re = sf.band
     r.setTileRows(rb, re)
-    # the library addresses the FULL frame; hand it the strip shifted up by the band's first row
-    strip_ptr = sf.strip.data_ptr() - rb * 16 * w * 4
+    # the library addresses the FULL frame; hand it the strips shifted up by the band's first row
+    strip_ptrs = [s_.data_ptr() - rb * 16 * w * 4 for s_ in sf.strips]
+    strip_ptr = strip_ptrs[0]
     r.setStream(torch.cuda.current_stream().cuda_stream)   # same stream as the RCCL gather
 
-    def step():
-        r.drawDevice(scene, strip_ptr, sync=False)
+    step_no = [0]
+
+    def step(renderer=None):
+        # two strips in flight: the gather of frame f (RCCL's own stream) overlaps the compute of frame f+1
+        k = step_no[0] & 1
+        step_no[0] += 1
+        sf.wait(k)
+        (renderer or r).drawDevice(scene, strip_ptrs[k], sync=False)
         if world > 1:
-            sf.gather()
+            sf.gather_async(k)
 
     def barrier():
+        sf.wait_all()
         torch.cuda.synchronize()
         if world > 1:
             tdist.barrier()
             torch.cuda.synchronize()
+
+    # N > 1: the assembled frame must equal what one GPU renders alone (checked once, untimed)
+    sharded_ok = None
+    if world > 1:
+        sf.wait(0)
+        r.drawDevice(scene, strip_ptrs[0], sync=False)
+        strips = sf.gather(0)
+        torch.cuda.synchronize()
+        if rank == 0:
+            full = torch.zeros((h, w, 4), dtype=torch.uint8, device=device)
+            rf = make(0)
+            rf.setStream(torch.cuda.current_stream().cuda_stream)
+            rf.drawDevice(scene, full.data_ptr(), sync=True)
+            rf.setStream(None)
+            rf.cleanup()
+            sharded_ok = bool(torch.equal(sf.assemble(strips).to(full.device), full))
+            log(f"[bench] sharded frame equals the single-GPU frame: {sharded_ok}")
+        barrier()
 
     for _ in range(args.warmup):
         step()
@@ -186,13 +212,11 @@ def main():
         ra.setTileRows(rb, re)
         ra.setStream(torch.cuda.current_stream().cuda_stream)
         for _ in range(10):
-            ra.drawDevice(scene, strip_ptr, sync=False)
+            step(ra)
         barrier()
         t_a = time.perf_counter()
         for _ in range(args.steps):
-            ra.drawDevice(scene, strip_ptr, sync=False)
-            if world > 1:
-                sf.gather()
+            step(ra)
         barrier()
         alt_ms = (time.perf_counter() - t_a) / args.steps * 1e3
         ra.setStream(None)
@@ -274,6 +298,7 @@ def main():
         if alt is not None:
             out["alt"] = alt
         if world > 1:
+            out["sharded_image_matches_single_gpu"] = sharded_ok
             out["per_rank_total_ms"] = [round(float(s[6]), 4) for s in allstats]
             out["per_rank_sort_elements"] = [int(s[0]) for s in allstats]
         if world == 1 and not args.no_cpu_baseline:

@@ -32,10 +32,14 @@ def strip_rows(tiles_y: int, world_size: int, tile: int = 16) -> int:
 
 
 class ShardedFrame:
-    """Band render + gather.  `render_band(row_begin, row_end, strip)` must write the band's pixel
-    rows into the first rows of `strip` ([strip_rows, W, 4] uint8, torch tensor on the rank's
-    device or CPU); it is the only thing that differs between the GPU path (Renderer.drawDevice
-    into the strip's storage) and the CPU test (an injected checker)."""
+    """Band render + gather.  Two strips (ping-pong) so that the gather of frame f can run beside the
+    compute of frame f+1: `gather_async(k)` starts the collective on strip k, `wait(k)` orders the
+    current stream (or the host, for gloo) behind it before strip k is rendered into again.
+
+    `render_band(row_begin, row_end, strip)` (see `frame`) must write the band's pixel rows into the
+    first rows of `strip` ([strip_rows, W, 4] uint8, torch tensor on the rank's device or CPU); it is
+    the only thing that differs between the GPU path (Renderer.drawDevice into the strip's storage) and
+    the CPU test (an injected checker)."""
 
     def __init__(self, width: int, height: int, rank: int, world_size: int, device="cpu", group=None,
                  host_gather: bool = False):
@@ -48,25 +52,49 @@ class ShardedFrame:
         self.rows = strip_rows(self.tiles_y, world_size)
         self.group = group
         self.device = device
-        self.strip = torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=device)
+        self.strips = [torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=device) for _ in range(2)]
         # host_gather: rehearsal of the N > 1 path on one GPU (gloo has no device gather)
         self.host_gather = host_gather
         gdev = "cpu" if host_gather else device
-        self.gathered = ([torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=gdev) for _ in range(world_size)]
-                         if rank == 0 and world_size > 1 else None)
+        self.gathered = [([torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=gdev) for _ in range(world_size)]
+                          if rank == 0 and world_size > 1 else None) for _ in range(2)]
+        self._pending = [None, None]
+
+    @property
+    def strip(self):
+        return self.strips[0]
 
     @property
     def band(self) -> Tuple[int, int]:
         return self.bands[self.rank]
 
-    def gather(self):
-        """All ranks call; rank 0 gets the list of strips."""
+    def gather_async(self, k: int = 0):
+        """All ranks call, in the same order; starts the gather of strip k to rank 0."""
         if self.world == 1:
-            return [self.strip]
+            return
         import torch.distributed as dist
-        src = self.strip.cpu() if self.host_gather else self.strip
-        dist.gather(src, self.gathered, dst=0, group=self.group)
-        return self.gathered
+        src = self.strips[k].cpu() if self.host_gather else self.strips[k]
+        work = dist.gather(src, self.gathered[k], dst=0, group=self.group, async_op=True)
+        self._pending[k] = (work, src)
+
+    def wait(self, k: int = 0):
+        """Order everything that follows (rendering into strip k again, reading gathered[k]) behind the
+        pending gather of strip k."""
+        if self._pending[k] is not None:
+            self._pending[k][0].wait()
+            self._pending[k] = None
+
+    def wait_all(self):
+        self.wait(0)
+        self.wait(1)
+
+    def gather(self, k: int = 0):
+        """Synchronous form: rank 0 gets the list of strips."""
+        if self.world == 1:
+            return [self.strips[k]]
+        self.gather_async(k)
+        self.wait(k)
+        return self.gathered[k]
 
     def assemble(self, strips) -> "np.ndarray":
         """Rank 0: strips -> [H, W, 4] image (crops the padding of the last band)."""
@@ -77,10 +105,11 @@ class ShardedFrame:
                 img[y0:y1] = strips[r][: y1 - y0]
         return img
 
-    def frame(self, render_band: Callable) -> "np.ndarray | None":
+    def frame(self, render_band: Callable, k: int = 0) -> "np.ndarray | None":
         b, e = self.band
-        render_band(b, e, self.strip)
-        strips = self.gather()
+        self.wait(k)
+        render_band(b, e, self.strips[k])
+        strips = self.gather(k)
         if self.rank == 0:
             return self.assemble(strips)
         return None
