@@ -332,6 +332,39 @@ def test_config_d_4k_keys_and_ranges(oracle_mod):
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_extreme_but_finite_inputs(oracle_mod):
+    """Saturating conversions, huge and tiny footprints, splats on the cull boundaries, opacity 0 and 1,
+    large SH coefficients: the HIP path must make exactly the oracle's decisions (counter, keys, ranges,
+    pixels), including list overflow caused by the screen-filling splats."""
+    rng = np.random.default_rng(2024)
+    w, h = 200, 120
+    n = 4000
+    aos = synth.generate(n, w, h, -2.5, seed=99, morton=False)
+    # scales from 1e-7 to 1e4 (radius saturates the int conversion for the largest)
+    aos[:, 4:7] = np.exp(rng.uniform(np.log(1e-7), np.log(1e4), (n, 3))).astype(np.float32)
+    # a block of splats hugging the near plane and the 1.3 NDC side planes
+    k = 500
+    aos[:k, 2] = np.float32(0.1) + np.float32(1e-6) * rng.integers(0, 40, k).astype(np.float32)
+    aos[:k, 0] = aos[:k, 2] * np.float32(w / h) * rng.choice(np.float32([1.2999, 1.3, 1.3001, -1.3, 0.0]), k)
+    aos[:k, 1] = aos[:k, 2] * rng.choice(np.float32([1.2999, 1.3, 1.3001, -1.3, 0.5]), k)
+    # far beyond the far plane (depth key saturates) -- there is no far cull in the reference
+    aos[k:2 * k, 2] = rng.uniform(90, 5000, k).astype(np.float32)
+    aos[k:2 * k, 0] = aos[k:2 * k, 2] * rng.uniform(-1, 1, k).astype(np.float32)
+    aos[k:2 * k, 1] = aos[k:2 * k, 2] * rng.uniform(-0.7, 0.7, k).astype(np.float32)
+    aos[:, 15] = rng.choice(np.float32([0.0, 1.0, 0.5, 1e-3, 0.999]), n)          # opacity
+    aos[::7, 12:15] = rng.uniform(-100, 100, (len(aos[::7]), 3)).astype(np.float32)  # SH dc
+    aos[::11, 8:12] = 0.0                                                             # zero quaternion
+    aos[::13, 4:7] = 0.0                                                              # zero scale
+    sc = make_scene(aos, w, h)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    assert np.isfinite(ref["stage1"]["cov"]).all() and np.isfinite(ref["stage1"]["color"]).all()
+    for sort in (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET):
+        r = make_renderer(sc, w, h, sort=sort)
+        img = r.draw(sc)
+        assert_frame_equals_oracle(r, img, ref)
+        r.cleanup()
+
+
 def test_c_abi_call_order_status_codes(small_cloud):
     """Straight through ctypes: wrong call order is reported, never fatal."""
     import ctypes as C
