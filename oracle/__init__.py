@@ -97,6 +97,7 @@ def lib() -> C.CDLL:
         L.gso_render.argtypes = [PP, vp, vp, vp, vp, vp, vp]
         L.gso_render_libm_exp.argtypes = [PP, vp, vp, vp, vp, vp, vp]
         L.gso_frame.argtypes = [PP, vp, u32, vp, vp]; L.gso_frame.restype = u32
+        L.gso_frame_mt.argtypes = [PP, vp, u32, vp, vp, u32]; L.gso_frame_mt.restype = u32
         L.gso_camera_matrices.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                           C.c_float, vp, vp]
         L.gso_morton.argtypes = [u32, u32, u32]; L.gso_morton.restype = u32
@@ -216,6 +217,15 @@ def frame(p: Params, aos):
     out = np.zeros((p.height, p.width, 4), dtype=np.uint8)
     t = np.zeros(5, dtype=np.float64)
     e = lib().gso_frame(C.byref(p), _ptr(aos), aos.shape[0], _ptr(out), _ptr(t))
+    return out, int(e), t
+
+
+def frame_mt(p: Params, aos, threads: int):
+    """Whole frame on `threads` host threads; same image and E as frame()."""
+    aos = np.ascontiguousarray(aos, dtype=np.float32).reshape(-1, FLOATS_PER_GAUSSIAN)
+    out = np.zeros((p.height, p.width, 4), dtype=np.uint8)
+    t = np.zeros(5, dtype=np.float64)
+    e = lib().gso_frame_mt(C.byref(p), _ptr(aos), aos.shape[0], _ptr(out), _ptr(t), int(threads))
     return out, int(e), t
 
 

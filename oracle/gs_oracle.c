@@ -7,6 +7,7 @@
  * /root/reference/vkGaussianSplatting/ (S/ = Resources/Shaders/).
  */
 #define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
 #include "gs_oracle.h"
 
 #include <math.h>
@@ -743,6 +744,206 @@ uint32_t gso_frame(const gso_params* p, const float* aos, uint32_t n, uint8_t* r
         timings_ms[4] = t4 - t0;
     }
     free(color); free(cov); free(lt); free(ld); free(li); free(ranges);
+    return e;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Whole frame on several host threads (the all-cores CPU baseline).  The     */
+/* reference has no CPU path; this is the same restatement, split the way its GPU stages are  */
+/* data-parallel: splats for InitSortList (count, scan, emit -- the deterministic order N8),  */
+/* a parallel stable LSD radix (8-bit digits over the 4P key bits) for the sort, tile rows    */
+/* for RenderGaussians.  Every per-element value comes from the single-thread functions       */
+/* above, so the image and the sorted list equal gso_frame()'s (tests/test_oracle.py).        */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct mt_ctx {
+    const gso_params* p;
+    const float* aos;
+    uint32_t n, threads, e, bits;
+    float *color, *cov;
+    gso_splat* splats;
+    uint64_t* offsets;                 /* exclusive scan of per-splat element counts */
+    uint32_t cap;
+    uint32_t *t[2], *d[2], *i[2];      /* ping-pong sort list (SoA) */
+    uint32_t* hist;                    /* [threads][256] */
+    uint32_t shift, src;
+    const uint32_t* ranges;
+    uint8_t* rgba;
+    volatile uint32_t next_row;        /* dynamic tile-row queue for the render phase */
+    pthread_mutex_t lock;
+} mt_ctx;
+
+typedef struct mt_arg { mt_ctx* c; uint32_t tid; void (*fn)(mt_ctx*, uint32_t); } mt_arg;
+
+static void* mt_tramp(void* a) {
+    mt_arg* m = (mt_arg*)a;
+    m->fn(m->c, m->tid);
+    return NULL;
+}
+
+static void mt_run(mt_ctx* c, void (*fn)(mt_ctx*, uint32_t)) {
+    pthread_t th[GSO_MAX_THREADS];
+    mt_arg args[GSO_MAX_THREADS];
+    for (uint32_t k = 0; k < c->threads; ++k) {
+        args[k].c = c; args[k].tid = k; args[k].fn = fn;
+        if (k + 1 == c->threads) mt_tramp(&args[k]);            /* caller works too */
+        else pthread_create(&th[k], NULL, mt_tramp, &args[k]);
+    }
+    for (uint32_t k = 0; k + 1 < c->threads; ++k) pthread_join(th[k], NULL);
+}
+
+static void mt_chunk(uint32_t total, uint32_t parts, uint32_t k, uint32_t* b, uint32_t* e) {
+    const uint64_t per = ((uint64_t)total + parts - 1) / parts;
+    uint64_t lo = per * k, hi = lo + per;
+    if (lo > total) lo = total;
+    if (hi > total) hi = total;
+    *b = (uint32_t)lo; *e = (uint32_t)hi;
+}
+
+/* phase 1: project + count (gso_init_sort_list without a list = count only) */
+static void mt_project(mt_ctx* c, uint32_t tid) {
+    uint32_t b, e;
+    mt_chunk(c->n, c->threads, tid, &b, &e);
+    if (e > b)
+        gso_init_sort_list(c->p, c->aos + (size_t)b * GSO_FLOATS_PER_GAUSSIAN, e - b, 0,
+                           c->color + (size_t)b * 4, c->cov + (size_t)b * 4, c->splats + b, NULL, NULL, NULL);
+}
+
+static void splat_band(const gso_params* p, const gso_splat* s, uint32_t* y0, uint32_t* y1) {
+    *y0 = s->min_y > p->row_begin ? s->min_y : p->row_begin;     /* as gso_init_sort_list */
+    *y1 = s->max_y < p->row_end ? s->max_y : p->row_end;
+    if (*y1 < *y0) *y1 = *y0;
+}
+
+/* phase 2: emit at the scanned offsets (InitSortList.comp:130-150, ascending splat index) */
+static void mt_emit(mt_ctx* c, uint32_t tid) {
+    uint32_t b, e;
+    mt_chunk(c->n, c->threads, tid, &b, &e);
+    const uint32_t grid_w = gso_num_tiles_x(c->p->width, c->p->tile_size);
+    for (uint32_t g = b; g < e; ++g) {
+        const gso_splat* s = &c->splats[g];
+        if (!s->visible) continue;
+        uint32_t y0, y1;
+        splat_band(c->p, s, &y0, &y1);
+        uint64_t id = c->offsets[g];
+        for (uint32_t y = y0; y < y1; ++y)
+            for (uint32_t x = s->min_x; x < s->max_x; ++x, ++id)
+                if (id < c->cap) {                                /* :143 */
+                    c->t[0][id] = y * grid_w + x;
+                    c->d[0][id] = s->depth_key;
+                    c->i[0][id] = g;
+                }
+    }
+}
+
+static inline uint32_t mt_digit(uint32_t tile, uint32_t depth, uint32_t shift) {
+    return (shift < 32 ? depth >> shift : tile >> (shift - 32)) & 255u;
+}
+
+static void mt_hist(mt_ctx* c, uint32_t tid) {
+    uint32_t b, e;
+    mt_chunk(c->e, c->threads, tid, &b, &e);
+    uint32_t* h = c->hist + (size_t)tid * 256;
+    memset(h, 0, 256 * sizeof(uint32_t));
+    const uint32_t *t = c->t[c->src], *d = c->d[c->src];
+    for (uint32_t k = b; k < e; ++k) ++h[mt_digit(t[k], d[k], c->shift)];
+}
+
+static void mt_scatter(mt_ctx* c, uint32_t tid) {                 /* hist now holds start offsets */
+    uint32_t b, e;
+    mt_chunk(c->e, c->threads, tid, &b, &e);
+    uint32_t* h = c->hist + (size_t)tid * 256;
+    const uint32_t s = c->src;
+    for (uint32_t k = b; k < e; ++k) {
+        const uint32_t pos = h[mt_digit(c->t[s][k], c->d[s][k], c->shift)]++;
+        c->t[s ^ 1][pos] = c->t[s][k];
+        c->d[s ^ 1][pos] = c->d[s][k];
+        c->i[s ^ 1][pos] = c->i[s][k];
+    }
+}
+
+static void mt_render(mt_ctx* c, uint32_t tid) {
+    (void)tid;
+    const uint32_t grid_h = gso_num_tiles_y(c->p->height, c->p->tile_size);
+    const uint32_t row_end = c->p->row_end < grid_h ? c->p->row_end : grid_h;
+    for (;;) {
+        pthread_mutex_lock(&c->lock);
+        const uint32_t row = c->next_row++;
+        pthread_mutex_unlock(&c->lock);
+        if (row >= row_end) break;
+        gso_params q = *c->p;
+        q.row_begin = row;
+        q.row_end = row + 1;
+        render_impl(&q, c->aos, c->color, c->cov, c->i[c->src], c->ranges, c->rgba, gso_exp);
+    }
+}
+
+uint32_t gso_frame_mt(const gso_params* p, const float* aos, uint32_t n, uint8_t* rgba_out,
+                      double* timings_ms, uint32_t threads) {
+    if (threads < 1) threads = 1;
+    if (threads > GSO_MAX_THREADS) threads = GSO_MAX_THREADS;
+    const uint32_t grid_w = gso_num_tiles_x(p->width, p->tile_size);
+    const uint32_t grid_h = gso_num_tiles_y(p->height, p->tile_size);
+    const uint32_t num_tiles = grid_w * grid_h;
+    mt_ctx c;
+    memset(&c, 0, sizeof c);
+    c.p = p; c.aos = aos; c.n = n; c.threads = threads; c.rgba = rgba_out;
+    c.cap = gso_capacity(n, num_tiles);
+    c.bits = gso_num_sort_bits(num_tiles);
+    c.color = (float*)calloc((size_t)n * 4 + 4, 4);
+    c.cov = (float*)calloc((size_t)n * 4 + 4, 4);
+    c.splats = (gso_splat*)calloc((size_t)n + 1, sizeof(gso_splat));
+    c.offsets = (uint64_t*)malloc(((size_t)n + 1) * sizeof(uint64_t));
+    for (int k = 0; k < 2; ++k) {
+        c.t[k] = (uint32_t*)malloc((size_t)c.cap * 4);
+        c.d[k] = (uint32_t*)malloc((size_t)c.cap * 4);
+        c.i[k] = (uint32_t*)malloc((size_t)c.cap * 4);
+    }
+    c.hist = (uint32_t*)malloc((size_t)threads * 256 * sizeof(uint32_t));
+    uint32_t* ranges = (uint32_t*)malloc((size_t)num_tiles * 8);
+    pthread_mutex_init(&c.lock, NULL);
+
+    double t0 = now_ms();
+    mt_run(&c, mt_project);
+    uint64_t counter = 0;
+    for (uint32_t g = 0; g < n; ++g) {                            /* the scan that replaces the atomic */
+        c.offsets[g] = counter;
+        if (c.splats[g].visible) {
+            uint32_t y0, y1;
+            splat_band(p, &c.splats[g], &y0, &y1);
+            counter += (uint64_t)(c.splats[g].max_x - c.splats[g].min_x) * (y1 - y0);
+        }
+    }
+    c.e = counter < c.cap ? (uint32_t)counter : c.cap;            /* IndirectSetup.comp:28 */
+    mt_run(&c, mt_emit);
+    double t1 = now_ms();
+    for (c.shift = 0; c.shift < c.bits; c.shift += 8) {           /* stable LSD, 8 bits per pass */
+        mt_run(&c, mt_hist);
+        uint32_t run = 0;
+        for (uint32_t dg = 0; dg < 256; ++dg)
+            for (uint32_t k = 0; k < threads; ++k) {
+                const uint32_t v = c.hist[(size_t)k * 256 + dg];
+                c.hist[(size_t)k * 256 + dg] = run;
+                run += v;
+            }
+        mt_run(&c, mt_scatter);
+        c.src ^= 1;
+    }
+    double t2 = now_ms();
+    gso_find_ranges(c.t[c.src], c.e, num_tiles, ranges, 0);
+    double t3 = now_ms();
+    c.ranges = ranges;
+    c.next_row = p->row_begin;
+    mt_run(&c, mt_render);
+    double t4 = now_ms();
+    if (timings_ms) {
+        timings_ms[0] = t1 - t0; timings_ms[1] = t2 - t1; timings_ms[2] = t3 - t2;
+        timings_ms[3] = t4 - t3; timings_ms[4] = t4 - t0;
+    }
+    const uint32_t e = c.e;
+    pthread_mutex_destroy(&c.lock);
+    free(c.color); free(c.cov); free(c.splats); free(c.offsets); free(c.hist); free(ranges);
+    for (int k = 0; k < 2; ++k) { free(c.t[k]); free(c.d[k]); free(c.i[k]); }
     return e;
 }
 

@@ -120,6 +120,13 @@ void gso_render_libm_exp(const gso_params* p, const float* aos, const float* col
 uint32_t gso_frame(const gso_params* p, const float* aos, uint32_t n, uint8_t* rgba_out,
                    double* timings_ms);
 
+/* The same frame on `threads` host threads (1..GSO_MAX_THREADS): splats split across threads for
+ * InitSortList (count, scan, emit in ascending splat index), a parallel stable LSD radix for the
+ * sort, tile rows for RenderGaussians.  Same image and same E as gso_frame(). */
+#define GSO_MAX_THREADS 256
+uint32_t gso_frame_mt(const gso_params* p, const float* aos, uint32_t n, uint8_t* rgba_out,
+                      double* timings_ms, uint32_t threads);
+
 /* Camera (Camera.cpp:7-48 over glm 0.9.9.8 lookAtRH / perspectiveRH_ZO). */
 void gso_camera_matrices(const float pos[3], float yaw, float pitch, float aspect,
                          float near_plane, float far_plane, float* view16, float* proj16);

@@ -182,6 +182,23 @@ def test_pinned_exp_image_within_one_step_of_libm(oracle_mod, small_cloud):
     assert (d > 0).mean() < 1e-3
 
 
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_threaded_frame_equals_single_thread_frame(oracle_mod, small_cloud, threads):
+    # the all-cores CPU baseline is the same restatement split across threads: same E, same image,
+    # also for a tile-row band and for an overflowing list
+    p, r = _pipeline(oracle_mod, small_cloud, 320, 180)
+    img, e, _ = oracle_mod.frame(p, small_cloud)
+    img_mt, e_mt, t = oracle_mod.frame_mt(p, small_cloud, threads)
+    assert e_mt == e == r["e"]
+    assert np.array_equal(img_mt, img) and np.array_equal(img, r["image"])
+    assert t[4] > 0
+    view, proj, pos = default_camera(oracle_mod, 320, 180)
+    band = oracle_mod.make_params(320, 180, view, proj, pos, row_begin=3, row_end=7)
+    a, ea, _ = oracle_mod.frame(band, small_cloud)
+    b, eb, _ = oracle_mod.frame_mt(band, small_cloud, threads)
+    assert ea == eb and np.array_equal(a, b)
+
+
 def test_empty_view_is_black(oracle_mod, small_cloud):
     # camera looking away from the cloud: everything near-culled, E = 0
     p, r = _pipeline(oracle_mod, small_cloud, 320, 180, yaw=np.pi)

@@ -22,3 +22,10 @@ print("visited      mean %.0f max %.0f  total/E %.3f" % (vis.mean(), vis.max(), 
 print("need exp     mean %.0f max %.0f  total/visited %.3f" % (need.mean(), need.max(), need.sum() / max(vis.sum(), 1)))
 print("ticks (100MHz?) mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (ticks.mean(), *np.percentile(ticks, [50, 90, 99]), ticks.max()))
 print("ticks per visited splat: %.1f" % (ticks.sum() / vis.sum()))
+# imbalance model: every tile's wave is resident at once when T <= 8192 (8 waves x 1024 SIMDs); the kernel
+# ends with its slowest wave.  Compare the slowest wave with the mean and with the mean load of a SIMD.
+order = np.argsort(-ticks)
+print("slowest 10 tiles: ticks", ticks[order[:10]].astype(int), "len", ln[order[:10]].astype(int), "visited", vis[order[:10]].astype(int), "need", need[order[:10]].astype(int))
+print("sum ticks / 1024 SIMDs = %.0f; max tile / that = %.2f" % (ticks.sum() / 1024, ticks.max() / (ticks.sum() / 1024)))
+hist, edges = np.histogram(ticks, bins=12)
+print("tick histogram:", list(zip(edges[:-1].astype(int), hist)))
