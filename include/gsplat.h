@@ -134,6 +134,12 @@ int gs_convert_ply(const char* path, void* aos336_out, uint32_t max_records, uin
  * happly.h:1089-1094). */
 const char* gs_ply_last_error(void);
 
+/* Frame output sink: where the reference's frame goes to the swapchain image
+ * (RenderGaussians.comp:150 imageStore, presented by Renderer.cpp:341-397) a windowless host writes the
+ * RGBA8 frame of gs_render to disk.  Format by extension: ".ppm" (binary P6, alpha dropped) or ".png"
+ * (8-bit RGBA).  GS_ERR_IO when the file cannot be written, GS_ERR_INVALID for another extension. */
+int gs_write_image(const char* path, const uint8_t* rgba, uint32_t width, uint32_t height);
+
 /* Swapchain extent -> tile grid, list capacity and pass count (Renderer.cpp:696-701, 725-755;
  * RadixSort::initForScene, RadixSort.cpp:144-205).  Must follow gs_upload_gaussians. */
 int gs_set_resolution(gs_ctx* ctx, uint32_t width, uint32_t height);

@@ -181,3 +181,48 @@ def test_scene_presets_follow_reference():
     assert r.getNumTiles() == 120 * 68 and r.getCeilPowTwo(5_834_784 + 1024 * 8160) == 2**24
     rs_bits = gs.RadixSort.getMinNumBits(8160 - 1)
     assert ((32 + rs_bits + 3) // 4) * 4 == 48
+
+
+def _decode_png(data: bytes):
+    import struct
+    import zlib
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(data):
+        ln, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + ln]
+        crc, = struct.unpack(">I", data[pos + 8 + ln:pos + 12 + ln])
+        assert zlib.crc32(typ + body) == crc
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + ln
+    w, h, depth, colour, comp, filt, inter = ihdr
+    assert (depth, colour, comp, filt, inter) == (8, 6, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, w * 4 + 1)
+    assert np.all(raw[:, 0] == 0)
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+@pytest.mark.parametrize("shape", [(3, 5), (180, 320), (300, 333)])
+def test_frame_sinks_round_trip(tmp_path, shape):
+    # gs_write_image: PNG decodes (zlib + CRCs checked) to the same RGBA frame, PPM carries the RGB
+    import vk3dgaussiansplatting_amd as gs
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=shape + (4,), dtype=np.uint8)
+    png, ppm = str(tmp_path / "f.png"), str(tmp_path / "f.PPM")
+    gs.saveImage(png, img)
+    gs.saveImage(ppm, img)
+    assert np.array_equal(_decode_png(open(png, "rb").read()), img)
+    data = open(ppm, "rb").read()
+    head = b"P6\n%d %d\n255\n" % (shape[1], shape[0])
+    assert data.startswith(head)
+    assert np.array_equal(np.frombuffer(data[len(head):], dtype=np.uint8).reshape(shape + (3,)), img[..., :3])
+    ref = str(tmp_path / "ref.ppm")
+    gs.savePpm(ref, img)
+    assert open(ref, "rb").read() == data
+    with pytest.raises(gs.GsplatError):
+        gs.saveImage(str(tmp_path / "f.bmp"), img)
+    with pytest.raises(gs.GsplatError):
+        gs.saveImage(str(tmp_path / "no_such_dir" / "f.png"), img)

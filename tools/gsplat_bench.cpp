@@ -4,7 +4,7 @@
 // Renderer.cpp:477-510 does, and print them.
 //
 //   gsplat_bench <scene.ply | --synthetic N> [--scene garden|train|bicycle|origin] [--res WxH]
-//                [--warmup F] [--frames F] [--fast] [--ppm out.ppm]
+//                [--warmup F] [--frames F] [--fast] [--out frame.png|frame.ppm]
 #include "../include/gsplat.h"
 
 #include <cmath>
@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
         else if (a == "--res" && i + 1 < argc) sscanf(argv[++i], "%ux%u", &w, &h);
         else if (a == "--warmup" && i + 1 < argc) warmup = (uint32_t)atol(argv[++i]);
         else if (a == "--frames" && i + 1 < argc) frames = (uint32_t)atol(argv[++i]);
-        else if (a == "--ppm" && i + 1 < argc) ppm = argv[++i];
+        else if ((a == "--out" || a == "--ppm") && i + 1 < argc) ppm = argv[++i];
         else if (a == "--fast") fast = true;
         else ply = a;
     }
@@ -95,11 +95,8 @@ int main(int argc, char** argv) {
     if (!ppm.empty()) {
         std::vector<uint8_t> img((size_t)w * h * 4);
         gs_debug_read(ctx, GS_BUF_IMAGE, img.data(), img.size());
-        if (FILE* fp = fopen(ppm.c_str(), "wb")) {
-            fprintf(fp, "P6\n%u %u\n255\n", w, h);
-            for (size_t p = 0; p < (size_t)w * h; ++p) fwrite(&img[p * 4], 1, 3, fp);
-            fclose(fp);
-        }
+        if (gs_write_image(ppm.c_str(), img.data(), w, h) != GS_OK)    // .ppm or .png by extension
+            fprintf(stderr, "cannot write %s\n", ppm.c_str());
     }
     gs_destroy(ctx);
     return 0;

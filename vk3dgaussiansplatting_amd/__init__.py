@@ -12,6 +12,6 @@ from ._lib import (GS_OK, GS_WARN_OVERFLOW, GS_RENDER_EXACT, GS_RENDER_FAST, GS_
                    BUF_COUNT, BUF_UNSORTED_TILE, BUF_UNSORTED_DEPTH, BUF_UNSORTED_ID, BUF_IMAGE)
 from .renderer import (Camera, GpuSort, GsplatError, PlyScene, RadixSort, Renderer, ResourceManager,
                        Scene, SimpleTestGaussiansScene, SphericalHarmonicsMode, TestSortScene,
-                       makeGaussian, savePpm)
+                       makeGaussian, saveImage, savePpm)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

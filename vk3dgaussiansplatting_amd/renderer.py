@@ -239,6 +239,16 @@ def savePpm(path: str, rgba: np.ndarray):
         f.write(img.tobytes())
 
 
+def saveImage(path: str, rgba: np.ndarray):
+    """The library's own sink (gs_write_image): .ppm or .png by extension; raises GsplatError on failure."""
+    img = np.ascontiguousarray(rgba, dtype=np.uint8)
+    if img.ndim != 3 or img.shape[2] != 4:
+        raise ValueError("saveImage wants an [H, W, 4] uint8 frame")
+    rc = _lib.lib().gs_write_image(os.fsencode(path), _p(img), img.shape[1], img.shape[0])
+    if rc != 0:
+        raise GsplatError(rc, f"gs_write_image({path!r}) failed")
+
+
 class _Context:
     """Owns one gs_ctx."""
 
