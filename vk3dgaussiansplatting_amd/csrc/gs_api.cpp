@@ -39,6 +39,9 @@ struct gs_ctx {
     uint32_t width = 0, height = 0, grid_w = 0, grid_h = 0;
     uint32_t row_begin = 0, row_end = 0;
     uint32_t capacity = 0, num_sort_bits = 0;
+    // what the sort of the current tile-row band runs over: tile ids relative to the band's first tile, so
+    // ceil((32 + bits(T_band - 1)) / 4) passes (the reference's formula, RadixSort.cpp:203-204, for the band's T)
+    uint32_t band_sort_bits = 0, band_tile_bias = 0;
     SortBuffers sort{};
     uint32_t* ranges = nullptr;
     uint8_t* framebuffer = nullptr;
@@ -162,9 +165,9 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[2], st));
     // gpuSort->computeSort (RadixSort.cpp:207-653)
     const bool bucket = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET;
-    c->sorted_index = launch_radix_sort(c->sort, c->capacity, c->num_sort_bits, st,
+    c->sorted_index = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st,
                                         c->cfg.record_timings >= 2 ? c->scatter_ev : nullptr,
-                                        bucket ? 32u : 0u);
+                                        bucket ? 32u : 0u, c->band_tile_bias);
     if (int r = check_launch(c, "RadixSort")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[3], st));
     // computeRanges (Subrenderer.cpp:172-216)
@@ -213,7 +216,7 @@ int finish_frame(gs_ctx* c) {
     }
     if (c->cfg.record_timings >= 2) {
         const uint32_t first_bit = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET ? 32u : 0u;
-        const uint32_t passes = (c->num_sort_bits - first_bit) / kRadixBits;
+        const uint32_t passes = (c->band_sort_bits - first_bit) / kRadixBits;
         float sum = 0.0f;
         for (uint32_t k = 0; k < passes; ++k) {
             float ms = 0.0f;
@@ -402,6 +405,7 @@ int gs_set_resolution(gs_ctx* c, uint32_t width, uint32_t height) {
     c->row_begin = 0; c->row_end = gh;
     c->capacity = ceil_pow2((uint32_t)want);
     c->num_sort_bits = num_sort_bits_for(gw * gh);
+    c->band_sort_bits = c->num_sort_bits; c->band_tile_bias = 0;
     int rc = alloc_sort(c, c->sort, c->capacity);
     if (rc != GS_OK) { free_resolution(c); return rc; }
     HIP_TRY(c, hipMalloc((void**)&c->ranges, (size_t)gw * gh * 2 * sizeof(uint32_t)));
@@ -417,6 +421,9 @@ int gs_set_tile_rows(gs_ctx* c, uint32_t row_begin, uint32_t row_end) {
     if (row_begin > row_end || row_end > c->grid_h)
         return fail(c, GS_ERR_INVALID, "gs_set_tile_rows: need row_begin <= row_end <= tiles_y");
     c->row_begin = row_begin; c->row_end = row_end;
+    const uint32_t band_tiles = (row_end - row_begin) * c->grid_w;
+    c->band_sort_bits = num_sort_bits_for(band_tiles ? band_tiles : 1u);
+    c->band_tile_bias = row_begin * c->grid_w;
     return GS_OK;
 }
 

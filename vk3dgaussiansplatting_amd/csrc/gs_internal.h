@@ -111,9 +111,11 @@ void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffer
                  hipStream_t stream);
 // Sorts buffers [0] -> result index returned (0 or 1) after num_sort_bits/4 passes.
 // scatter_events: optional 2*passes events recorded right before / after every Scatter launch.
-// Passes run over key bits [first_bit, num_sort_bits).
+// Passes run over key bits [first_bit, num_sort_bits) of (tile - tile_bias) << 32 | depth: a context that
+// owns a tile-row band sorts on tile ids relative to its first tile (same order, fewer significant bits).
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
-                      hipStream_t stream, hipEvent_t* scatter_events = nullptr, uint32_t first_bit = 0);
+                      hipStream_t stream, hipEvent_t* scatter_events = nullptr, uint32_t first_bit = 0,
+                      uint32_t tile_bias = 0);
 // GS_SORT_TILE_BUCKET: per-tile depth sort of tiles [tile0, tile0 + num_tiles) (gs_tilesort.hip)
 int init_tile_sort();
 void launch_tile_sort(const uint32_t* ranges, uint32_t tile0, uint32_t num_tiles, uint32_t* lo, uint32_t* id,

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
                                                            const SceneBuffers scene,
                                                            const SplatScratch sc) {
     __shared__ uint32_t s_wave_sum[kProjThreads / 64];
+    __shared__ uint32_t s_wave_emits[kProjThreads / 64];
     // The 48-byte raster records of the workgroup's 256 splats are staged here and written out as one
     // contiguous 12 KB block of full cache lines: per-lane 16-byte stores at a 48-byte stride reached HBM
     // as 32-byte partial writes (WRITE_SIZE 355 MB per frame against 219 MB of payload, config C).
@@ -273,7 +274,15 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
     s_raster[threadIdx.x * 3 + 2] = rec2;
     // per-workgroup total -> block_sums (input of the scan that replaces the atomic counter)
     const uint32_t wsum = wave_sum_to_lane63(count);
-    if (lane_id() == 63) s_wave_sum[wave_id()] = wsum;
+    if (lane_id() == 63) {
+        s_wave_sum[wave_id()] = wsum;
+        // A context that owns a tile-row band (multi-GPU) never reads the records of splats that emit nothing
+        // into the band -- RenderGaussians reaches records only through the sorted list -- so a wave whose 64
+        // splats all emit nothing skips its 3 KB of the block (most waves of a narrow band; the arrays are in
+        // Morton order).  With the full grid every record is written as the reference does (N6).
+        const bool band = fp.row_begin != 0u || fp.row_end != fp.grid_h;
+        s_wave_emits[wave_id()] = (!band || wsum != 0u) ? 1u : 0u;
+    }
     __syncthreads();
     {
         const uint32_t first = blockIdx.x * kProjThreads;
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const uint32_t i = q * kProjThreads + threadIdx.x;
-            if (i < valid * 3u) out[i] = s_raster[i];
+            if (i < valid * 3u && s_wave_emits[i / 192u]) out[i] = s_raster[i];
         }
     }
     if (threadIdx.x == 0) {

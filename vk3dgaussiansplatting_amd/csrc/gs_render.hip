@@ -19,6 +19,7 @@
 // emit for the same source); <= 1 step per 8-bit channel against the oracle.
 #include "gs_device_utils.h"
 #include "gs_internal.h"
+#include <cstdlib>
 
 namespace gs {
 
@@ -116,6 +117,65 @@ __device__ __forceinline__ Fetched fetch_splat(const SplatRaster* __restrict__ r
     return f;
 }
 
+// RenderGaussians.comp:86-108, the per-splat setup one lane does while a batch is staged: screen position,
+// inverse 2x2 covariance, colour, plus two things the shader does not have -- the exponent below which
+// alpha < 1/255 is certain, and an exact rejection of splats that cannot touch the pixel rectangle
+// [tile_x0, tile_x0 + 15] x [tile_y0, tile_y0 + rows_m1].  Returns false when the splat can be dropped.
+__device__ __forceinline__ bool stage_splat(const Fetched& nxt, float tile_x0, float tile_y0, float rows_m1,
+                                            float4& r0, float4& r1, float4& r2) {
+    bool keep = false;
+    if (nxt.valid) {
+        const float sx = nxt.a.x, sy = nxt.a.y;
+        const float cx = nxt.a.z, cy = nxt.a.w, cz = nxt.b.x;
+        float alpha0 = nxt.c.x;
+        const float det = cx * cz - cy * cy;                       // :96
+        float ix = 0.0f, iy = 0.0f, iz = 0.0f;
+        if (det != 0.0f) {
+            const float det_inv = 1.0f / det;                      // :99
+            ix = cz * det_inv;                                     // :100
+            iy = -cy * det_inv;
+            iz = cx * det_inv;
+        } else {
+            alpha0 = 0.0f;                                         // :104
+        }
+        // Skip threshold: alpha = a*exp(f) < 1/255 (the `continue` of :127) is certain once
+        // f < ln(1/(255 a)) - margin; the margin (0.01) dwarfs the errors of the fast log and of
+        // the pinned exp (<= 2e-6 relative), so the test below never changes a result.  a <= 0 or
+        // NaN gives +inf / NaN, i.e. "always skip" / "never skip", both exact.
+        const float fthr = __logf(1.0f / (255.0f * alpha0)) - 0.01f;
+        r0 = make_float4(sx, sy, ix, iy);
+        r1 = make_float4(iz, nxt.b.y, nxt.b.z, nxt.b.w);
+        r2 = make_float4(alpha0, fthr, 0.f, 0.f);
+        // Whole-rectangle rejection (the reference assigns tiles by a 3-sigma bounding box, so many list
+        // entries touch no pixel of the tile).  With u = sx - px, v = py - sy the shader's exponent is
+        // f = -q/2, q(u,v) = ix u^2 + 2 iy u v + iz v^2 (positive definite for a valid covariance).
+        // Over the pixel rectangle q is minimal either at the centre (inside: keep) or on one
+        // of the four edges, where it is a 1-D parabola with a closed-form clamped minimiser.  If
+        // -q_min/2, widened by a generous bound on the fp32 error of the per-pixel f, is below the
+        // skip threshold, every pixel would `continue` (:127): dropping the splat is unobservable.
+        const float u0 = sx - (tile_x0 + 15.0f), u1 = sx - tile_x0;                 // u range (u0 <= u1)
+        const float v0 = tile_y0 - sy, v1 = tile_y0 + rows_m1 - sy;                 // v range
+        bool reject = false;
+        if (det > 0.0f && ix > 0.0f && iz > 0.0f && !(u0 <= 0.0f && u1 >= 0.0f && v0 <= 0.0f && v1 >= 0.0f)) {
+            auto edge_u = [&](float ue) {   // min over v in [v0,v1] of q(ue, v)
+                const float vs = fminf(fmaxf(-iy * ue / iz, v0), v1);
+                return ix * ue * ue + 2.0f * iy * ue * vs + iz * vs * vs;
+            };
+            auto edge_v = [&](float ve) {   // min over u in [u0,u1] of q(u, ve)
+                const float us = fminf(fmaxf(-iy * ve / ix, u0), u1);
+                return ix * us * us + 2.0f * iy * us * ve + iz * ve * ve;
+            };
+            const float qmin = fminf(fminf(edge_u(u0), edge_u(u1)), fminf(edge_v(v0), edge_v(v1)));
+            const float far_x = fmaxf(fabsf(u0), fabsf(u1)), far_y = fmaxf(fabsf(v0), fabsf(v1));
+            const float mag = fabsf(ix) * far_x * far_x + fabsf(iz) * far_y * far_y + 2.0f * fabsf(iy) * far_x * far_y;
+            const float tol = 0.01f + 8e-6f * mag;      // >> rounding of qmin here and of f in the pixel loop
+            reject = (-0.5f * qmin + tol < fthr);
+        }
+        keep = !reject;
+    }
+    return keep;
+}
+
 // STATS is a tuning-only instantiation (gs_debug_render_stats): per tile {list length, splats
 // visited, splats with any pixel needing exp, clock ticks}.  The product launches STATS = false.
 // PX = pixels per lane: 4 -> one wave per tile (16 rows x 4 lanes), 2 -> two waves per tile (each
@@ -164,57 +224,8 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
     Fetched nxt = fetch_splat(raster, sorted_id, start + lane, end);
     for (uint32_t i = start; i < end; i += 64) {                       // :81
         // :86-108 per-splat setup, one splat per lane
-        bool keep = false;
         float4 r0, r1, r2;
-        if (nxt.valid) {
-            const float sx = nxt.a.x, sy = nxt.a.y;
-            const float cx = nxt.a.z, cy = nxt.a.w, cz = nxt.b.x;
-            float alpha0 = nxt.c.x;
-            const float det = cx * cz - cy * cy;                       // :96
-            float ix = 0.0f, iy = 0.0f, iz = 0.0f;
-            if (det != 0.0f) {
-                const float det_inv = 1.0f / det;                      // :99
-                ix = cz * det_inv;                                     // :100
-                iy = -cy * det_inv;
-                iz = cx * det_inv;
-            } else {
-                alpha0 = 0.0f;                                         // :104
-            }
-            // Skip threshold: alpha = a*exp(f) < 1/255 (the `continue` of :127) is certain once
-            // f < ln(1/(255 a)) - margin; the margin (0.01) dwarfs the errors of the fast log and of
-            // the pinned exp (<= 2e-6 relative), so the test below never changes a result.  a <= 0 or
-            // NaN gives +inf / NaN, i.e. "always skip" / "never skip", both exact.
-            const float fthr = __logf(1.0f / (255.0f * alpha0)) - 0.01f;
-            r0 = make_float4(sx, sy, ix, iy);
-            r1 = make_float4(iz, nxt.b.y, nxt.b.z, nxt.b.w);
-            r2 = make_float4(alpha0, fthr, 0.f, 0.f);
-            // Whole-tile rejection (the reference assigns tiles by a 3-sigma bounding box, so many list
-            // entries touch no pixel of the tile).  With u = sx - px, v = py - sy the shader's exponent is
-            // f = -q/2, q(u,v) = ix u^2 + 2 iy u v + iz v^2 (positive definite for a valid covariance).
-            // Over the wave's pixel rectangle q is minimal either at the centre (inside: keep) or on one
-            // of the four edges, where it is a 1-D parabola with a closed-form clamped minimiser.  If
-            // -q_min/2, widened by a generous bound on the fp32 error of the per-pixel f, is below the
-            // skip threshold, every pixel would `continue` (:127): dropping the splat is unobservable.
-            const float u0 = sx - (tile_x0 + 15.0f), u1 = sx - tile_x0;                 // u range (u0 <= u1)
-            const float v0 = tile_y0 - sy, v1 = tile_y0 + (float)(ROWS - 1) - sy;       // v range
-            bool reject = false;
-            if (det > 0.0f && ix > 0.0f && iz > 0.0f && !(u0 <= 0.0f && u1 >= 0.0f && v0 <= 0.0f && v1 >= 0.0f)) {
-                auto edge_u = [&](float ue) {   // min over v in [v0,v1] of q(ue, v)
-                    const float vs = fminf(fmaxf(-iy * ue / iz, v0), v1);
-                    return ix * ue * ue + 2.0f * iy * ue * vs + iz * vs * vs;
-                };
-                auto edge_v = [&](float ve) {   // min over u in [u0,u1] of q(u, ve)
-                    const float us = fminf(fmaxf(-iy * ve / ix, u0), u1);
-                    return ix * us * us + 2.0f * iy * us * ve + iz * ve * ve;
-                };
-                const float qmin = fminf(fminf(edge_u(u0), edge_u(u1)), fminf(edge_v(v0), edge_v(v1)));
-                const float far_x = fmaxf(fabsf(u0), fabsf(u1)), far_y = fmaxf(fabsf(v0), fabsf(v1));
-                const float mag = fabsf(ix) * far_x * far_x + fabsf(iz) * far_y * far_y + 2.0f * fabsf(iy) * far_x * far_y;
-                const float tol = 0.01f + 8e-6f * mag;      // >> rounding of qmin here and of f in the pixel loop
-                reject = (-0.5f * qmin + tol < fthr);
-            }
-            keep = !reject;
-        }
+        const bool keep = stage_splat(nxt, tile_x0, tile_y0, (float)(ROWS - 1), r0, r1, r2);
         const uint64_t kmask = __ballot(keep);
         const uint32_t n = (uint32_t)__popcll(kmask);
         if (keep) {
@@ -364,6 +375,122 @@ finish:
     }
 }
 
+// One 256-thread workgroup per tile, one pixel per lane -- the reference's own shape (RenderGaussians.comp:
+// local_size 16x16, 256-splat shared batch) with the wave-level tricks of k_render kept: the four waves stage a
+// batch of 256 list entries together (each entry is fetched, set up and rectangle-tested ONCE per tile, then
+// compacted in list order across the waves), and each wave blends its own four pixel rows over the compacted
+// batch, skipping entries none of its pixels can see by wave vote.  A wave whose 64 pixels are all done stops
+// blending but keeps staging; the workgroup leaves the list when all four are done.  Against one wave per tile
+// with 4 px/lane the longest dependent chain of a tile is about a quarter as long, and 4T workgroups are handed
+// out dynamically instead of all T waves being resident from the start.
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
+                                                    const SplatRaster* __restrict__ raster,
+                                                    const uint32_t* __restrict__ sorted_id,
+                                                    const uint32_t* __restrict__ ranges,
+                                                    uint32_t* __restrict__ rgba) {
+    __shared__ float4 s_batch[256][3];
+    __shared__ uint32_t s_wcnt[4];
+    __shared__ uint32_t s_done;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t ty = fp.row_begin + blockIdx.x / fp.grid_w;
+    const uint32_t tx = blockIdx.x % fp.grid_w;
+    const uint32_t tile_index = ty * fp.grid_w + tx;                   // :74-76
+    const uint32_t start = ranges[tile_index * 2 + 0];                 // :77
+    const uint32_t end = ranges[tile_index * 2 + 1];
+    const uint32_t py = ty * kTile + (uint32_t)wave * 4u + (uint32_t)(lane >> 4);
+    const uint32_t px = tx * kTile + (uint32_t)(lane & 15);
+    const float fpx = (float)px, fpy = (float)py;                      // integer pixel coords (R1)
+    const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
+
+    float col0 = 0.0f, col1 = 0.0f, col2 = 0.0f, T = 1.0f;
+    bool done = !(px < fp.width && py < fp.height);                    // never stored (:147)
+    bool wave_done = __all(done);
+    if (tid == 0) s_done = 0u;
+    __syncthreads();
+    if (wave_done && lane == 0) atomicAdd(&s_done, 1u);
+
+    Fetched nxt = fetch_splat(raster, sorted_id, start + tid, end);
+    for (uint32_t i = start; i < end; i += 256) {                      // :81
+        float4 r0, r1, r2;
+        const bool keep = stage_splat(nxt, tile_x0, tile_y0, 15.0f, r0, r1, r2);
+        const uint64_t kmask = __ballot(keep);
+        if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(kmask);
+        __syncthreads();                                               // counts of this batch; s_done settled
+        if (s_done == 4u) break;                                       // every pixel of the tile is finished
+        uint32_t off = 0, n = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t c = s_wcnt[w];
+            off += w < wave ? c : 0u;
+            n += c;
+        }
+        if (keep) {
+            const uint32_t slot = off + mbcnt(kmask);                  // list order preserved across the waves
+            s_batch[slot][0] = r0;
+            s_batch[slot][1] = r1;
+            s_batch[slot][2] = r2;
+        }
+        __syncthreads();                                               // :109
+        nxt = fetch_splat(raster, sorted_id, i + 256 + tid, end);      // prefetch next batch
+
+        if (!wave_done) {
+            for (uint32_t j = 0; j < n; ++j) {                         // :112
+                const float4 g0 = s_batch[j][0];
+                const float4 g1 = s_batch[j][1];
+                const float2 g2 = *reinterpret_cast<const float2*>(&s_batch[j][2]);
+                const float ga = g2.x, fthr = g2.y;
+                float ey = g0.y - fpy;                                 // :119
+                ey = -ey;                                              // :120
+                const float ex = g0.x - fpx;
+                float f;
+                if constexpr (EXACT) {
+                    f = -0.5f * (g0.z * ex * ex + g1.x * ey * ey) - g0.w * ex * ey;   // :123
+                } else {
+                    const float q = __builtin_fmaf(g0.z * ex, ex, g1.x * ey * ey);
+                    f = __builtin_fmaf(-0.5f, q, -(g0.w * ey * ex));
+                }
+                const bool need = !done && !(f > 0.0f) && !(f < fthr);
+                if (!__any(need)) continue;                            // nobody in these rows can pass :127
+                float alpha;
+                if constexpr (EXACT) alpha = ga * exp_pinned(f);       // :124
+                else alpha = ga * __builtin_amdgcn_exp2f(f * 0x1.715476p+0f);
+                const bool act = need && !(alpha < 1.0f / 255.0f);     // :127
+                const float wgt = T * alpha;                           // :131
+                if constexpr (EXACT) {
+                    col0 = act ? col0 + wgt * g1.y : col0;
+                    col1 = act ? col1 + wgt * g1.z : col1;
+                    col2 = act ? col2 + wgt * g1.w : col2;
+                } else {
+                    const float w0 = act ? wgt : 0.0f;
+                    col0 = __builtin_fmaf(w0, g1.y, col0);
+                    col1 = __builtin_fmaf(w0, g1.z, col1);
+                    col2 = __builtin_fmaf(w0, g1.w, col2);
+                }
+                const float next_t = T * (1.0f - alpha);               // :133
+                const bool fin = act && next_t < 0.0001f;              // :136-140, colour already added
+                done = done || fin;
+                T = (act && !fin) ? next_t : T;                        // :142
+                if (__all(done)) {                                     // this wave's rows are finished
+                    wave_done = true;
+                    if (lane == 0) atomicAdd(&s_done, 1u);
+                    break;
+                }
+            }
+        }
+        __syncthreads();                                               // :84
+    }
+    // :147-151 clamp + RGBA8 UNORM store, A = 255
+    if (px < fp.width && py < fp.height) {
+        uint32_t v = 0xFF000000u;
+        v |= (uint32_t)(clampf(col0, 0.0f, 1.0f) * 255.0f + 0.5f);
+        v |= (uint32_t)(clampf(col1, 0.0f, 1.0f) * 255.0f + 0.5f) << 8;
+        v |= (uint32_t)(clampf(col2, 0.0f, 1.0f) * 255.0f + 0.5f) << 16;
+        rgba[(size_t)py * fp.width + px] = v;
+    }
+}
+
 // Pixels per lane.  0 = choose per launch: few tiles cannot fill 1024 SIMDs with one wave each, so below
 // 6000 tiles every tile gets four waves (1 px/lane); above, one wave with 4 px/lane does the least
 // per-splat work.  Measured (exact mode, 1 / 2 / 4 px per lane): 920 tiles 0.055 / 0.075 / 0.126 ms,
@@ -395,11 +522,17 @@ void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint3
     const uint32_t tiles = rows * fp.grid_w;
     if (tiles == 0) return;
     uint32_t* out = reinterpret_cast<uint32_t*>(rgba);
-    const int px = GS_RENDER_PX != 0 ? GS_RENDER_PX : (tiles < 6000u ? 1 : 4);
+    static const int px_env = getenv("GS_RENDER_PX") ? atoi(getenv("GS_RENDER_PX")) : 0;   // tuning only
+    const int px = px_env ? px_env : GS_RENDER_PX != 0 ? GS_RENDER_PX : (tiles < 6000u ? 1 : 4);
 #define GS_LAUNCH_RENDER(EXACT, PX)                                                                   \
     hipLaunchKernelGGL((k_render<EXACT, PX, false>), dim3(tiles * (4 / PX)), dim3(64), 0, stream, fp, \
                        raster, sorted_id, ranges, out, (uint4*)nullptr)
-    if (render_mode == 0u) {
+    if (px == 16) {   // workgroup-per-tile kernel
+        if (render_mode == 0u)
+            hipLaunchKernelGGL((k_render_wg<true>), dim3(tiles), dim3(256), 0, stream, fp, raster, sorted_id, ranges, out);
+        else
+            hipLaunchKernelGGL((k_render_wg<false>), dim3(tiles), dim3(256), 0, stream, fp, raster, sorted_id, ranges, out);
+    } else if (render_mode == 0u) {
         if (px == 1) GS_LAUNCH_RENDER(true, 1);
         else if (px == 2) GS_LAUNCH_RENDER(true, 2);
         else GS_LAUNCH_RENDER(true, 4);

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
                                                          const uint32_t* __restrict__ word,
                                                          uint32_t* __restrict__ table,
                                                          uint32_t* __restrict__ seg_sum,
-                                                         uint32_t sh) {
+                                                         uint32_t sh, uint32_t bias) {
     __shared__ uint32_t s_pack[2][kSortWaves][8];   // per-wave packed totals (two 16-bit counters per word)
     const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
             const uint32_t k[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t d = digit_of(k[q], sh);
+                const uint32_t d = digit_of(k[q] - bias, sh);
                 const bool ok = full || tile_base + (uint32_t)(r * kSortThreads + tid) * 4u + q < e;
                 const uint64_t inc = ok ? 1ull << ((d & 7u) * 8u) : 0ull;
                 c0 += (d & 8u) ? 0ull : inc;
@@ -204,7 +204,8 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
     const SortParams* __restrict__ params, const uint32_t* __restrict__ in_lo,
     const uint32_t* __restrict__ in_hi, const uint32_t* __restrict__ in_id,
     uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_hi, uint32_t* __restrict__ out_id,
-    const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base, uint32_t shift) {
+    const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base, uint32_t shift,
+    uint32_t hi_bias) {
     __shared__ uint32_t s_lo[kSortTile];
     __shared__ uint32_t s_hi[kSortTile];
     __shared__ uint32_t s_id[kSortTile];
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
         for (int r = 0; r < kSortKeysPerThread; ++r) {
             const uint32_t idx = base + r * 64;
             const bool ok = idx < e;
-            const uint32_t dg = digit_of(use_hi ? k.hi[r] : k.lo[r], sh);
+            const uint32_t dg = digit_of(use_hi ? k.hi[r] - hi_bias : k.lo[r], sh);
             uint64_t mask = __ballot(ok);
 #pragma unroll
             for (int b = 0; b < kRadixBits; ++b) {
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
         for (int r = 0; r < kSortKeysPerThread; ++r) {
             const uint32_t idx = base + r * 64;
             if (idx < e) {
-                const uint32_t dg = digit_of(use_hi ? k.hi[r] : k.lo[r], sh);
+                const uint32_t dg = digit_of(use_hi ? k.hi[r] - hi_bias : k.lo[r], sh);
 #if GS_SCATTER_ABLATE & 4
                 const uint32_t p = rank[r];
 #else
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
             const uint32_t p = (uint32_t)r * kSortThreads + tid;
             if (p < valid) {
                 const uint32_t l = s_lo[p], h = s_hi[p];
-                const uint32_t d = digit_of(use_hi ? h : l, sh);
+                const uint32_t d = digit_of(use_hi ? h - hi_bias : l, sh);
 #if GS_SCATTER_ABLATE & 8
                 const uint32_t o = tile_base + p + 13u + (d & 0u) < e ? tile_base + p + 13u : p;   // contiguous but misaligned
 #elif GS_SCATTER_ABLATE & 5
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
 }
 
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
-                      hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit) {
+                      hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit, uint32_t tile_bias) {
     const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
     const uint32_t sgrid = max_groups < (uint32_t)GS_SCATTER_GRID ? max_groups : (uint32_t)GS_SCATTER_GRID;
     int src = 0;
@@ -364,12 +365,12 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
         const int dst = src ^ 1;
         const uint32_t* word = shift >= 32u ? sb.hi[src] : sb.lo[src];
         hipLaunchKernelGGL(k_count<0>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
-                           word, sb.table, sb.seg_sum, shift & 31u);
+                           word, sb.table, sb.seg_sum, shift & 31u, shift >= 32u ? tile_bias : 0u);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, sb.seg_sum);
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass], stream);
         hipLaunchKernelGGL(k_scatter, dim3(sgrid), dim3(kSortThreads), 0, stream, sb.params,
                            sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],
-                           sb.table, sb.seg_sum, shift);
+                           sb.table, sb.seg_sum, shift, tile_bias);
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass + 1], stream);
         src = dst;                                                            // RadixSort.cpp:638-641
     }
@@ -417,9 +418,9 @@ __global__ void k_check_sorted(const uint32_t* lo, const uint32_t* hi, uint32_t 
 void launch_count_ablate(int ablate, const SortBuffers& sb, uint32_t capacity, uint32_t grid, hipStream_t stream) {
     (void)capacity; (void)grid;
     switch (ablate) {
-        case 0: hipLaunchKernelGGL(k_count<0>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u); break;
-        case 3: hipLaunchKernelGGL(k_count<2>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u); break;
-        default: hipLaunchKernelGGL(k_count<6>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u); break;
+        case 0: hipLaunchKernelGGL(k_count<0>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u, 0u); break;
+        case 3: hipLaunchKernelGGL(k_count<2>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u, 0u); break;
+        default: hipLaunchKernelGGL(k_count<6>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u, 0u); break;
     }
 }
 
