@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
     ap.add_argument("--sort", default="radix4", choices=["radix4", "bucket"],
                     help="radix4 = the contractual nine-stage sort (default); bucket = GS_SORT_TILE_BUCKET")
+    ap.add_argument("--render-kernel", default="auto", choices=["auto", "1", "2", "4", "16"],
+                    help="gs_config.render_kernel: auto, 1/2/4 = px per lane with independent waves, 16 = workgroup per tile")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra pass with the other sort back-end")
     ap.add_argument("--rehearse", action="store_true",
@@ -131,7 +133,8 @@ def main():
 
     def make(record, sort=None):
         r = gs.Renderer(w, h, device=local_rank, render_mode=mode, record_timings=record, warmup_frames=0,
-                        sort_algorithm=sort_ids[sort or args.sort])
+                        sort_algorithm=sort_ids[sort or args.sort],
+                        render_kernel=0 if args.render_kernel == "auto" else int(args.render_kernel))
         r.init(rm)
         r.initForScene(scene)
         return r
@@ -294,6 +297,7 @@ def main():
                              "E": "stress: 50,000,000 synthetic gaussians @ 1920x1080"}[args.config],
                 "num_gaussians": n, "width": w, "height": h, "sort_elements": e_total,
                 "capacity": int(info.capacity), "radix_passes": passes, "render_mode": args.mode,
+                "render_kernel": args.render_kernel,
                 "sort_algorithm": args.sort,
                 "parallelism": f"tile-row shard x{world}" if world > 1 else "single GPU",
                 "baseline_note": "vs_baseline = Msplats/s over the reference README's RTX 3080 Ti figure for the "

@@ -57,6 +57,13 @@ typedef struct gs_ctx gs_ctx;
 
 /* Replaces the compile-time constants of Renderer.h:145-147, RadixSort.h:36-39,
  * Camera.cpp:4-5 and Resources/Shaders/Common/Common.glsl:2-15. */
+/* RenderGaussians launch shapes (all bit-identical in GS_RENDER_EXACT).  AUTO picks by tile count. */
+#define GS_RENDER_KERNEL_AUTO 0u
+#define GS_RENDER_KERNEL_WAVE_1PX 1u   /* four independent waves per tile, 1 pixel per lane */
+#define GS_RENDER_KERNEL_WAVE_2PX 2u   /* two independent waves per tile, 2 pixels per lane */
+#define GS_RENDER_KERNEL_WAVE_4PX 4u   /* one wave per tile, 4 pixels per lane */
+#define GS_RENDER_KERNEL_WORKGROUP 16u /* one 256-thread workgroup per tile sharing the staged batch (the reference's shape) */
+
 typedef struct gs_config {
     int32_t device_ordinal;   /* HIP device index */
     uint32_t tile_size;       /* 16; only 16 is supported (TILE_SIZE) */
@@ -69,6 +76,7 @@ typedef struct gs_config {
     uint32_t render_mode;     /* GS_RENDER_* */
     uint32_t record_timings;  /* 1 = hipEvents at the reference's 7 timestamp points (RECORD_GPU_TIMES, Renderer.h:35);
                                  2 = additionally one event pair around every Scatter launch (roofline measurement) */
+    uint32_t render_kernel;   /* GS_RENDER_KERNEL_*: how a tile maps to waves in RenderGaussians; same pixels either way */
 } gs_config;
 
 /* The five buckets of Renderer.cpp:471-475 (ms) + the sort element count ("Elements To Sort"

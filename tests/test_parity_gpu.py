@@ -29,8 +29,8 @@ def make_scene(aos, w, h, pos=(0.0, 0.0, 0.0), yaw=0.0, pitch=0.0, sh_mode=0):
     return sc
 
 
-def make_renderer(sc, w, h, mode=gs.GS_RENDER_EXACT, sort=gs.GS_SORT_RADIX4):
-    r = gs.Renderer(w, h, render_mode=mode, warmup_frames=0, sort_algorithm=sort)
+def make_renderer(sc, w, h, mode=gs.GS_RENDER_EXACT, sort=gs.GS_SORT_RADIX4, kernel=gs.GS_RENDER_KERNEL_AUTO):
+    r = gs.Renderer(w, h, render_mode=mode, warmup_frames=0, sort_algorithm=sort, render_kernel=kernel)
     r.init(sc.getResourceManager())
     r.initForScene(sc)
     return r
@@ -603,3 +603,35 @@ def test_sort_stress_sortedness(n):
     assert ok and ms > 0
     print(f"n={n}: {ms:.3f} ms per sort, {n / ms / 1e3:.0f} M elements/s")
     rs.cleanup()
+
+
+@pytest.mark.parametrize("kernel", [gs.GS_RENDER_KERNEL_WAVE_1PX, gs.GS_RENDER_KERNEL_WAVE_2PX,
+                                    gs.GS_RENDER_KERNEL_WAVE_4PX, gs.GS_RENDER_KERNEL_WORKGROUP])
+def test_every_render_launch_shape_is_bit_exact(oracle_mod, kernel):
+    """gs_config.render_kernel only changes how a tile maps to waves: same pixels as the oracle for the full
+    frame (ragged right/bottom tiles), for a tile-row band, with sh modes, and FAST stays within one step."""
+    w, h = 333, 190                                            # 21 x 12 tiles, partial last column and row
+    aos = synth.generate(6000, w, h, -3.0, seed=23)
+    sc = make_scene(aos, w, h)
+    r = make_renderer(sc, w, h, kernel=kernel)
+    img = r.draw(sc)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    assert ref["e"] > 10000
+    assert_frame_equals_oracle(r, img, ref)
+    r.setTileRows(3, 8)
+    band_img = r.draw(sc)
+    _, band = oracle_run(oracle_mod, sc, w, h, row_begin=3, row_end=8)
+    assert np.array_equal(band_img[48:128], band["image"][48:128])
+    r.cleanup()
+    # a dense cloud so that tiles saturate (early-outs of single waves and of whole workgroups)
+    dense = synth.generate(20000, 160, 96, -1.6, seed=29)
+    sc2 = make_scene(dense, 160, 96)
+    r2 = make_renderer(sc2, 160, 96, kernel=kernel)
+    img2 = r2.draw(sc2)
+    _, ref2 = oracle_run(oracle_mod, sc2, 160, 96)
+    assert np.array_equal(img2, ref2["image"])
+    r2.cleanup()
+    rf = make_renderer(sc, w, h, mode=gs.GS_RENDER_FAST, kernel=kernel)
+    fast = rf.draw(sc)
+    assert np.abs(fast.astype(np.int16) - ref["image"].astype(np.int16)).max() <= 1
+    rf.cleanup()

@@ -6,6 +6,7 @@ import numpy as np
 import vk3dgaussiansplatting_amd as gs
 from vk3dgaussiansplatting_amd import synth, dist
 name = sys.argv[1] if len(sys.argv) > 1 else "C"
+kernel = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # gs_config.render_kernel
 aos, cfg = synth.generate_config(name)
 w, h = cfg["width"], cfg["height"]
 rm = gs.ResourceManager(); rm.setGaussians(aos)
@@ -17,7 +18,7 @@ for R in (1, 2, 4, 8):
         if R == 1 and label == "first": continue
         b, e = bands[k]
         for rec in (0, 2):
-            r = gs.Renderer(w, h, record_timings=rec, warmup_frames=0); r.init(rm); r.initForScene(sc)
+            r = gs.Renderer(w, h, record_timings=rec, warmup_frames=0, render_kernel=kernel); r.init(rm); r.initForScene(sc)
             r.setTileRows(b, e)
             for _ in range(20): r.drawDevice(sc, None, sync=False)
             r.synchronize()

@@ -24,6 +24,8 @@ GS_ERR_NO_DEVICE = -6
 
 GS_RENDER_EXACT = 0
 GS_RENDER_FAST = 1
+GS_RENDER_KERNEL_AUTO, GS_RENDER_KERNEL_WAVE_1PX, GS_RENDER_KERNEL_WAVE_2PX = 0, 1, 2
+GS_RENDER_KERNEL_WAVE_4PX, GS_RENDER_KERNEL_WORKGROUP = 4, 16
 GS_SORT_RADIX4 = 0
 GS_SORT_TILE_BUCKET = 1
 
@@ -45,6 +47,7 @@ class GsConfig(C.Structure):
         ("sort_algorithm", C.c_uint32),
         ("render_mode", C.c_uint32),
         ("record_timings", C.c_uint32),
+        ("render_kernel", C.c_uint32),
     ]
 
 

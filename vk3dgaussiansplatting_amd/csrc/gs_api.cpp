@@ -186,7 +186,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[4], st));
     // computeRenderGaussians (Subrenderer.cpp:218-346)
     launch_render(fp, c->scratch.raster, c->sort.id[c->sorted_index], c->ranges,
-                  out_dev ? out_dev : c->framebuffer, c->cfg.render_mode, st);
+                  out_dev ? out_dev : c->framebuffer, c->cfg.render_mode, c->cfg.render_kernel, st);
     if (int r = check_launch(c, "RenderGaussians")) return r;
     if (tm) { HIP_TRY(c, hipEventRecord(c->ev[5], st)); HIP_TRY(c, hipEventRecord(c->ev[6], st)); }
     c->have_frame = true;
@@ -250,6 +250,7 @@ void gs_default_config(gs_config* cfg) {
     cfg->sort_algorithm = GS_SORT_RADIX4;
     cfg->render_mode = GS_RENDER_EXACT;
     cfg->record_timings = 1;
+    cfg->render_kernel = GS_RENDER_KERNEL_AUTO;
 }
 
 int gs_create(const gs_config* cfg_in, gs_ctx** out) {
@@ -260,6 +261,10 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
     if (cfg.tile_size != 16) return fail(nullptr, GS_ERR_INVALID, "gs_create: only tile_size 16 is supported");
     if (cfg.sort_algorithm > GS_SORT_TILE_BUCKET) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown sort_algorithm");
     if (cfg.render_mode > GS_RENDER_FAST) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown render_mode");
+    if (cfg.render_kernel != GS_RENDER_KERNEL_AUTO && cfg.render_kernel != GS_RENDER_KERNEL_WAVE_1PX &&
+        cfg.render_kernel != GS_RENDER_KERNEL_WAVE_2PX && cfg.render_kernel != GS_RENDER_KERNEL_WAVE_4PX &&
+        cfg.render_kernel != GS_RENDER_KERNEL_WORKGROUP)
+        return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown render_kernel");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)

@@ -124,7 +124,8 @@ void launch_tile_sort(const uint32_t* ranges, uint32_t tile0, uint32_t num_tiles
 void launch_find_ranges(const uint32_t* sorted_tile, const SortParams* params, uint32_t capacity,
                         uint32_t* ranges, hipStream_t stream);
 void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
-                   const uint32_t* ranges, uint8_t* rgba, uint32_t render_mode, hipStream_t stream);
+                   const uint32_t* ranges, uint8_t* rgba, uint32_t render_mode, uint32_t render_kernel,
+                   hipStream_t stream);
 void launch_aos_to_soa(const float* chunk, uint32_t first, uint32_t count, uint32_t n,
                        const SceneBuffers& s, hipStream_t stream);
 void launch_stream_probe(int kind, const void* src, void* dst, size_t bytes, uint32_t blocks, hipStream_t stream);

@@ -4,22 +4,20 @@
 //   capacity (the reference runs 2^24 threads in 16-wide groups over mostly 0xFFFFFFFF sentinels,
 //   Subrenderer.cpp:205-215); last end = E (differs from the reference only when the list
 //   overflowed, quirk Q1 in SURVEY.md).
-// k_render: RenderGaussians.comp:56-152.  One wave64 per 16x16 tile, four horizontally adjacent
-//   pixels per lane, so: no workgroup barriers (the wave is the workgroup), the staged splat is
-//   read from LDS once per four pixels, one 16-byte RGBA8 store per lane, and a wave vote gives the
-//   whole-tile early-out the reference lacks (its `done` only zeroes `limit`, :111).  The splat
-//   batch (64 per wave) is gathered through the sorted id list from the 48-byte SplatRaster
-//   records and prefetched one batch ahead of the blend loop; splats that provably touch no pixel
-//   of the tile are dropped while the batch is staged (conservative, unobservable).  Measured on
-//   MI355X: one wave per tile (4 px/lane) 0.41 ms, two waves (2 px/lane) 0.57 ms, four 0.54 ms --
-//   the kernel is bound by per-splat VALU work, not by the longest tile.
+// k_render / k_render_wg: RenderGaussians.comp:56-152 in two launch shapes (gs_config.render_kernel; table of
+//   measurements above launch_render).  k_render<PX>: independent wave64s, PX horizontally adjacent pixels per
+//   lane (PX = 4: one wave per 16x16 tile), no workgroup barriers, one 16-byte RGBA8 store per lane.
+//   k_render_wg: one 256-thread workgroup per tile, one pixel per lane (the shader's own shape), the four waves
+//   staging each 256-entry batch together.  Both gather the batch through the sorted id list from the 48-byte
+//   SplatRaster records, prefetch one batch ahead of the blend loop, drop while staging the splats that provably
+//   touch no pixel of the rectangle (conservative, unobservable), and use wave votes for the early-outs the
+//   reference lacks (its `done` only zeroes `limit`, :111).
 // GS_RENDER_EXACT evaluates every expression in the reference's order without contraction and with
 // the pinned exp of oracle/gs_oracle.h => pixels bit-identical to the CPU oracle.
 // GS_RENDER_FAST uses fused multiply-adds and the hardware exp2 (what a GLSL compiler is free to
 // emit for the same source); <= 1 step per 8-bit channel against the oracle.
 #include "gs_device_utils.h"
 #include "gs_internal.h"
-#include <cstdlib>
 
 namespace gs {
 
@@ -117,6 +115,31 @@ __device__ __forceinline__ Fetched fetch_splat(const SplatRaster* __restrict__ r
     return f;
 }
 
+// True when no pixel of the rectangle [x0, x0 + 15] x [y0, y0 + rows_m1] can reach the exponent fthr for the
+// conic (ix, iy, iz) centred at (sx, sy); the caller guarantees a positive determinant.  See stage_splat.
+__device__ __forceinline__ bool rect_unreachable(float sx, float sy, float ix, float iy, float iz, float fthr,
+                                                 float x0, float y0, float rows_m1) {
+    const float u0 = sx - (x0 + 15.0f), u1 = sx - x0;                               // u range (u0 <= u1)
+    const float v0 = y0 - sy, v1 = y0 + rows_m1 - sy;                               // v range
+    bool reject = false;
+    if (ix > 0.0f && iz > 0.0f && !(u0 <= 0.0f && u1 >= 0.0f && v0 <= 0.0f && v1 >= 0.0f)) {
+        auto edge_u = [&](float ue) {   // min over v in [v0,v1] of q(ue, v)
+            const float vs = fminf(fmaxf(-iy * ue / iz, v0), v1);
+            return ix * ue * ue + 2.0f * iy * ue * vs + iz * vs * vs;
+        };
+        auto edge_v = [&](float ve) {   // min over u in [u0,u1] of q(u, ve)
+            const float us = fminf(fmaxf(-iy * ve / ix, u0), u1);
+            return ix * us * us + 2.0f * iy * us * ve + iz * ve * ve;
+        };
+        const float qmin = fminf(fminf(edge_u(u0), edge_u(u1)), fminf(edge_v(v0), edge_v(v1)));
+        const float far_x = fmaxf(fabsf(u0), fabsf(u1)), far_y = fmaxf(fabsf(v0), fabsf(v1));
+        const float mag = fabsf(ix) * far_x * far_x + fabsf(iz) * far_y * far_y + 2.0f * fabsf(iy) * far_x * far_y;
+        const float tol = 0.01f + 8e-6f * mag;      // >> rounding of qmin here and of f in the pixel loop
+        reject = (-0.5f * qmin + tol < fthr);
+    }
+    return reject;
+}
+
 // RenderGaussians.comp:86-108, the per-splat setup one lane does while a batch is staged: screen position,
 // inverse 2x2 covariance, colour, plus two things the shader does not have -- the exponent below which
 // alpha < 1/255 is certain, and an exact rejection of splats that cannot touch the pixel rectangle
@@ -153,24 +176,7 @@ __device__ __forceinline__ bool stage_splat(const Fetched& nxt, float tile_x0, f
         // of the four edges, where it is a 1-D parabola with a closed-form clamped minimiser.  If
         // -q_min/2, widened by a generous bound on the fp32 error of the per-pixel f, is below the
         // skip threshold, every pixel would `continue` (:127): dropping the splat is unobservable.
-        const float u0 = sx - (tile_x0 + 15.0f), u1 = sx - tile_x0;                 // u range (u0 <= u1)
-        const float v0 = tile_y0 - sy, v1 = tile_y0 + rows_m1 - sy;                 // v range
-        bool reject = false;
-        if (det > 0.0f && ix > 0.0f && iz > 0.0f && !(u0 <= 0.0f && u1 >= 0.0f && v0 <= 0.0f && v1 >= 0.0f)) {
-            auto edge_u = [&](float ue) {   // min over v in [v0,v1] of q(ue, v)
-                const float vs = fminf(fmaxf(-iy * ue / iz, v0), v1);
-                return ix * ue * ue + 2.0f * iy * ue * vs + iz * vs * vs;
-            };
-            auto edge_v = [&](float ve) {   // min over u in [u0,u1] of q(u, ve)
-                const float us = fminf(fmaxf(-iy * ve / ix, u0), u1);
-                return ix * us * us + 2.0f * iy * us * ve + iz * ve * ve;
-            };
-            const float qmin = fminf(fminf(edge_u(u0), edge_u(u1)), fminf(edge_v(v0), edge_v(v1)));
-            const float far_x = fmaxf(fabsf(u0), fabsf(u1)), far_y = fmaxf(fabsf(v0), fabsf(v1));
-            const float mag = fabsf(ix) * far_x * far_x + fabsf(iz) * far_y * far_y + 2.0f * fabsf(iy) * far_x * far_y;
-            const float tol = 0.01f + 8e-6f * mag;      // >> rounding of qmin here and of f in the pixel loop
-            reject = (-0.5f * qmin + tol < fthr);
-        }
+        const bool reject = det > 0.0f && rect_unreachable(sx, sy, ix, iy, iz, fthr, tile_x0, tile_y0, rows_m1);
         keep = !reject;
     }
     return keep;
@@ -491,14 +497,19 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
     }
 }
 
-// Pixels per lane.  0 = choose per launch: few tiles cannot fill 1024 SIMDs with one wave each, so below
-// 6000 tiles every tile gets four waves (1 px/lane); above, one wave with 4 px/lane does the least
-// per-splat work.  Measured (exact mode, 1 / 2 / 4 px per lane): 920 tiles 0.055 / 0.075 / 0.126 ms,
-// 3600 tiles 0.102 / 0.104 / 0.125, 8160 tiles 0.348 / 0.371 / 0.285, 32400 tiles 0.71 / 0.62 / 0.66.
-#ifndef GS_RENDER_PX
-#define GS_RENDER_PX 0
-#endif
-
+// Launch shape (gs_config.render_kernel; every shape gives the same pixels).  AUTO picks by the number of tiles
+// to render, from these measurements on MI355X (exact mode, ms; 1 / 2 / 4 px per lane with independent waves,
+// then the shared-batch workgroup):
+//    920 tiles (config A)                 0.056 / 0.075 / 0.126 / 0.064
+//   1080 tiles (C, 1/8 row band)          0.068 / 0.095 / 0.148 / 0.080
+//   2040 tiles (C, 1/4 band)              0.085 / 0.103 / 0.159 / 0.087
+//   3600 tiles (config B)                 0.102 / 0.104 / 0.125 / 0.102
+//   4080 tiles (C, lower / upper half)    0.249, 0.133 / 0.285, 0.143 / 0.179, 0.191 / 0.142, 0.145
+//   8160 tiles (config C)                 0.348 / 0.371 / 0.282 / 0.243
+//  32400 tiles (config D)                 0.709 / 0.620 / 0.670 / 0.695
+// Few tiles cannot fill 1024 SIMDs with one wave each, so they get four independent waves; in the middle the
+// workgroup kernel wins because a tile is staged once and its longest dependent chain is a quarter as long; with
+// very many tiles every shape is throughput-bound and the ones that do the least per-splat work lead.
 void launch_find_ranges(const uint32_t* sorted_tile, const SortParams* params, uint32_t capacity,
                         uint32_t* ranges, hipStream_t stream) {
     uint32_t blocks = (capacity / 4u + 255u) / 256u;
@@ -517,13 +528,13 @@ void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const
 }
 
 void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
-                   const uint32_t* ranges, uint8_t* rgba, uint32_t render_mode, hipStream_t stream) {
+                   const uint32_t* ranges, uint8_t* rgba, uint32_t render_mode, uint32_t render_kernel,
+                   hipStream_t stream) {
     const uint32_t rows = fp.row_end > fp.row_begin ? fp.row_end - fp.row_begin : 0u;
     const uint32_t tiles = rows * fp.grid_w;
     if (tiles == 0) return;
     uint32_t* out = reinterpret_cast<uint32_t*>(rgba);
-    static const int px_env = getenv("GS_RENDER_PX") ? atoi(getenv("GS_RENDER_PX")) : 0;   // tuning only
-    const int px = px_env ? px_env : GS_RENDER_PX != 0 ? GS_RENDER_PX : (tiles < 6000u ? 1 : 4);
+    const uint32_t px = render_kernel != 0u ? render_kernel : tiles < 1500u ? 1u : tiles < 20000u ? 16u : 2u;
 #define GS_LAUNCH_RENDER(EXACT, PX)                                                                   \
     hipLaunchKernelGGL((k_render<EXACT, PX, false>), dim3(tiles * (4 / PX)), dim3(64), 0, stream, fp, \
                        raster, sorted_id, ranges, out, (uint4*)nullptr)

@@ -253,13 +253,14 @@ class _Context:
     """Owns one gs_ctx."""
 
     def __init__(self, device: int = 0, render_mode: int = _lib.GS_RENDER_EXACT, record_timings=True,
-                 sort_algorithm: int = _lib.GS_SORT_RADIX4):
+                 sort_algorithm: int = _lib.GS_SORT_RADIX4, render_kernel: int = _lib.GS_RENDER_KERNEL_AUTO):
         L = _lib.lib()
         cfg = GsConfig()
         L.gs_default_config(C.byref(cfg))
         cfg.device_ordinal = device
         cfg.render_mode = render_mode
         cfg.sort_algorithm = sort_algorithm
+        cfg.render_kernel = render_kernel
         cfg.record_timings = int(record_timings)   # 0 off, 1 buckets, 2 buckets + per-Scatter events
         self.cfg = cfg
         self.handle = C.c_void_p()
@@ -352,8 +353,10 @@ class Renderer:
 
     def __init__(self, width: int = 1280, height: int = 720, device: int = 0,
                  render_mode: int = _lib.GS_RENDER_EXACT, record_timings: bool = True,
-                 warmup_frames: int | None = None, sort_algorithm: int = _lib.GS_SORT_RADIX4):
+                 warmup_frames: int | None = None, sort_algorithm: int = _lib.GS_SORT_RADIX4,
+                 render_kernel: int = _lib.GS_RENDER_KERNEL_AUTO):
         self.width, self.height = int(width), int(height)   # swapchain extent (Engine.cpp:35)
+        self._render_kernel = render_kernel
         self._device, self._render_mode, self._record = device, render_mode, record_timings
         self._sort_algorithm = sort_algorithm   # GPU_SORT_ALGORITHM, Renderer.h:33
         self._ctx: _Context | None = None
@@ -371,7 +374,8 @@ class Renderer:
     # -- Renderer.cpp:688-694
     def init(self, resourceManager: ResourceManager):
         self.resourceManager = resourceManager
-        self._ctx = _Context(self._device, self._render_mode, self._record, self._sort_algorithm)
+        self._ctx = _Context(self._device, self._render_mode, self._record, self._sort_algorithm,
+                             self._render_kernel)
 
     # -- Renderer.cpp:696-710
     def getNumTiles(self) -> int:
