@@ -34,6 +34,18 @@ __device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v) {
     return v;
 }
 
+// Inclusive prefix maximum (unsigned) over the wave, same six DPP steps with max; 0 is the identity.
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false));   // row_shr:4
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false));   // row_shr:8
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31
+    return v;
+}
+
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {   // all 64 lanes active
     return wave_sum_to_lane63(v);
 }

@@ -352,8 +352,10 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict
 }
 
 // Emit: workgroup b owns splats [b*256, b*256+256) and therefore output elements
-// [block_offsets[b], +block_sums[b]).  Threads walk the OUTPUT range (coalesced stores) and find
-// their splat by binary search in the LDS scan of the 256 tile counts.
+// [block_offsets[b], +block_sums[b]).  Threads walk the OUTPUT range (coalesced stores); which splat
+// owns an element is resolved per chunk in LDS from the scan of the 256 tile counts (see the loop).
+constexpr int kEmitChunk = 4 * kProjThreads;   // output elements resolved per round of k_emit
+
 __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, const SplatScratch sc,
                                                         uint32_t* __restrict__ out_lo,
                                                         uint32_t* __restrict__ out_hi,
@@ -362,6 +364,8 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
     __shared__ uint32_t s_wave_tot[kProjThreads / 64];
     __shared__ uint2 s_ext[kProjThreads];
     __shared__ uint32_t s_depth[kProjThreads];
+    __shared__ uint32_t s_owner[kEmitChunk];
+    __shared__ uint32_t s_wmax[kProjThreads / 64];
     const uint32_t n = fp.num_gaussians;
     const int tid = threadIdx.x;
     const uint32_t g = blockIdx.x * kProjThreads + tid;
@@ -385,29 +389,64 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
     __syncthreads();
 
     const uint32_t g0 = blockIdx.x * kProjThreads;
-    for (uint32_t j = tid; j < total; j += kProjThreads) {
-        // smallest s with s_incl[s] > j
-        int lo = 0, hi = kProjThreads - 1;
+    const uint32_t my_excl = s_incl[tid] - cnt;
+    // Owner of every output element: the list is cut into chunks of kEmitChunk elements; each splat marks the
+    // first element it owns inside the chunk with its index + 1 and a prefix maximum spreads the marks (splat
+    // index grows with the start offset), instead of one 8-step binary search per element.
+    for (uint32_t c0 = 0; c0 < total; c0 += kEmitChunk) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int mid = (lo + hi) >> 1;
-            if (s_incl[mid] > j) hi = mid; else lo = mid + 1;
+        for (int k = 0; k < kEmitChunk / kProjThreads; ++k) s_owner[k * kProjThreads + tid] = 0u;
+        __syncthreads();
+        if (cnt != 0u) {
+            if (my_excl >= c0) {
+                if (my_excl - c0 < (uint32_t)kEmitChunk) s_owner[my_excl - c0] = (uint32_t)tid + 1u;
+            } else if (my_excl + cnt > c0) {
+                s_owner[0] = (uint32_t)tid + 1u;                        // the splat that straddles the chunk start
+            }
         }
-        const int s = lo;
-        const uint32_t excl = s > 0 ? s_incl[s - 1] : 0u;
-        const uint32_t id_local = j - excl;
-        const uint2 ext = s_ext[s];
-        const uint32_t min_x = ext.x & 0xFFFFu, y0 = ext.x >> 16, max_x = ext.y & 0xFFFFu;
-        const uint32_t wdt = max_x - min_x;
-        const uint32_t ry = id_local / wdt;
-        const uint32_t rx = id_local - ry * wdt;
-        const uint32_t tile_key = (y0 + ry) * fp.grid_w + (min_x + rx);  // :137
-        const uint64_t out = (uint64_t)base + j;
-        if (out < fp.capacity) {                                          // :143
-            out_hi[out] = tile_key;
-            out_lo[out] = s_depth[s];
-            out_id[out] = g0 + (uint32_t)s;
+        __syncthreads();
+        uint4 o = *reinterpret_cast<const uint4*>(&s_owner[4 * tid]);   // thread t owns elements [4t, 4t + 4)
+        o.y = o.y > o.x ? o.y : o.x;
+        o.z = o.z > o.y ? o.z : o.y;
+        o.w = o.w > o.z ? o.w : o.z;
+        const uint32_t winc = wave_inclusive_max(o.w);
+        if (lane_id() == 63) s_wmax[wave_id()] = winc;
+        uint32_t prev = __shfl_up(winc, 1, 64);
+        if (lane_id() == 0) prev = 0u;
+        __syncthreads();
+        for (int w = 0; w < wave_id(); ++w) prev = prev > s_wmax[w] ? prev : s_wmax[w];
+        o.x = o.x > prev ? o.x : prev;
+        o.y = o.y > prev ? o.y : prev;
+        o.z = o.z > prev ? o.z : prev;
+        o.w = o.w > prev ? o.w : prev;
+        *reinterpret_cast<uint4*>(&s_owner[4 * tid]) = o;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kEmitChunk / kProjThreads; ++k) {
+            const uint32_t jj = (uint32_t)(k * kProjThreads + tid);    // coalesced: consecutive lanes, consecutive slots
+            const uint32_t j = c0 + jj;
+            if (j < total) {
+                const uint32_t s = s_owner[jj] - 1u;
+                const uint32_t excl = s > 0u ? s_incl[s - 1u] : 0u;
+                const uint32_t id_local = j - excl;
+                const uint2 ext = s_ext[s];
+                const uint32_t min_x = ext.x & 0xFFFFu, y0 = ext.x >> 16, max_x = ext.y & 0xFFFFu;
+                const uint32_t wdt = max_x - min_x;
+                // id_local / wdt (both < 2^24, exact in fp32) by reciprocal with a two-sided fix-up
+                uint32_t ry = (uint32_t)((float)id_local * __builtin_amdgcn_rcpf((float)wdt));
+                int32_t rx = (int32_t)(id_local - ry * wdt);
+                if (rx < 0) { --ry; rx += (int32_t)wdt; }
+                else if ((uint32_t)rx >= wdt) { ++ry; rx -= (int32_t)wdt; }
+                const uint32_t tile_key = (y0 + ry) * fp.grid_w + (min_x + (uint32_t)rx);  // :137
+                const uint64_t out = (uint64_t)base + j;
+                if (out < fp.capacity) {                                  // :143
+                    out_hi[out] = tile_key;
+                    out_lo[out] = s_depth[s];
+                    out_id[out] = g0 + s;
+                }
+            }
         }
+        __syncthreads();
     }
 }
 
