@@ -226,3 +226,39 @@ def test_frame_sinks_round_trip(tmp_path, shape):
         gs.saveImage(str(tmp_path / "f.bmp"), img)
     with pytest.raises(gs.GsplatError):
         gs.saveImage(str(tmp_path / "no_such_dir" / "f.png"), img)
+
+
+def _build_and_run(tmp_path, name, compiler, flags, sources, args=()):
+    import shutil
+    import subprocess
+    if shutil.which(compiler) is None:
+        pytest.skip(f"{compiler} not available")
+    exe = str(tmp_path / name)
+    build = subprocess.run([compiler, *flags, "-o", exe, *sources, "-lm", "-lpthread"], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr and "cannot find" in build.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe, *args], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
+    return run.stdout
+
+
+def test_host_parsers_and_sinks_under_sanitizers(tmp_path):
+    """gs_ply.cpp + gs_image.cpp with -fsanitize=address,undefined on valid, truncated and corrupted inputs
+    (GPU sanitizers are not available on the pool: the host code is where memory checking is possible)."""
+    csrc = os.path.join(ROOT, "vk3dgaussiansplatting_amd", "csrc")
+    out = _build_and_run(tmp_path, "san_host", "g++",
+                         ["-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"],
+                         [os.path.join(ROOT, "tests", "host", "sanitize_host.cpp"),
+                          os.path.join(csrc, "gs_ply.cpp"), os.path.join(csrc, "gs_image.cpp")], [str(tmp_path)])
+    assert "sanitize_host ok" in out
+
+
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_oracle_under_sanitizers(tmp_path, san):
+    """The CPU oracle (incl. the threaded frame under -fsanitize=thread) on a small cloud."""
+    out = _build_and_run(tmp_path, "san_oracle", "gcc",
+                         ["-std=c11", "-O1", "-g", f"-fsanitize={san}", "-fno-sanitize-recover=all", "-ffp-contract=off"],
+                         [os.path.join(ROOT, "tests", "host", "sanitize_oracle.c"),
+                          os.path.join(ROOT, "oracle", "gs_oracle.c")])
+    assert "sanitize_oracle ok" in out

@@ -182,7 +182,7 @@ int gs_convert_ply(const char* path, void* aos336_out, uint32_t max_records, uin
     *n_out = n;
     if (aos336_out) {
         const uint32_t m = n < max_records ? n : max_records;
-        std::memcpy(aos336_out, rec.data(), (size_t)m * GS_GAUSSIAN_RECORD_BYTES);
+        if (m) std::memcpy(aos336_out, rec.data(), (size_t)m * GS_GAUSSIAN_RECORD_BYTES);
     }
     return GS_OK;
 }
