@@ -187,7 +187,9 @@ int gs_debug_read(gs_ctx* ctx, int which, void* dst, size_t bytes);
 int gs_debug_init_sort_list(gs_ctx* ctx, const float view[16], const float proj[16],
                             const float cam_pos[3], uint32_t sh_mode);
 
-/* Use a caller-owned hipStream_t (passed as void*) instead of the context's own stream. */
+/* Use a caller-owned hipStream_t (passed as void*) instead of the context's own stream.  NULL switches back
+ * to the context's own (non-blocking) stream: the legacy default stream has handle 0 and cannot be selected --
+ * a caller that works on it must create a stream of its own and hand that over. */
 int gs_set_stream(gs_ctx* ctx, void* hip_stream);
 
 /* Camera::updateDirVectors + updateMatrices (Engine/Graphics/Camera.cpp:7-48): yaw/pitch/position

@@ -1,0 +1,38 @@
+"""Soak: render the same frame thousands of times and require every image to be bit-identical to the first
+(catches rare races in the LDS protocols of the sort / render kernels).  usage: soak.py [config] [frames]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import vk3dgaussiansplatting_amd as gs
+from vk3dgaussiansplatting_amd import synth
+name = sys.argv[1] if len(sys.argv) > 1 else "C"
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+aos, cfg = synth.generate_config(name)
+w, h = cfg["width"], cfg["height"]
+rm = gs.ResourceManager(); rm.setGaussians(aos)
+sc = gs.Scene(rm, aspect_ratio=w / h); cam = sc.getCamera(); cam.setPosition((0, 0, 0)); cam.setRotation(0, 0); cam.recalculate()
+dev = torch.device("cuda:0")
+wts = torch.arange(1, w * h + 1, device=dev, dtype=torch.int64) * 2654435761 % 1000003
+for sort in (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET):
+    for kernel in (gs.GS_RENDER_KERNEL_AUTO, gs.GS_RENDER_KERNEL_WAVE_4PX):
+        r = gs.Renderer(w, h, record_timings=0, warmup_frames=0, sort_algorithm=sort, render_kernel=kernel)
+        r.init(rm); r.initForScene(sc)
+        img = torch.zeros((h, w), dtype=torch.int32, device=dev)
+        side = torch.cuda.Stream()               # a real stream: handle 0 (torch's default stream) means "own stream" to gs_set_stream
+        torch.cuda.synchronize()
+        r.setStream(side.cuda_stream)
+        sums = []
+        t0 = time.time()
+        with torch.cuda.stream(side):
+            for f in range(frames):
+                r.drawDevice(sc, img.data_ptr(), sync=False)
+                sums.append((img.view(-1).to(torch.int64) * wts).sum())
+        torch.cuda.synchronize()
+        vals = torch.stack(sums).cpu().numpy()
+        bad = int((vals != vals[0]).sum())
+        print(f"config {name} sort={sort} render_kernel={kernel}: {frames} frames in {time.time() - t0:.1f} s, checksum {vals[0]}, "
+              f"frames differing from the first: {bad}", flush=True)
+        r.cleanup()
+        if bad:
+            sys.exit(1)
+print("soak ok")
