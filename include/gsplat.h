@@ -131,6 +131,13 @@ const char* gs_last_error(const gs_ctx* ctx);
  * GS_GAUSSIAN_RECORD_BYTES each, as ResourceManager::getGaussians() returns them
  * (ResourceManager.h:53).  Converted once to the device SoA layout. */
 int gs_upload_gaussians(gs_ctx* ctx, const void* aos336, uint32_t n);
+/* Frames in flight (the reference keeps GfxSettings::FRAMES_IN_FLIGHT = 3 command buffers, GfxSettings.h:15,
+ * Renderer.cpp:304-310, 514): `ctx` renders the gaussians already uploaded to `owner` -- the read-only arrays
+ * are shared, everything a frame writes (sort lists, ranges, raster records, image, stream, timings) stays per
+ * context, so F contexts on F streams keep F frames in flight on one GPU.  Follow with gs_set_resolution.
+ * The owner refuses gs_destroy / gs_upload_gaussians / gs_load_ply while borrowers exist (GS_ERR_INVALID). */
+int gs_share_scene(gs_ctx* ctx, gs_ctx* owner);
+
 /* ResourceManager::loadGaussians (ResourceManager.cpp:167-300): binary little-endian .ply with the
  * INRIA property names -> records (axis flips, exp, quaternion permutation, sigmoid, SH repack,
  * Morton order) -> upload. */

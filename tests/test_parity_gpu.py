@@ -4,6 +4,7 @@ seeded inputs, the committed golden fixture, and size-independent properties at 
 Bar: sort keys, payload order, tile ranges and the element counter are bit-exact; colour /
 covariance floats are bit-exact; GS_RENDER_EXACT pixels are bit-exact; GS_RENDER_FAST pixels are
 within 1 step per 8-bit channel (north_star tolerance)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -635,3 +636,42 @@ def test_every_render_launch_shape_is_bit_exact(oracle_mod, kernel):
     fast = rf.draw(sc)
     assert np.abs(fast.astype(np.int16) - ref["image"].astype(np.int16)).max() <= 1
     rf.cleanup()
+
+
+def test_shared_scene_frames_in_flight(oracle_mod, small_cloud):
+    """gs_share_scene: three contexts over one uploaded scene, each on its own stream with its own per-frame
+    buffers, enqueued back to back without waiting (GfxSettings::FRAMES_IN_FLIGHT = 3): every slot's image is
+    the oracle's; the owner cannot be destroyed or re-uploaded while borrowed."""
+    import torch
+    w, h = 320, 180
+    sc = make_scene(small_cloud, w, h)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    owner = make_renderer(sc, w, h)
+    slots = [owner]
+    for _ in range(2):
+        r = gs.Renderer(w, h, warmup_frames=0)
+        r.init(sc.getResourceManager())
+        r.initForScene(sc, share_with=owner)
+        slots.append(r)
+    dev = torch.device("cuda:0")
+    imgs = [torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) for _ in slots]
+    streams = [torch.cuda.Stream(device=dev) for _ in slots]
+    torch.cuda.synchronize()
+    for r, st in zip(slots, streams):
+        r.setStream(st.cuda_stream)
+    for f in range(30):                                     # 30 frames, never waiting in between
+        k = f % 3
+        with torch.cuda.stream(streams[k]):
+            slots[k].drawDevice(sc, imgs[k].data_ptr(), sync=False)
+    torch.cuda.synchronize()
+    for img in imgs:
+        assert np.array_equal(img.cpu().numpy(), ref["image"])
+    L = _lib.lib()
+    assert L.gs_destroy(owner._ctx.handle) == _lib.GS_ERR_INVALID          # still borrowed
+    assert b"shared" in L.gs_last_error(owner._ctx.handle)
+    g = np.ascontiguousarray(small_cloud, dtype=np.float32)
+    assert L.gs_upload_gaussians(owner._ctx.handle, g.ctypes.data_as(C.c_void_p), g.shape[0]) == _lib.GS_ERR_INVALID
+    assert L.gs_share_scene(slots[1]._ctx.handle, slots[2]._ctx.handle) == _lib.GS_ERR_INVALID   # a borrower cannot lend
+    for r in reversed(slots):
+        r.setStream(None)
+        r.cleanup()

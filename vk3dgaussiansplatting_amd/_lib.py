@@ -86,7 +86,7 @@ EXPORTS = [
     "gs_load_ply", "gs_convert_ply", "gs_ply_last_error", "gs_set_resolution", "gs_set_tile_rows",
     "gs_get_scene_info", "gs_render", "gs_render_device", "gs_render_device_async",
     "gs_synchronize", "gs_get_timings", "gs_debug_read", "gs_debug_init_sort_list",
-    "gs_set_stream", "gs_camera_matrices", "gs_sort_host", "gs_sort_bench", "gs_membench", "gs_write_image",
+    "gs_set_stream", "gs_camera_matrices", "gs_sort_host", "gs_sort_bench", "gs_membench", "gs_write_image", "gs_share_scene",
 ]
 
 
@@ -144,5 +144,6 @@ def lib() -> C.CDLL:
     L.gs_sort_bench.argtypes = [ctxp, u32, u32, u32, C.c_uint64, C.POINTER(f32), C.POINTER(u32)]
     L.gs_membench.argtypes = [ctxp, C.c_int, C.c_size_t, u32, u32, C.POINTER(f32), C.POINTER(f32)]
     L.gs_write_image.argtypes = [C.c_char_p, vp, u32, u32]
+    L.gs_share_scene.argtypes = [ctxp, ctxp]
     _lib = L
     return L

@@ -34,6 +34,8 @@ struct gs_ctx {
     SceneBuffers scene{};
     SplatScratch scratch{};
     uint32_t num_blocks = 0;
+    gs_ctx* scene_owner = nullptr;    // gs_share_scene: the gaussian arrays belong to that context
+    uint32_t borrowers = 0;           // contexts currently sharing this context's arrays
 
     // resolution-dependent
     uint32_t width = 0, height = 0, grid_w = 0, grid_h = 0;
@@ -73,6 +75,11 @@ void free_dev(T*& p) {
 }
 
 void free_scene(gs_ctx* c) {
+    if (c->scene_owner) {             // borrowed arrays: hand them back, free only what is ours
+        if (c->scene_owner->borrowers) --c->scene_owner->borrowers;
+        c->scene_owner = nullptr;
+        c->scene = SceneBuffers{};
+    }
     free_dev(c->scene.pos); free_dev(c->scene.scale); free_dev(c->scene.rot);
     free_dev(c->scene.sh); free_dev(c->scene.opacity);
     free_dev(c->scratch.raster); free_dev(c->scratch.depth_key); free_dev(c->scratch.tiles_touched);
@@ -322,6 +329,7 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
 
 int gs_destroy(gs_ctx* c) {
     if (!c) return GS_OK;
+    if (c->borrowers) return fail(c, GS_ERR_INVALID, "gs_destroy: the scene is shared (gs_share_scene); destroy the borrowers first");
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_resolution(c);
@@ -346,19 +354,9 @@ int gs_set_stream(gs_ctx* c, void* hip_stream) {
     return GS_OK;
 }
 
-int gs_upload_gaussians(gs_ctx* c, const void* aos336, uint32_t n) {
-    if (!c) return GS_ERR_INVALID;
-    if (!aos336 || n == 0) return fail(c, GS_ERR_INVALID, "gs_upload_gaussians: empty input");
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    free_resolution(c);   // capacity depends on n (Renderer.cpp:725)
-    free_scene(c);
+// per-context, per-frame outputs of InitSortList's first kernel
+static int alloc_scratch(gs_ctx* c, uint32_t n) {
     const size_t N = n;
-    HIP_TRY(c, hipMalloc((void**)&c->scene.pos, 3 * N * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&c->scene.scale, 3 * N * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&c->scene.rot, 4 * N * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&c->scene.sh, 48 * N * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&c->scene.opacity, N * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->scratch.raster, N * sizeof(SplatRaster)));
     HIP_TRY(c, hipMalloc((void**)&c->scratch.depth_key, N * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void**)&c->scratch.tiles_touched, N * sizeof(uint32_t)));
@@ -371,6 +369,45 @@ int gs_upload_gaussians(gs_ctx* c, const void* aos336, uint32_t n) {
     HIP_TRY(c, hipMemsetAsync(c->scratch.block_sums, 0, padded * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->scratch.block_offsets, 0, padded * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->scratch.raster, 0, N * sizeof(SplatRaster), c->stream));
+    return GS_OK;
+}
+
+// Frames in flight (GfxSettings::FRAMES_IN_FLIGHT = 3, GfxSettings.h:15): several contexts render the same scene
+// on their own streams with their own per-frame buffers; only the read-only gaussian arrays are shared.
+int gs_share_scene(gs_ctx* c, gs_ctx* owner) {
+    if (!c || !owner || c == owner) return GS_ERR_INVALID;
+    if (!owner->n) return fail(c, GS_ERR_NO_SCENE, "gs_share_scene: the owner has no gaussians uploaded");
+    if (owner->scene_owner) return fail(c, GS_ERR_INVALID, "gs_share_scene: the owner itself borrows its scene");
+    if (owner->device != c->device) return fail(c, GS_ERR_INVALID, "gs_share_scene: contexts are on different devices");
+    if (c->borrowers) return fail(c, GS_ERR_INVALID, "gs_share_scene: this context's scene is shared with others");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_resolution(c);
+    free_scene(c);
+    if (int r = alloc_scratch(c, owner->n)) { free_scene(c); return r; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->scene = owner->scene;
+    c->scene_owner = owner;
+    ++owner->borrowers;
+    c->n = owner->n;
+    return GS_OK;
+}
+
+int gs_upload_gaussians(gs_ctx* c, const void* aos336, uint32_t n) {
+    if (!c) return GS_ERR_INVALID;
+    if (!aos336 || n == 0) return fail(c, GS_ERR_INVALID, "gs_upload_gaussians: empty input");
+    if (c->borrowers) return fail(c, GS_ERR_INVALID, "gs_upload_gaussians: the current scene is shared (gs_share_scene); release the borrowers first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_resolution(c);   // capacity depends on n (Renderer.cpp:725)
+    free_scene(c);
+    const size_t N = n;
+    HIP_TRY(c, hipMalloc((void**)&c->scene.pos, 3 * N * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->scene.scale, 3 * N * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->scene.rot, 4 * N * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->scene.sh, 48 * N * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->scene.opacity, N * sizeof(float)));
+    if (int r = alloc_scratch(c, n)) { free_scene(c); return r; }
 
     // AoS -> SoA on the device, through a bounded staging buffer
     const uint32_t chunk = n < (1u << 20) ? n : (1u << 20);

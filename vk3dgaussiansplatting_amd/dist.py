@@ -32,8 +32,8 @@ def strip_rows(tiles_y: int, world_size: int, tile: int = 16) -> int:
 
 
 class ShardedFrame:
-    """Band render + gather.  Two strips (ping-pong) so that the gather of frame f can run beside the
-    compute of frame f+1: `gather_async(k)` starts the collective on strip k, `wait(k)` orders the
+    """Band render + gather.  n_strips strips (round-robin) so that the gather of frame f can run beside the
+    compute of the following frames: `gather_async(k)` starts the collective on strip k, `wait(k)` orders the
     current stream (or the host, for gloo) behind it before strip k is rendered into again.
 
     `render_band(row_begin, row_end, strip)` (see `frame`) must write the band's pixel rows into the
@@ -42,7 +42,7 @@ class ShardedFrame:
     the CPU test (an injected checker)."""
 
     def __init__(self, width: int, height: int, rank: int, world_size: int, device="cpu", group=None,
-                 host_gather: bool = False):
+                 host_gather: bool = False, n_strips: int = 2):
         import torch
         self.torch = torch
         self.width, self.height = width, height
@@ -52,13 +52,14 @@ class ShardedFrame:
         self.rows = strip_rows(self.tiles_y, world_size)
         self.group = group
         self.device = device
-        self.strips = [torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.n_strips = n_strips
+        self.strips = [torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=device) for _ in range(n_strips)]
         # host_gather: rehearsal of the N > 1 path on one GPU (gloo has no device gather)
         self.host_gather = host_gather
         gdev = "cpu" if host_gather else device
         self.gathered = [([torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=gdev) for _ in range(world_size)]
-                          if rank == 0 and world_size > 1 else None) for _ in range(2)]
-        self._pending = [None, None]
+                          if rank == 0 and world_size > 1 else None) for _ in range(n_strips)]
+        self._pending = [None] * n_strips
 
     @property
     def strip(self):
@@ -85,8 +86,8 @@ class ShardedFrame:
             self._pending[k] = None
 
     def wait_all(self):
-        self.wait(0)
-        self.wait(1)
+        for k in range(self.n_strips):
+            self.wait(k)
 
     def gather(self, k: int = 0):
         """Synchronous form: rank 0 gets the list of strips."""

@@ -275,7 +275,10 @@ class _Context:
 
     def close(self):
         if self.handle:
-            _lib.lib().gs_destroy(self.handle)
+            L = _lib.lib()
+            rc = L.gs_destroy(self.handle)
+            if rc != 0:     # e.g. other contexts still share this one's scene: the handle stays valid
+                raise GsplatError(rc, L.gs_last_error(self.handle).decode())
             self.handle = C.c_void_p()
 
     def __del__(self):
@@ -389,14 +392,21 @@ class Renderer:
         return num
 
     # -- Renderer.cpp:712-756
-    def initForScene(self, scene: Scene | None = None):
+    def initForScene(self, scene: Scene | None = None, share_with: "Renderer | None" = None):
+        """share_with: another Renderer whose uploaded gaussians this one renders too (gs_share_scene) -- the way
+        to keep several frames in flight (GfxSettings::FRAMES_IN_FLIGHT, GfxSettings.h:15) without uploading the
+        scene once per frame slot.  The sharing renderer must be cleaned up before the one it borrows from."""
         assert self._ctx is not None, "Renderer.init() first"
-        g = self.resourceManager.getGaussians()
-        if g.shape[0] == 0:
-            raise GsplatError(_lib.GS_ERR_NO_SCENE, "no gaussians in the resource manager")
-        g = np.ascontiguousarray(g, dtype=np.float32)
         L = _lib.lib()
-        self._ctx.check(L.gs_upload_gaussians(self._ctx.handle, _p(g), g.shape[0]))
+        if share_with is not None:
+            assert share_with._ctx is not None
+            self._ctx.check(L.gs_share_scene(self._ctx.handle, share_with._ctx.handle))
+        else:
+            g = self.resourceManager.getGaussians()
+            if g.shape[0] == 0:
+                raise GsplatError(_lib.GS_ERR_NO_SCENE, "no gaussians in the resource manager")
+            g = np.ascontiguousarray(g, dtype=np.float32)
+            self._ctx.check(L.gs_upload_gaussians(self._ctx.handle, _p(g), g.shape[0]))
         self._ctx.check(L.gs_set_resolution(self._ctx.handle, self.width, self.height))
         info = self.sceneInfo()
         self.numGaussians = info.num_gaussians
