@@ -43,6 +43,16 @@ public:
         for (double& a : avg_) a = 0.0;
         return rc;
     }
+    // Frame slot (GfxSettings::FRAMES_IN_FLIGHT, GfxSettings.h:15): render the scene `owner` uploaded, with this
+    // renderer's own per-frame buffers and stream.  Clean this renderer up before the owner.
+    int initForSceneSharedWith(Renderer& owner) {
+        int rc = gs_share_scene(ctx_, owner.ctx_);
+        if (rc == GS_OK) rc = gs_set_resolution(ctx_, width_, height_);
+        if (rc != GS_OK) error_ = gs_last_error(ctx_);
+        elapsedFrames_ = 0;
+        for (double& a : avg_) a = 0.0;
+        return rc;
+    }
     int initForScenePly(const std::string& path) {   // ResourceManager::loadGaussians + initForScene
         int rc = gs_load_ply(ctx_, path.c_str());
         if (rc == GS_OK) rc = gs_set_resolution(ctx_, width_, height_);
