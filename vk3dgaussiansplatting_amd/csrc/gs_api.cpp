@@ -48,6 +48,12 @@ struct gs_ctx {
     uint32_t* ranges = nullptr;
     uint8_t* framebuffer = nullptr;
     int sorted_index = 0;       // which ping-pong half holds the sorted list after the last frame
+    // The radix passes of a frame (3 launches per pass, parameters fixed once resolution and band are) replayed
+    // as one hipGraph launch: 36 launches -> 1 on the host side.  Built lazily, dropped when anything it baked in
+    // changes.  Not used while per-Scatter events are recorded (record_timings == 2).
+    hipGraphExec_t sort_graph = nullptr;
+    int sort_graph_result = 0;
+    bool sort_graph_failed = false;
 
     gs_timings timings{};
     bool have_frame = false;
@@ -92,7 +98,13 @@ void free_sort(SortBuffers& s) {
     free_dev(s.table); free_dev(s.seg_sum); free_dev(s.params);
 }
 
+void drop_sort_graph(gs_ctx* c) {
+    if (c->sort_graph) { (void)hipGraphExecDestroy(c->sort_graph); c->sort_graph = nullptr; }
+    c->sort_graph_failed = false;
+}
+
 void free_resolution(gs_ctx* c) {
+    drop_sort_graph(c);
     free_sort(c->sort);
     free_dev(c->ranges); free_dev(c->framebuffer);
     c->capacity = 0; c->width = c->height = 0;
@@ -172,9 +184,28 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[2], st));
     // gpuSort->computeSort (RadixSort.cpp:207-653)
     const bool bucket = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET;
-    c->sorted_index = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st,
-                                        c->cfg.record_timings >= 2 ? c->scatter_ev : nullptr,
-                                        bucket ? 32u : 0u, c->band_tile_bias);
+    const bool per_pass_events = c->cfg.record_timings >= 2;
+    if (!per_pass_events && !c->sort_graph && !c->sort_graph_failed) {
+        // capture the passes once (nothing executes during capture)
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+            c->sort_graph_result = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, nullptr,
+                                                     bucket ? 32u : 0u, c->band_tile_bias);
+            ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&c->sort_graph, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) { c->sort_graph = nullptr; c->sort_graph_failed = true; (void)hipGetLastError(); }
+    }
+    if (!per_pass_events && c->sort_graph) {
+        HIP_TRY(c, hipGraphLaunch(c->sort_graph, st));
+        c->sorted_index = c->sort_graph_result;
+    } else {
+        c->sorted_index = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st,
+                                            per_pass_events ? c->scatter_ev : nullptr,
+                                            bucket ? 32u : 0u, c->band_tile_bias);
+    }
     if (int r = check_launch(c, "RadixSort")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[3], st));
     // computeRanges (Subrenderer.cpp:172-216)
@@ -466,6 +497,10 @@ int gs_set_tile_rows(gs_ctx* c, uint32_t row_begin, uint32_t row_end) {
     const uint32_t band_tiles = (row_end - row_begin) * c->grid_w;
     c->band_sort_bits = num_sort_bits_for(band_tiles ? band_tiles : 1u);
     c->band_tile_bias = row_begin * c->grid_w;
+    if (c->sort_graph) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));   // the graph may still be executing
+        drop_sort_graph(c);
+    }
     return GS_OK;
 }
 
