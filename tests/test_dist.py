@@ -75,3 +75,55 @@ def test_sharded_frame_equals_single_process(oracle_mod, world):
         assert p.exitcode == 0
     assert img.shape == (h, w, 4)
     assert np.array_equal(img, whole)
+
+
+def _ring_worker(rank, world, port, w, h, q):
+    """Three strips used round-robin with asynchronous gathers, as bench.py's frame slots do: frame f fills strip
+    f % 3 with a value that identifies (frame, rank), starts its gather and moves on; before a strip is filled again
+    its previous gather is waited for.  Rank 0 checks every assembled frame."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    sf = gsdist.ShardedFrame(w, h, rank, world, device="cpu", n_strips=3)
+    b, e = sf.band
+    ok, pending = True, {}
+    frames = 8
+
+    def check(k, f):
+        sf.wait(k)
+        if rank == 0:
+            img = sf.assemble(sf.gathered[k])
+            for r, (rb, re) in enumerate(sf.bands):
+                rows = img[rb * 16:min(re * 16, h)]
+                if rows.numel() and not bool((rows == (10 * f + r) % 251).all()):
+                    return False
+        return True
+
+    for f in range(frames):
+        k = f % 3
+        if k in pending:
+            ok = check(k, pending.pop(k)) and ok
+        sf.strips[k].fill_((10 * f + rank) % 251)
+        sf.gather_async(k)
+        pending[k] = f
+    for k, f in sorted(pending.items(), key=lambda kv: kv[1]):
+        ok = check(k, f) and ok
+    sf.wait_all()
+    if rank == 0:
+        q.put(ok)
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_three_strips_in_flight():
+    w, h, world = 96, 150, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, w, h, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=120) is True
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
