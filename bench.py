@@ -238,6 +238,7 @@ def main():
     ri.setStream(torch.cuda.current_stream().cuda_stream)
     buckets = np.zeros(5)
     scat = 0.0
+    scat_tile = 0.0
     k_inst = max(10, min(args.steps, 100))
     for i in range(5 + k_inst):
         ri.drawDevice(scene, strip_ptr, sync=True)
@@ -245,11 +246,15 @@ def main():
             t = ri.timings()
             buckets += [t.init_sort_list_ms, t.radix_sort_ms, t.find_ranges_ms, t.render_ms, t.total_ms]
             scat += t.scatter_ms_avg
+            scat_tile += t.scatter_tile_ms_avg
     buckets /= k_inst
     scat /= k_inst
+    scat_tile /= k_inst
     t = ri.timings()
     e_rank = int(t.num_sort_elements)
-    passes = int(t.scatter_launches)
+    passes_full = int(t.scatter_launches)
+    passes_tile = int(t.scatter_tile_launches)
+    passes = passes_full + passes_tile
     info = ri.sceneInfo()
     ri.setStream(None)
     ri.cleanup()
@@ -299,8 +304,17 @@ def main():
         value = n / ms_per_step / 1000.0            # Msplats/s, whole job
         # roofline of the dominant kernel (k_scatter): algorithmic bytes per launch =
         # 24 B per element (read 12 B key+payload, write 12 B; SURVEY 8(d): Scatter share of B_sort)
+        # the launches that move key + payload (k_scatter<true>: the eight depth-word passes of the contractual
+        # sort, every pass of the tile-bucket sorter); the tile-word passes of the frame path leave the sorted
+        # depth words behind (k_scatter<false>, 16 B per element) and are reported beside them
         alg_bytes = 24.0 * e_rank
         achieved = alg_bytes / (scat * 1e-3) / 1e9 if scat > 0 else 0.0
+        tile_pass = None
+        if passes_tile:
+            tile_pass = {"kernel": "k_scatter<false> (tile-word passes: depth words not carried)",
+                         "alg_bytes_per_launch": 16.0 * e_rank, "avg_launch_ms": round(scat_tile, 5),
+                         "achieved": round(16.0 * e_rank / (scat_tile * 1e-3) / 1e9, 1) if scat_tile > 0 else 0.0,
+                         "unit": "GB/s", "launches_per_frame": passes_tile}
         # HBM bytes per Scatter launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE
         # doubled per MI355X_MICROARCH.md; summary committed under profiles/), when measured at this E
         traffic = None
@@ -338,14 +352,16 @@ def main():
                             "incl. the strip gather with config.frames_in_flight slots overlapping on the GPU "
                             "(GfxSettings::FRAMES_IN_FLIGHT in the reference), so it can be below buckets_ms.total",
             "frame_slots_identical": slots_ok,
-            "roofline": {"bound": "hbm", "kernel": "k_scatter (radix Scatter, one launch per 4-bit pass)",
+            "roofline": {"bound": "hbm", "kernel": "k_scatter<true> (radix Scatter moving key + payload, one launch per 4-bit pass)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scat, 5),
-                         "launches_per_frame": passes,
+                         "launches_per_frame": passes_full,
                          "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
                          "frac_of_measured_copy": round(achieved / copy_gbps, 4) if copy_gbps else None},
         }
+        if tile_pass is not None:
+            out["roofline"]["tile_word_passes"] = tile_pass
         if alt is not None:
             out["alt"] = alt
         if world > 1:

@@ -91,8 +91,13 @@ typedef struct gs_timings {
     uint32_t num_sort_elements;   /* min(counter, capacity) */
     uint32_t overflowed;          /* counter > capacity this frame */
     uint64_t emitted_elements;    /* un-truncated counter */
-    float scatter_ms_avg;         /* record_timings == 2: mean duration of one Scatter launch (the dominant kernel) */
-    uint32_t scatter_launches;    /* number of Scatter launches in the frame (= passes P) */
+    float scatter_ms_avg;         /* record_timings == 2: mean duration of one Scatter launch that moves key + payload
+                                     (24 bytes per element; the dominant kernel) */
+    uint32_t scatter_launches;    /* number of those launches in the frame (the 8 depth-word passes; all passes
+                                     with GS_SORT_TILE_BUCKET) */
+    float scatter_tile_ms_avg;    /* mean duration of a tile-word pass of the frame path, which leaves the already
+                                     sorted depth words behind (16 bytes per element) */
+    uint32_t scatter_tile_launches;
 } gs_timings;
 
 /* Scene-derived sizes: Renderer.cpp:696-701 (tiles), :725 (capacity), RadixSort.cpp:203-204 (bits). */

@@ -63,6 +63,8 @@ class GsTimings(C.Structure):
         ("emitted_elements", C.c_uint64),
         ("scatter_ms_avg", C.c_float),
         ("scatter_launches", C.c_uint32),
+        ("scatter_tile_ms_avg", C.c_float),
+        ("scatter_tile_launches", C.c_uint32),
     ]
 
 

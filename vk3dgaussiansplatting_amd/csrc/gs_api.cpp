@@ -54,6 +54,7 @@ struct gs_ctx {
     hipGraphExec_t sort_graph = nullptr;
     int sort_graph_result = 0;
     bool sort_graph_failed = false;
+    bool depth_dropped = false;   // last frame's tile-word passes did not carry the depth words (see k_scatter)
 
     gs_timings timings{};
     bool have_frame = false;
@@ -191,7 +192,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
         bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
             c->sort_graph_result = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, nullptr,
-                                                     bucket ? 32u : 0u, c->band_tile_bias);
+                                                     bucket ? 32u : 0u, c->band_tile_bias, !bucket);
             ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph != nullptr;
         }
         if (ok) ok = hipGraphInstantiate(&c->sort_graph, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -204,8 +205,9 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     } else {
         c->sorted_index = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st,
                                             per_pass_events ? c->scatter_ev : nullptr,
-                                            bucket ? 32u : 0u, c->band_tile_bias);
+                                            bucket ? 32u : 0u, c->band_tile_bias, !bucket);
     }
+    c->depth_dropped = !bucket && c->band_sort_bits > 32u;
     if (int r = check_launch(c, "RadixSort")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[3], st));
     // computeRanges (Subrenderer.cpp:172-216)
@@ -255,14 +257,21 @@ int finish_frame(gs_ctx* c) {
     if (c->cfg.record_timings >= 2) {
         const uint32_t first_bit = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET ? 32u : 0u;
         const uint32_t passes = (c->band_sort_bits - first_bit) / kRadixBits;
-        float sum = 0.0f;
+        // launches that move all 24 bytes per element (k_scatter<true>) and the tile-word passes of the frame
+        // path that leave the depth words behind (k_scatter<false>, 16 bytes per element) are averaged apart
+        const bool bucket = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET;
+        float sum_full = 0.0f, sum_tile = 0.0f;
+        uint32_t n_full = 0, n_tile = 0;
         for (uint32_t k = 0; k < passes; ++k) {
             float ms = 0.0f;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->scatter_ev[2 * k], c->scatter_ev[2 * k + 1]));
-            sum += ms;
+            const uint32_t shift = first_bit + k * kRadixBits;
+            if (shift < 32u || bucket) { sum_full += ms; ++n_full; } else { sum_tile += ms; ++n_tile; }
         }
-        t.scatter_ms_avg = passes ? sum / (float)passes : 0.0f;
-        t.scatter_launches = passes;
+        t.scatter_ms_avg = n_full ? sum_full / (float)n_full : 0.0f;
+        t.scatter_launches = n_full;
+        t.scatter_tile_ms_avg = n_tile ? sum_tile / (float)n_tile : 0.0f;
+        t.scatter_tile_launches = n_tile;
     }
     t.num_sort_elements = sp.num_elems;
     t.overflowed = sp.overflow;
@@ -585,7 +594,18 @@ int gs_debug_read(gs_ctx* c, int which, void* dst, size_t bytes) {
     const int si = c->sorted_index;
     switch (which) {
         case GS_BUF_SORTED_TILE: src = c->sort.hi[si]; avail = e_bytes; break;
-        case GS_BUF_SORTED_DEPTH: src = c->sort.lo[si]; avail = e_bytes; break;
+        case GS_BUF_SORTED_DEPTH:
+            if (c->depth_dropped && c->have_frame && !c->unsorted_valid) {
+                // the frame path stops moving the depth words once they are sorted: rebuild them from the ids
+                if (bytes > e_bytes) return fail(c, GS_ERR_INVALID, "gs_debug_read: size exceeds buffer");
+                std::vector<uint32_t> ids(sp.num_elems), depth(c->n);
+                if (sp.num_elems) HIP_TRY(c, hipMemcpy(ids.data(), c->sort.id[si], e_bytes, hipMemcpyDeviceToHost));
+                HIP_TRY(c, hipMemcpy(depth.data(), c->scratch.depth_key, (size_t)c->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                uint32_t* out = static_cast<uint32_t*>(dst);
+                for (size_t i = 0; i < bytes / sizeof(uint32_t); ++i) out[i] = ids[i] < c->n ? depth[ids[i]] : 0u;
+                return GS_OK;
+            }
+            src = c->sort.lo[si]; avail = e_bytes; break;
         case GS_BUF_SORTED_ID: src = c->sort.id[si]; avail = e_bytes; break;
         case GS_BUF_RANGES: src = c->ranges; avail = (size_t)c->grid_w * c->grid_h * 8; break;
         case GS_BUF_COUNT: {

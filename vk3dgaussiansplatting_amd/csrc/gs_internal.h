@@ -113,9 +113,10 @@ void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffer
 // scatter_events: optional 2*passes events recorded right before / after every Scatter launch.
 // Passes run over key bits [first_bit, num_sort_bits) of (tile - tile_bias) << 32 | depth: a context that
 // owns a tile-row band sorts on tile ids relative to its first tile (same order, fewer significant bits).
+// drop_depth_payload: the tile-word passes (bits >= 32) do not carry the depth words (frame path only).
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events = nullptr, uint32_t first_bit = 0,
-                      uint32_t tile_bias = 0);
+                      uint32_t tile_bias = 0, bool drop_depth_payload = false);
 // GS_SORT_TILE_BUCKET: per-tile depth sort of tiles [tile0, tile0 + num_tiles) (gs_tilesort.hip)
 int init_tile_sort();
 void launch_tile_sort(const uint32_t* ranges, uint32_t tile0, uint32_t num_tiles, uint32_t* lo, uint32_t* id,

@@ -172,6 +172,7 @@ struct ScatterKeys {
     uint32_t lo[kSortKeysPerThread], hi[kSortKeysPerThread], id[kSortKeysPerThread];
 };
 
+template <bool MOVE_LO>
 __device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
                                              const uint32_t* __restrict__ in_hi,
                                              const uint32_t* __restrict__ in_id, uint32_t base,
@@ -180,7 +181,8 @@ __device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
     for (int r = 0; r < kSortKeysPerThread; ++r) {   // coalesced: 256 contiguous bytes per wave-instruction
         const uint32_t idx = base + r * 64;
         const bool ok = idx < e;
-        k.lo[r] = ok ? in_lo[idx] : 0xFFFFFFFFu;
+        if constexpr (MOVE_LO) k.lo[r] = ok ? in_lo[idx] : 0xFFFFFFFFu;
+        else k.lo[r] = 0u;
         k.hi[r] = ok ? in_hi[idx] : 0xFFFFFFFFu;
         k.id[r] = ok ? in_id[idx] : 0u;
     }
@@ -200,6 +202,11 @@ __device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
 #ifndef GS_SCATTER_MINWAVES
 #define GS_SCATTER_MINWAVES 4
 #endif
+// MOVE_LO = false: a tile-word pass of a frame.  Once the eight depth passes are done the depth words are pure
+// payload that nothing downstream reads (FindRanges wants the tile words, RenderGaussians the ids), so the last
+// passes do not carry them: 8 of 24 bytes per element less.  gs_debug_read rebuilds the sorted depth words from
+// the ids when asked.  The stand-alone sorter (gs_sort_host) and GS_SORT_TILE_BUCKET always move all three.
+template <bool MOVE_LO>
 __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
     const SortParams* __restrict__ params, const uint32_t* __restrict__ in_lo,
     const uint32_t* __restrict__ in_hi, const uint32_t* __restrict__ in_id,
@@ -224,17 +231,17 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
 
 #if GS_SCATTER_PREFETCH
     ScatterKeys nxt;
-    scatter_load(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, nxt);
+    scatter_load<MOVE_LO>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, nxt);
 #endif
 
     for (; grp < G; grp += gridDim.x) {
 #if GS_SCATTER_PREFETCH
         ScatterKeys k = nxt;
         if (grp + gridDim.x < G)
-            scatter_load(in_lo, in_hi, in_id, (grp + gridDim.x) * kSortTile + wave_off, e, nxt); // prefetch
+            scatter_load<MOVE_LO>(in_lo, in_hi, in_id, (grp + gridDim.x) * kSortTile + wave_off, e, nxt); // prefetch
 #else
         ScatterKeys k;
-        scatter_load(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, k);
+        scatter_load<MOVE_LO>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, k);
 #endif
         const uint32_t tile_base = grp * kSortTile;
         const uint32_t base = tile_base + wave_off;
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
 #else
                 const uint32_t p = s_wbase[wave][dg] + rank[r];
 #endif
-                s_lo[p] = k.lo[r];
+                if constexpr (MOVE_LO) s_lo[p] = k.lo[r];
                 s_hi[p] = k.hi[r];
                 s_id[p] = k.id[r];
             }
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
         for (int r = 0; r < kSortKeysPerThread; ++r) {
             const uint32_t p = (uint32_t)r * kSortThreads + tid;
             if (p < valid) {
-                const uint32_t l = s_lo[p], h = s_hi[p];
+                const uint32_t l = MOVE_LO ? s_lo[p] : 0u, h = s_hi[p];
                 const uint32_t d = digit_of(use_hi ? h - hi_bias : l, sh);
 #if GS_SCATTER_ABLATE & 8
                 const uint32_t o = tile_base + p + 13u + (d & 0u) < e ? tile_base + p + 13u : p;   // contiguous but misaligned
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
 #if GS_SCATTER_ABLATE & 2
                 if (l == 0x12345678u && h == 0x9abcdef0u) out_lo[o] = l;   // keeps the pipeline alive, ~never taken
 #else
-                out_lo[o] = l;
+                if constexpr (MOVE_LO) out_lo[o] = l;
                 out_hi[o] = h;
                 out_id[o] = s_id[p];
 #endif
@@ -356,7 +363,8 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
 }
 
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
-                      hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit, uint32_t tile_bias) {
+                      hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit, uint32_t tile_bias,
+                      bool drop_depth_payload) {
     const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
     const uint32_t sgrid = max_groups < (uint32_t)GS_SCATTER_GRID ? max_groups : (uint32_t)GS_SCATTER_GRID;
     int src = 0;
@@ -368,9 +376,14 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
                            word, sb.table, sb.seg_sum, shift & 31u, shift >= 32u ? tile_bias : 0u);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, sb.seg_sum);
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass], stream);
-        hipLaunchKernelGGL(k_scatter, dim3(sgrid), dim3(kSortThreads), 0, stream, sb.params,
-                           sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],
-                           sb.table, sb.seg_sum, shift, tile_bias);
+        if (shift >= 32u && drop_depth_payload)
+            hipLaunchKernelGGL(k_scatter<false>, dim3(sgrid), dim3(kSortThreads), 0, stream, sb.params,
+                               sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],
+                               sb.table, sb.seg_sum, shift, tile_bias);
+        else
+            hipLaunchKernelGGL(k_scatter<true>, dim3(sgrid), dim3(kSortThreads), 0, stream, sb.params,
+                               sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],
+                               sb.table, sb.seg_sum, shift, tile_bias);
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass + 1], stream);
         src = dst;                                                            // RadixSort.cpp:638-641
     }
