@@ -307,13 +307,16 @@ def main():
         # the launches that move key + payload (k_scatter<true>: the eight depth-word passes of the contractual
         # sort, every pass of the tile-bucket sorter); the tile-word passes of the frame path leave the sorted
         # depth words behind (k_scatter<false>, 16 B per element) and are reported beside them
-        alg_bytes = 24.0 * e_rank
+        tw = int(info.tile_word_bytes)                      # 2: tile ids travel as uint16 (grids of <= 65535 tiles)
+        per_elem_full = 2.0 * (4 + tw + 4)                  # depth word + tile word + id, read and written
+        per_elem_tile = 2.0 * (tw + 4)
+        alg_bytes = per_elem_full * e_rank
         achieved = alg_bytes / (scat * 1e-3) / 1e9 if scat > 0 else 0.0
         tile_pass = None
         if passes_tile:
             tile_pass = {"kernel": "k_scatter<false> (tile-word passes: depth words not carried)",
-                         "alg_bytes_per_launch": 16.0 * e_rank, "avg_launch_ms": round(scat_tile, 5),
-                         "achieved": round(16.0 * e_rank / (scat_tile * 1e-3) / 1e9, 1) if scat_tile > 0 else 0.0,
+                         "alg_bytes_per_launch": per_elem_tile * e_rank, "avg_launch_ms": round(scat_tile, 5),
+                         "achieved": round(per_elem_tile * e_rank / (scat_tile * 1e-3) / 1e9, 1) if scat_tile > 0 else 0.0,
                          "unit": "GB/s", "launches_per_frame": passes_tile}
         # HBM bytes per Scatter launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE
         # doubled per MI355X_MICROARCH.md; summary committed under profiles/), when measured at this E
@@ -321,7 +324,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_scatter.json")) as f:
                 pmc = json.load(f)
-            if pmc["elements"] == e_rank:
+            if pmc["elements"] == e_rank and pmc.get("tile_word_bytes", 4) == tw:
                 traffic = pmc["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -355,7 +358,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_scatter<true> (radix Scatter moving key + payload, one launch per 4-bit pass)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(scat, 5),
+                         "alg_bytes_per_launch": alg_bytes, "bytes_per_element": per_elem_full,
+                         "avg_launch_ms": round(scat, 5),
                          "launches_per_frame": passes_full,
                          "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
                          "frac_of_measured_copy": round(achieved / copy_gbps, 4) if copy_gbps else None},

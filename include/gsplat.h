@@ -108,6 +108,8 @@ typedef struct gs_scene_info {
     uint32_t capacity;            /* C = ceilPow2(N + 64*16*T) */
     uint32_t num_sort_bits;       /* 4 * P */
     uint32_t row_begin, row_end;  /* tile-row band rendered by this context */
+    uint32_t tile_word_bytes;     /* how the frame's sort list stores a tile id: 2 (uint16 relative to the band's first
+                                     tile, bands of at most 65535 tiles) or 4; callers always see uint32 global ids */
 } gs_scene_info;
 
 /* buffers readable through gs_debug_read (state after the last gs_render*) */

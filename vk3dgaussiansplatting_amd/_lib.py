@@ -79,6 +79,7 @@ class GsSceneInfo(C.Structure):
         ("num_sort_bits", C.c_uint32),
         ("row_begin", C.c_uint32),
         ("row_end", C.c_uint32),
+        ("tile_word_bytes", C.c_uint32),
     ]
 
 

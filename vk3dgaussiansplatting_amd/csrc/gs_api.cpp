@@ -44,6 +44,7 @@ struct gs_ctx {
     // what the sort of the current tile-row band runs over: tile ids relative to the band's first tile, so
     // ceil((32 + bits(T_band - 1)) / 4) passes (the reference's formula, RadixSort.cpp:203-204, for the band's T)
     uint32_t band_sort_bits = 0, band_tile_bias = 0;
+    bool hi16 = false;   // the frame's sort list stores tile ids as uint16 relative to band_tile_bias (band <= 65535 tiles)
     SortBuffers sort{};
     uint32_t* ranges = nullptr;
     uint8_t* framebuffer = nullptr;
@@ -158,6 +159,8 @@ FrameParams make_frame_params(const gs_ctx* c, const float* view, const float* p
     fp.near_plane = c->cfg.near_plane; fp.far_plane = c->cfg.far_plane;
     fp.ndc_cull = c->cfg.ndc_cull; fp.in_view_limit = c->cfg.in_view_limit;
     fp.tan_fov_y = (float)std::tan((double)(c->cfg.fov_y * 0.5f));   // Common.glsl:53, host-folded
+    fp.hi16 = c->hi16 ? 1u : 0u;
+    fp.tile_bias = c->band_tile_bias;
     return fp;
 }
 
@@ -192,7 +195,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
         bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
             c->sort_graph_result = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, nullptr,
-                                                     bucket ? 32u : 0u, c->band_tile_bias, !bucket);
+                                                     bucket ? 32u : 0u, c->band_tile_bias, !bucket, c->hi16);
             ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph != nullptr;
         }
         if (ok) ok = hipGraphInstantiate(&c->sort_graph, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -205,13 +208,14 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     } else {
         c->sorted_index = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st,
                                             per_pass_events ? c->scatter_ev : nullptr,
-                                            bucket ? 32u : 0u, c->band_tile_bias, !bucket);
+                                            bucket ? 32u : 0u, c->band_tile_bias, !bucket, c->hi16);
     }
     c->depth_dropped = !bucket && c->band_sort_bits > 32u;
     if (int r = check_launch(c, "RadixSort")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[3], st));
     // computeRanges (Subrenderer.cpp:172-216)
-    launch_find_ranges(c->sort.hi[c->sorted_index], c->sort.params, c->capacity, c->ranges, st);
+    launch_find_ranges(c->sort.hi[c->sorted_index], c->sort.params, c->capacity, c->ranges, st,
+                       c->hi16 ? 1u : 0u, c->band_tile_bias);
     if (int r = check_launch(c, "FindRanges")) return r;
     if (bucket) {
         // second half of the alternative sorter: per-tile depth sort (needs the ranges)
@@ -488,6 +492,7 @@ int gs_set_resolution(gs_ctx* c, uint32_t width, uint32_t height) {
     c->capacity = ceil_pow2((uint32_t)want);
     c->num_sort_bits = num_sort_bits_for(gw * gh);
     c->band_sort_bits = c->num_sort_bits; c->band_tile_bias = 0;
+    c->hi16 = kHi16Supported && (uint64_t)gw * gh <= 65535u;
     int rc = alloc_sort(c, c->sort, c->capacity);
     if (rc != GS_OK) { free_resolution(c); return rc; }
     HIP_TRY(c, hipMalloc((void**)&c->ranges, (size_t)gw * gh * 2 * sizeof(uint32_t)));
@@ -506,6 +511,7 @@ int gs_set_tile_rows(gs_ctx* c, uint32_t row_begin, uint32_t row_end) {
     const uint32_t band_tiles = (row_end - row_begin) * c->grid_w;
     c->band_sort_bits = num_sort_bits_for(band_tiles ? band_tiles : 1u);
     c->band_tile_bias = row_begin * c->grid_w;
+    c->hi16 = kHi16Supported && band_tiles <= 65535u;
     if (c->sort_graph) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));   // the graph may still be executing
         drop_sort_graph(c);
@@ -520,6 +526,7 @@ int gs_get_scene_info(const gs_ctx* c, gs_scene_info* out) {
     out->tiles_x = c->grid_w; out->tiles_y = c->grid_h;
     out->capacity = c->capacity; out->num_sort_bits = c->num_sort_bits;
     out->row_begin = c->row_begin; out->row_end = c->row_end;
+    out->tile_word_bytes = c->hi16 ? 2u : 4u;
     return GS_OK;
 }
 
@@ -581,6 +588,16 @@ int gs_get_timings(const gs_ctx* c, gs_timings* out) {
     return GS_OK;
 }
 
+// tile words stored as uint16 relative to the band's first tile -> the uint32 global tile ids callers expect
+static int read_tile_words(gs_ctx* c, const uint32_t* dev, uint32_t num_elems, void* dst, size_t bytes) {
+    if (bytes > (size_t)num_elems * sizeof(uint32_t)) return fail(c, GS_ERR_INVALID, "gs_debug_read: size exceeds buffer");
+    std::vector<uint16_t> h(num_elems);
+    if (num_elems) HIP_TRY(c, hipMemcpy(h.data(), dev, (size_t)num_elems * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    uint32_t* out = static_cast<uint32_t*>(dst);
+    for (size_t i = 0; i < bytes / sizeof(uint32_t); ++i) out[i] = (uint32_t)h[i] + c->band_tile_bias;
+    return GS_OK;
+}
+
 int gs_debug_read(gs_ctx* c, int which, void* dst, size_t bytes) {
     if (!c || !dst) return GS_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -593,7 +610,9 @@ int gs_debug_read(gs_ctx* c, int which, void* dst, size_t bytes) {
     size_t avail = 0;
     const int si = c->sorted_index;
     switch (which) {
-        case GS_BUF_SORTED_TILE: src = c->sort.hi[si]; avail = e_bytes; break;
+        case GS_BUF_SORTED_TILE:
+            if (c->hi16) return read_tile_words(c, c->sort.hi[si], sp.num_elems, dst, bytes);
+            src = c->sort.hi[si]; avail = e_bytes; break;
         case GS_BUF_SORTED_DEPTH:
             if (c->depth_dropped && c->have_frame && !c->unsorted_valid) {
                 // the frame path stops moving the depth words once they are sorted: rebuild them from the ids
@@ -620,6 +639,7 @@ int gs_debug_read(gs_ctx* c, int which, void* dst, size_t bytes) {
             // the list as emitted lives in ping-pong half 0 and is overwritten by the second pass
             if (!c->unsorted_valid)
                 return fail(c, GS_ERR_INVALID, "gs_debug_read: unsorted list only valid after gs_debug_init_sort_list");
+            if (which == GS_BUF_UNSORTED_TILE && c->hi16) return read_tile_words(c, c->sort.hi[0], sp.num_elems, dst, bytes);
             src = which == GS_BUF_UNSORTED_TILE ? c->sort.hi[0] : which == GS_BUF_UNSORTED_DEPTH ? c->sort.lo[0] : c->sort.id[0];
             avail = e_bytes;
             break;

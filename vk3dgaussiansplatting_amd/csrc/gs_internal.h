@@ -27,6 +27,7 @@ constexpr int kSortThreads = GS_SORT_THREADS;
 #define GS_SORT_KPT 8
 #endif
 constexpr int kSortKeysPerThread = GS_SORT_KPT;
+constexpr bool kHi16Supported = GS_SORT_KPT == 8;   // the 16-bit tile-word Count path loads 8 keys as one uint4
 constexpr int kSortTile = kSortThreads * kSortKeysPerThread; // 2048 keys
 #ifndef GS_SEGMENTS
 #define GS_SEGMENTS 1024
@@ -51,6 +52,8 @@ struct FrameParams {
     float near_plane, far_plane;
     float ndc_cull, in_view_limit;
     float tan_fov_y;      // tan(FOV_Y*0.5f), folded on the host (Common.glsl:53)
+    uint32_t hi16;        // sort list stores tile ids as uint16 relative to tile_bias (band of <= 65535 tiles)
+    uint32_t tile_bias;   // first tile of the band = row_begin * grid_w
 };
 
 // Device-side dispatch record: the role of RadixIndirectDispatch (ShaderStructs.h:45-57) +
@@ -114,16 +117,17 @@ void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffer
 // Passes run over key bits [first_bit, num_sort_bits) of (tile - tile_bias) << 32 | depth: a context that
 // owns a tile-row band sorts on tile ids relative to its first tile (same order, fewer significant bits).
 // drop_depth_payload: the tile-word passes (bits >= 32) do not carry the depth words (frame path only).
+// hi16: the hi arrays hold 16-bit tile ids relative to the band (frame path, bands of at most 65535 tiles).
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events = nullptr, uint32_t first_bit = 0,
-                      uint32_t tile_bias = 0, bool drop_depth_payload = false);
+                      uint32_t tile_bias = 0, bool drop_depth_payload = false, bool hi16 = false);
 // GS_SORT_TILE_BUCKET: per-tile depth sort of tiles [tile0, tile0 + num_tiles) (gs_tilesort.hip)
 int init_tile_sort();
 void launch_tile_sort(const uint32_t* ranges, uint32_t tile0, uint32_t num_tiles, uint32_t* lo, uint32_t* id,
                       uint32_t* lo_alt, uint32_t* id_alt, hipStream_t stream, hipStream_t helper = nullptr,
                       hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 void launch_find_ranges(const uint32_t* sorted_tile, const SortParams* params, uint32_t capacity,
-                        uint32_t* ranges, hipStream_t stream);
+                        uint32_t* ranges, hipStream_t stream, uint32_t hi16 = 0, uint32_t tile_bias = 0);
 void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
                    const uint32_t* ranges, uint8_t* rgba, uint32_t render_mode, uint32_t render_kernel,
                    hipStream_t stream);

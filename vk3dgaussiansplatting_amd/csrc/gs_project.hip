@@ -440,7 +440,8 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
                 const uint32_t tile_key = (y0 + ry) * fp.grid_w + (min_x + (uint32_t)rx);  // :137
                 const uint64_t out = (uint64_t)base + j;
                 if (out < fp.capacity) {                                  // :143
-                    out_hi[out] = tile_key;
+                    if (fp.hi16) reinterpret_cast<uint16_t*>(out_hi)[out] = (uint16_t)(tile_key - fp.tile_bias);
+                    else out_hi[out] = tile_key;
                     out_lo[out] = s_depth[s];
                     out_id[out] = g0 + s;
                 }

@@ -23,25 +23,35 @@ namespace gs {
 
 __global__ __launch_bounds__(256) void k_find_ranges(const uint32_t* __restrict__ tile,
                                                       const SortParams* __restrict__ params,
-                                                      uint32_t* __restrict__ ranges) {
+                                                      uint32_t* __restrict__ ranges, uint32_t hi16, uint32_t tile_bias) {
     const uint32_t e = params->num_elems;
-    // four consecutive elements per thread (one 16-byte load) + the element in front of them
-    const uint32_t quads = (e + 3u) / 4u;
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
-        const uint32_t i0 = q * 4u;
-        uint32_t t[4];
-        if (i0 + 3u < e) {
-            const uint4 v = *reinterpret_cast<const uint4*>(tile + i0);
-            t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    // hi16: 16-bit tile ids relative to tile_bias (see k_scatter) -- eight elements per 16-byte load, else four
+    const uint16_t* tile16 = reinterpret_cast<const uint16_t*>(tile);
+    const uint32_t per = hi16 ? 8u : 4u;
+    const uint32_t chunks = (e + per - 1u) / per;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < chunks; q += gridDim.x * blockDim.x) {
+        const uint32_t i0 = q * per;
+        uint32_t t[8];
+        if (i0 + per - 1u < e) {
+            if (hi16) {
+                const uint4 v = *reinterpret_cast<const uint4*>(tile16 + i0);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = ((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) + tile_bias;
+            } else {
+                const uint4 v = *reinterpret_cast<const uint4*>(tile + i0);
+                t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+            }
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) t[k] = i0 + k < e ? tile[i0 + k] : 0u;
+            for (int k = 0; k < 8; ++k)
+                t[k] = (uint32_t)k < per && i0 + k < e ? (hi16 ? (uint32_t)tile16[i0 + k] + tile_bias : tile[i0 + k]) : 0u;
         }
-        uint32_t prev = i0 > 0 ? tile[i0 - 1] : 0u;
+        uint32_t prev = i0 > 0 ? (hi16 ? (uint32_t)tile16[i0 - 1] + tile_bias : tile[i0 - 1]) : 0u;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
             const uint32_t i = i0 + k;
-            if (i < e) {
+            if ((uint32_t)k < per && i < e) {
                 if (i == 0) {
                     ranges[t[k] * 2 + 0] = 0;               // FindRanges.comp:59-64
                 } else if (prev != t[k]) {                  // :48-58
@@ -511,11 +521,11 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
 // workgroup kernel wins because a tile is staged once and its longest dependent chain is a quarter as long; with
 // very many tiles every shape is throughput-bound and the ones that do the least per-splat work lead.
 void launch_find_ranges(const uint32_t* sorted_tile, const SortParams* params, uint32_t capacity,
-                        uint32_t* ranges, hipStream_t stream) {
+                        uint32_t* ranges, hipStream_t stream, uint32_t hi16, uint32_t tile_bias) {
     uint32_t blocks = (capacity / 4u + 255u) / 256u;
     if (blocks > 2048u) blocks = 2048u;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(k_find_ranges, dim3(blocks), dim3(256), 0, stream, sorted_tile, params, ranges);
+    hipLaunchKernelGGL(k_find_ranges, dim3(blocks), dim3(256), 0, stream, sorted_tile, params, ranges, hi16, tile_bias);
 }
 
 void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,

@@ -46,9 +46,29 @@ constexpr int kSortWaves = kSortThreads / 64;
 static_assert(kSortKeysPerThread % 4 == 0 && kSortKeysPerThread <= 252, "packed 8-bit counters");
 constexpr int kCountVec = kSortKeysPerThread / 4;
 
+// HI16: `word` is an array of 16-bit tile ids (a group of kSortTile keys is kSortTile * 2 bytes: with 8 keys per
+// thread exactly one 16-byte load, kept in v[0]).
+template <bool HI16>
 __device__ __forceinline__ void count_load(const uint32_t* __restrict__ word, uint32_t grp, uint32_t e,
                                            int tid, uint4 (&v)[kCountVec]) {
     const uint32_t tile_base = grp * kSortTile;
+    if constexpr (HI16) {
+        static_assert(kSortKeysPerThread == 8, "HI16 count path: 8 keys = one uint4 per thread");
+        const uint16_t* h = reinterpret_cast<const uint16_t*>(word);
+        if (tile_base + kSortTile <= e) {
+            v[0] = reinterpret_cast<const uint4*>(h + tile_base)[tid];
+        } else {
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t i0 = tile_base + (uint32_t)tid * 8u + (uint32_t)q * 2u;
+                const uint32_t a = i0 < e ? h[i0] : 0u, b = i0 + 1 < e ? h[i0 + 1] : 0u;
+                w[q] = a | (b << 16);
+            }
+            v[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        return;
+    }
     if (tile_base + kSortTile <= e) {
         const uint4* w4 = reinterpret_cast<const uint4*>(word + tile_base);
 #pragma unroll
@@ -67,7 +87,7 @@ __device__ __forceinline__ void count_load(const uint32_t* __restrict__ word, ui
 
 // ABLATE is a tuning-only switch (gs_debug_count_bench): bit 1 drops the table store, bit 2 the
 // counting itself.  The product always launches ABLATE = 0.
-template <int ABLATE>
+template <int ABLATE, bool HI16 = false>
 __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __restrict__ params,
                                                          const uint32_t* __restrict__ word,
                                                          uint32_t* __restrict__ table,
@@ -81,18 +101,29 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
     const uint32_t grp_end = (grp + K < G) ? grp + K : G;
     uint32_t seg_total = 0;     // threads 0..15: this segment's total of digit tid
     uint4 nxt[kCountVec];
-    if (grp < grp_end) count_load(word, grp, e, tid, nxt);
+    if (grp < grp_end) count_load<HI16>(word, grp, e, tid, nxt);
     for (int it = 0; grp < grp_end; ++grp, it ^= 1) {
         uint4 v[kCountVec];
 #pragma unroll
         for (int r = 0; r < kCountVec; ++r) v[r] = nxt[r];
-        if (grp + 1 < grp_end) count_load(word, grp + 1, e, tid, nxt);   // prefetch
+        if (grp + 1 < grp_end) count_load<HI16>(word, grp + 1, e, tid, nxt);   // prefetch
         const uint32_t tile_base = grp * kSortTile;
         const bool full = tile_base + kSortTile <= e;
         uint64_t c0 = 0, c1 = 0;   // digits 0-7 / 8-15, one byte each
         if (ABLATE & 4) {
 #pragma unroll
             for (int r = 0; r < kCountVec; ++r) c0 += v[r].x ^ v[r].y ^ v[r].z ^ v[r].w;
+        } else if constexpr (HI16) {
+            const uint32_t k[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t key = (k[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                const uint32_t d = digit_of(key - bias, sh);
+                const bool ok = full || tile_base + (uint32_t)tid * 8u + (uint32_t)q < e;
+                const uint64_t inc = ok ? 1ull << ((d & 7u) * 8u) : 0ull;
+                c0 += (d & 8u) ? 0ull : inc;
+                c1 += (d & 8u) ? inc : 0ull;
+            }
         } else
 #pragma unroll
         for (int r = 0; r < kCountVec; ++r) {
@@ -172,7 +203,7 @@ struct ScatterKeys {
     uint32_t lo[kSortKeysPerThread], hi[kSortKeysPerThread], id[kSortKeysPerThread];
 };
 
-template <bool MOVE_LO>
+template <bool MOVE_LO, bool HI16>
 __device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
                                              const uint32_t* __restrict__ in_hi,
                                              const uint32_t* __restrict__ in_id, uint32_t base,
@@ -183,7 +214,8 @@ __device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
         const bool ok = idx < e;
         if constexpr (MOVE_LO) k.lo[r] = ok ? in_lo[idx] : 0xFFFFFFFFu;
         else k.lo[r] = 0u;
-        k.hi[r] = ok ? in_hi[idx] : 0xFFFFFFFFu;
+        if constexpr (HI16) k.hi[r] = ok ? (uint32_t)reinterpret_cast<const uint16_t*>(in_hi)[idx] : 0xFFFFu;
+        else k.hi[r] = ok ? in_hi[idx] : 0xFFFFFFFFu;
         k.id[r] = ok ? in_id[idx] : 0u;
     }
 }
@@ -206,7 +238,9 @@ __device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
 // payload that nothing downstream reads (FindRanges wants the tile words, RenderGaussians the ids), so the last
 // passes do not carry them: 8 of 24 bytes per element less.  gs_debug_read rebuilds the sorted depth words from
 // the ids when asked.  The stand-alone sorter (gs_sort_host) and GS_SORT_TILE_BUCKET always move all three.
-template <bool MOVE_LO>
+// HI16: the tile words are stored as 16-bit ids relative to the band's first tile (any grid of at most 65535 tiles):
+// 2 bytes less read and 2 less written per element in every pass.
+template <bool MOVE_LO, bool HI16>
 __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
     const SortParams* __restrict__ params, const uint32_t* __restrict__ in_lo,
     const uint32_t* __restrict__ in_hi, const uint32_t* __restrict__ in_id,
@@ -231,17 +265,17 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
 
 #if GS_SCATTER_PREFETCH
     ScatterKeys nxt;
-    scatter_load<MOVE_LO>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, nxt);
+    scatter_load<MOVE_LO, HI16>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, nxt);
 #endif
 
     for (; grp < G; grp += gridDim.x) {
 #if GS_SCATTER_PREFETCH
         ScatterKeys k = nxt;
         if (grp + gridDim.x < G)
-            scatter_load<MOVE_LO>(in_lo, in_hi, in_id, (grp + gridDim.x) * kSortTile + wave_off, e, nxt); // prefetch
+            scatter_load<MOVE_LO, HI16>(in_lo, in_hi, in_id, (grp + gridDim.x) * kSortTile + wave_off, e, nxt); // prefetch
 #else
         ScatterKeys k;
-        scatter_load<MOVE_LO>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, k);
+        scatter_load<MOVE_LO, HI16>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, k);
 #endif
         const uint32_t tile_base = grp * kSortTile;
         const uint32_t base = tile_base + wave_off;
@@ -353,7 +387,8 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
                 if (l == 0x12345678u && h == 0x9abcdef0u) out_lo[o] = l;   // keeps the pipeline alive, ~never taken
 #else
                 if constexpr (MOVE_LO) out_lo[o] = l;
-                out_hi[o] = h;
+                if constexpr (HI16) reinterpret_cast<uint16_t*>(out_hi)[o] = (uint16_t)h;
+                else out_hi[o] = h;
                 out_id[o] = s_id[p];
 #endif
             }
@@ -364,26 +399,34 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
 
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit, uint32_t tile_bias,
-                      bool drop_depth_payload) {
+                      bool drop_depth_payload, bool hi16) {
     const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
     const uint32_t sgrid = max_groups < (uint32_t)GS_SCATTER_GRID ? max_groups : (uint32_t)GS_SCATTER_GRID;
+    if (hi16) tile_bias = 0;   // 16-bit tile words are stored relative to the band already
     int src = 0;
     uint32_t pass = 0;
     for (uint32_t shift = first_bit; shift < num_sort_bits; shift += kRadixBits, ++pass) { // RadixSort.cpp:309
         const int dst = src ^ 1;
-        const uint32_t* word = shift >= 32u ? sb.hi[src] : sb.lo[src];
-        hipLaunchKernelGGL(k_count<0>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
-                           word, sb.table, sb.seg_sum, shift & 31u, shift >= 32u ? tile_bias : 0u);
+        const bool tile_pass = shift >= 32u;
+        const uint32_t* word = tile_pass ? sb.hi[src] : sb.lo[src];
+        if constexpr (kHi16Supported) {
+            if (tile_pass && hi16)
+                hipLaunchKernelGGL((k_count<0, true>), dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
+                                   word, sb.table, sb.seg_sum, shift & 31u, 0u);
+        }
+        if (!(kHi16Supported && tile_pass && hi16))
+            hipLaunchKernelGGL((k_count<0, false>), dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
+                               word, sb.table, sb.seg_sum, shift & 31u, tile_pass ? tile_bias : 0u);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, sb.seg_sum);
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass], stream);
-        if (shift >= 32u && drop_depth_payload)
-            hipLaunchKernelGGL(k_scatter<false>, dim3(sgrid), dim3(kSortThreads), 0, stream, sb.params,
-                               sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],
-                               sb.table, sb.seg_sum, shift, tile_bias);
-        else
-            hipLaunchKernelGGL(k_scatter<true>, dim3(sgrid), dim3(kSortThreads), 0, stream, sb.params,
-                               sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],
-                               sb.table, sb.seg_sum, shift, tile_bias);
+        const bool move_lo = !(tile_pass && drop_depth_payload);
+#define GS_LAUNCH_SCATTER(MOVE_LO, HI16)                                                                    \
+        hipLaunchKernelGGL((k_scatter<MOVE_LO, HI16>), dim3(sgrid), dim3(kSortThreads), 0, stream, sb.params, \
+                           sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],           \
+                           sb.table, sb.seg_sum, shift, tile_bias)
+        if (move_lo) { if (hi16) GS_LAUNCH_SCATTER(true, true); else GS_LAUNCH_SCATTER(true, false); }
+        else         { if (hi16) GS_LAUNCH_SCATTER(false, true); else GS_LAUNCH_SCATTER(false, false); }
+#undef GS_LAUNCH_SCATTER
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass + 1], stream);
         src = dst;                                                            // RadixSort.cpp:638-641
     }
