@@ -307,16 +307,22 @@ def main():
         # the launches that move key + payload (k_scatter<true>: the eight depth-word passes of the contractual
         # sort, every pass of the tile-bucket sorter); the tile-word passes of the frame path leave the sorted
         # depth words behind (k_scatter<false>, 16 B per element) and are reported beside them
-        tw = int(info.tile_word_bytes)                      # 2: tile ids travel as uint16 (grids of <= 65535 tiles)
-        per_elem_full = 2.0 * (4 + tw + 4)                  # depth word + tile word + id, read and written
-        per_elem_tile = 2.0 * (tw + 4)
-        alg_bytes = per_elem_full * e_rank
+        # ALGORITHMIC bytes of a Scatter launch = SURVEY 8(d)'s figure: 12 B read + 12 B written per element.
+        # What this build really moves is less: tile ids travel as uint16 when the grid has <= 65535 tiles
+        # (tile_word_bytes), and the tile-word passes leave the sorted depth words behind; both are reported.
+        tw = int(info.tile_word_bytes)
+        moved_full = 2.0 * (4 + tw + 4)                     # depth word + tile word + id, read and written
+        moved_tile = 2.0 * (tw + 4)
+        alg_bytes = 24.0 * e_rank
         achieved = alg_bytes / (scat * 1e-3) / 1e9 if scat > 0 else 0.0
+        achieved_moved = moved_full * e_rank / (scat * 1e-3) / 1e9 if scat > 0 else 0.0
         tile_pass = None
         if passes_tile:
             tile_pass = {"kernel": "k_scatter<false> (tile-word passes: depth words not carried)",
-                         "alg_bytes_per_launch": per_elem_tile * e_rank, "avg_launch_ms": round(scat_tile, 5),
-                         "achieved": round(per_elem_tile * e_rank / (scat_tile * 1e-3) / 1e9, 1) if scat_tile > 0 else 0.0,
+                         "alg_bytes_per_launch": alg_bytes, "moved_bytes_per_element": moved_tile,
+                         "avg_launch_ms": round(scat_tile, 5),
+                         "achieved": round(alg_bytes / (scat_tile * 1e-3) / 1e9, 1) if scat_tile > 0 else 0.0,
+                         "achieved_on_moved_bytes": round(moved_tile * e_rank / (scat_tile * 1e-3) / 1e9, 1) if scat_tile > 0 else 0.0,
                          "unit": "GB/s", "launches_per_frame": passes_tile}
         # HBM bytes per Scatter launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE
         # doubled per MI355X_MICROARCH.md; summary committed under profiles/), when measured at this E
@@ -358,11 +364,14 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_scatter<true> (radix Scatter moving key + payload, one launch per 4-bit pass)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes, "bytes_per_element": per_elem_full,
+                         "alg_bytes_per_launch": alg_bytes, "alg_bytes_per_element": 24.0,
+                         "moved_bytes_per_element": moved_full, "achieved_on_moved_bytes": round(achieved_moved, 1),
                          "avg_launch_ms": round(scat, 5),
                          "launches_per_frame": passes_full,
                          "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
-                         "frac_of_measured_copy": round(achieved / copy_gbps, 4) if copy_gbps else None},
+                         "frac_of_measured_copy": round(achieved_moved / copy_gbps, 4) if copy_gbps else None,
+                         "note": "achieved/frac use SURVEY 8(d)'s 24 B per element; frac_of_measured_copy uses the bytes "
+                                 "really moved against the stream-copy rate measured on this GPU"},
         }
         if tile_pass is not None:
             out["roofline"]["tile_word_passes"] = tile_pass

@@ -14,7 +14,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"].split("(")[0][:48]].append(float(r["Counter_Value"]))
     res[c] = agg
+import json
+out = {}
 for k in sorted(res["FETCH_SIZE"]):
     fv = res["FETCH_SIZE"][k]; wv = res["WRITE_SIZE"].get(k, [0])
-    print(f"{k:50s} launches={len(fv):4d}  read {2*sum(fv)/len(fv)*1024/1e6:9.1f} MB  write {sum(wv)/len(wv)*1024/1e6:9.1f} MB")
+    rd, wr = 2 * sum(fv) / len(fv) * 1024, sum(wv) / len(wv) * 1024     # FETCH_SIZE x2 (MI355X_MICROARCH.md), KB -> bytes
+    out[k] = {"launches": len(fv), "read_bytes": round(rd), "write_bytes": round(wr)}
+    print(f"{k:50s} launches={len(fv):4d}  read {rd/1e6:9.1f} MB  write {wr/1e6:9.1f} MB")
+json.dump(out, open("gpurun_out/pmc_frame/traffic.json", "w"), indent=1)
 PY
