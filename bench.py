@@ -311,14 +311,14 @@ def main():
         # What this build really moves is less: tile ids travel as uint16 when the grid has <= 65535 tiles
         # (tile_word_bytes), and the tile-word passes leave the sorted depth words behind; both are reported.
         tw = int(info.tile_word_bytes)
-        moved_full = 2.0 * (4 + tw + 4)                     # depth word + tile word + id, read and written
-        moved_tile = 2.0 * (tw + 4)
+        moved_full = float(t.scatter_bytes_per_elem)        # depth word + tile word + id, read and written (mean over the launches)
+        moved_tile = float(t.scatter_tile_bytes_per_elem)
         alg_bytes = 24.0 * e_rank
         achieved = alg_bytes / (scat * 1e-3) / 1e9 if scat > 0 else 0.0
         achieved_moved = moved_full * e_rank / (scat * 1e-3) / 1e9 if scat > 0 else 0.0
         tile_pass = None
         if passes_tile:
-            tile_pass = {"kernel": "k_scatter<false> (tile-word passes: depth words not carried)",
+            tile_pass = {"kernel": "k_scatter<0, 0, .> (tile-word passes: depth words not carried)",
                          "alg_bytes_per_launch": alg_bytes, "moved_bytes_per_element": moved_tile,
                          "avg_launch_ms": round(scat_tile, 5),
                          "achieved": round(alg_bytes / (scat_tile * 1e-3) / 1e9, 1) if scat_tile > 0 else 0.0,
@@ -361,7 +361,7 @@ def main():
                             "incl. the strip gather with config.frames_in_flight slots overlapping on the GPU "
                             "(GfxSettings::FRAMES_IN_FLIGHT in the reference), so it can be below buckets_ms.total",
             "frame_slots_identical": slots_ok,
-            "roofline": {"bound": "hbm", "kernel": "k_scatter<true> (radix Scatter moving key + payload, one launch per 4-bit pass)",
+            "roofline": {"bound": "hbm", "kernel": "k_scatter, the depth-word passes (radix Scatter moving key + payload, one launch per 4-bit pass)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "alg_bytes_per_element": 24.0,

@@ -98,6 +98,8 @@ typedef struct gs_timings {
     float scatter_tile_ms_avg;    /* mean duration of a tile-word pass of the frame path, which leaves the already
                                      sorted depth words behind (16 bytes per element) */
     uint32_t scatter_tile_launches;
+    float scatter_bytes_per_elem;       /* bytes per element really moved (read + written) by the launches above, mean */
+    float scatter_tile_bytes_per_elem;
 } gs_timings;
 
 /* Scene-derived sizes: Renderer.cpp:696-701 (tiles), :725 (capacity), RadixSort.cpp:203-204 (bits). */

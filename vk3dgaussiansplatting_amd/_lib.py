@@ -65,6 +65,8 @@ class GsTimings(C.Structure):
         ("scatter_launches", C.c_uint32),
         ("scatter_tile_ms_avg", C.c_float),
         ("scatter_tile_launches", C.c_uint32),
+        ("scatter_bytes_per_elem", C.c_float),
+        ("scatter_tile_bytes_per_elem", C.c_float),
     ]
 
 

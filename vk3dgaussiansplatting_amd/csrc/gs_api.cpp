@@ -210,7 +210,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
                                             per_pass_events ? c->scatter_ev : nullptr,
                                             bucket ? 32u : 0u, c->band_tile_bias, !bucket, c->hi16);
     }
-    c->depth_dropped = !bucket && c->band_sort_bits > 32u;
+    c->depth_dropped = !bucket;
     if (int r = check_launch(c, "RadixSort")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[3], st));
     // computeRanges (Subrenderer.cpp:172-216)
@@ -264,14 +264,20 @@ int finish_frame(gs_ctx* c) {
         // launches that move all 24 bytes per element (k_scatter<true>) and the tile-word passes of the frame
         // path that leave the depth words behind (k_scatter<false>, 16 bytes per element) are averaged apart
         const bool bucket = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET;
-        float sum_full = 0.0f, sum_tile = 0.0f;
+        float sum_full = 0.0f, sum_tile = 0.0f, bytes_full = 0.0f, bytes_tile = 0.0f;
         uint32_t n_full = 0, n_tile = 0;
         for (uint32_t k = 0; k < passes; ++k) {
             float ms = 0.0f;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->scatter_ev[2 * k], c->scatter_ev[2 * k + 1]));
             const uint32_t shift = first_bit + k * kRadixBits;
-            if (shift < 32u || bucket) { sum_full += ms; ++n_full; } else { sum_tile += ms; ++n_tile; }
+            int lo_in, lo_out;
+            scatter_depth_bytes(shift, first_bit, !bucket, &lo_in, &lo_out);
+            const float moved = (float)(lo_in + lo_out) + 2.0f * (c->hi16 ? 2.0f : 4.0f) + 8.0f;   // depth + tile + id, r + w
+            if (shift < 32u || bucket) { sum_full += ms; ++n_full; bytes_full += moved; }
+            else { sum_tile += ms; ++n_tile; bytes_tile += moved; }
         }
+        t.scatter_bytes_per_elem = n_full ? bytes_full / (float)n_full : 0.0f;
+        t.scatter_tile_bytes_per_elem = n_tile ? bytes_tile / (float)n_tile : 0.0f;
         t.scatter_ms_avg = n_full ? sum_full / (float)n_full : 0.0f;
         t.scatter_launches = n_full;
         t.scatter_tile_ms_avg = n_tile ? sum_tile / (float)n_tile : 0.0f;

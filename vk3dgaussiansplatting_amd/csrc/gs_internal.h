@@ -105,6 +105,18 @@ struct SortBuffers {
     SortParams* params;
 };
 
+// Bytes of the depth word a radix pass reads / writes per element (k_scatter<LO_IN, LO_OUT, HI16>); shared by the
+// launcher and by the timing code that reports the bytes a pass moves.
+inline void scatter_depth_bytes(uint32_t shift, uint32_t first_bit, bool drop_depth_payload, int* lo_in, int* lo_out) {
+    *lo_in = 4; *lo_out = 4;
+    if (!drop_depth_payload) return;
+    if (shift >= 32u) { *lo_in = 0; *lo_out = 0; return; }
+    if (first_bit == 0u && kHi16Supported) {
+        *lo_in = shift >= 16u ? 2 : 4;
+        *lo_out = shift >= 28u ? 0 : (shift >= 12u ? 2 : 4);
+    }
+}
+
 // ---- launchers (each enqueues on `stream`, no host sync) ------------------------------------
 void launch_project(const FrameParams& fp, const SceneBuffers& scene, const SplatScratch& sc,
                     hipStream_t stream);

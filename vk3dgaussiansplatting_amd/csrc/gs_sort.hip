@@ -203,7 +203,7 @@ struct ScatterKeys {
     uint32_t lo[kSortKeysPerThread], hi[kSortKeysPerThread], id[kSortKeysPerThread];
 };
 
-template <bool MOVE_LO, bool HI16>
+template <int LO_IN, bool HI16>
 __device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
                                              const uint32_t* __restrict__ in_hi,
                                              const uint32_t* __restrict__ in_id, uint32_t base,
@@ -212,7 +212,8 @@ __device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
     for (int r = 0; r < kSortKeysPerThread; ++r) {   // coalesced: 256 contiguous bytes per wave-instruction
         const uint32_t idx = base + r * 64;
         const bool ok = idx < e;
-        if constexpr (MOVE_LO) k.lo[r] = ok ? in_lo[idx] : 0xFFFFFFFFu;
+        if constexpr (LO_IN == 4) k.lo[r] = ok ? in_lo[idx] : 0xFFFFFFFFu;
+        else if constexpr (LO_IN == 2) k.lo[r] = ok ? (uint32_t)reinterpret_cast<const uint16_t*>(in_lo)[idx] : 0xFFFFu;
         else k.lo[r] = 0u;
         if constexpr (HI16) k.hi[r] = ok ? (uint32_t)reinterpret_cast<const uint16_t*>(in_hi)[idx] : 0xFFFFu;
         else k.hi[r] = ok ? in_hi[idx] : 0xFFFFFFFFu;
@@ -234,13 +235,15 @@ __device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
 #ifndef GS_SCATTER_MINWAVES
 #define GS_SCATTER_MINWAVES 4
 #endif
-// MOVE_LO = false: a tile-word pass of a frame.  Once the eight depth passes are done the depth words are pure
-// payload that nothing downstream reads (FindRanges wants the tile words, RenderGaussians the ids), so the last
-// passes do not carry them: 8 of 24 bytes per element less.  gs_debug_read rebuilds the sorted depth words from
-// the ids when asked.  The stand-alone sorter (gs_sort_host) and GS_SORT_TILE_BUCKET always move all three.
+// LO_IN / LO_OUT = bytes of the depth word read / written per element (4, 2 or 0).  The stand-alone sorter
+// (gs_sort_host) and GS_SORT_TILE_BUCKET use <4, 4>: everything moves.  In a frame the depth word is needed only as a
+// sort key -- FindRanges reads the tile words, RenderGaussians the ids, gs_debug_read rebuilds the sorted depth
+// words from the ids -- so bits a pass has consumed are dead weight: passes 0-2 run <4, 4>, pass 3 writes only the
+// upper half <4, 2>, passes 4-6 sort on that half <2, 2>, pass 7 (last depth digit) does not write it <2, 0>, and the
+// tile-word passes run <0, 0>.
 // HI16: the tile words are stored as 16-bit ids relative to the band's first tile (any grid of at most 65535 tiles):
 // 2 bytes less read and 2 less written per element in every pass.
-template <bool MOVE_LO, bool HI16>
+template <int LO_IN, int LO_OUT, bool HI16>
 __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
     const SortParams* __restrict__ params, const uint32_t* __restrict__ in_lo,
     const uint32_t* __restrict__ in_hi, const uint32_t* __restrict__ in_id,
@@ -260,22 +263,22 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
     if (grp >= G) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool use_hi = shift >= 32u;
-    const uint32_t sh = shift & 31u;
+    const uint32_t sh = use_hi ? shift - 32u : (LO_IN == 2 ? shift - 16u : shift);   // bit offset inside the stored word
     const uint32_t wave_off = (uint32_t)wave * (kSortKeysPerThread * 64) + lane;
 
 #if GS_SCATTER_PREFETCH
     ScatterKeys nxt;
-    scatter_load<MOVE_LO, HI16>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, nxt);
+    scatter_load<LO_IN, HI16>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, nxt);
 #endif
 
     for (; grp < G; grp += gridDim.x) {
 #if GS_SCATTER_PREFETCH
         ScatterKeys k = nxt;
         if (grp + gridDim.x < G)
-            scatter_load<MOVE_LO, HI16>(in_lo, in_hi, in_id, (grp + gridDim.x) * kSortTile + wave_off, e, nxt); // prefetch
+            scatter_load<LO_IN, HI16>(in_lo, in_hi, in_id, (grp + gridDim.x) * kSortTile + wave_off, e, nxt); // prefetch
 #else
         ScatterKeys k;
-        scatter_load<MOVE_LO, HI16>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, k);
+        scatter_load<LO_IN, HI16>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, k);
 #endif
         const uint32_t tile_base = grp * kSortTile;
         const uint32_t base = tile_base + wave_off;
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
 #else
                 const uint32_t p = s_wbase[wave][dg] + rank[r];
 #endif
-                if constexpr (MOVE_LO) s_lo[p] = k.lo[r];
+                if constexpr (LO_IN != 0) s_lo[p] = k.lo[r];
                 s_hi[p] = k.hi[r];
                 s_id[p] = k.id[r];
             }
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
         for (int r = 0; r < kSortKeysPerThread; ++r) {
             const uint32_t p = (uint32_t)r * kSortThreads + tid;
             if (p < valid) {
-                const uint32_t l = MOVE_LO ? s_lo[p] : 0u, h = s_hi[p];
+                const uint32_t l = LO_IN != 0 ? s_lo[p] : 0u, h = s_hi[p];
                 const uint32_t d = digit_of(use_hi ? h - hi_bias : l, sh);
 #if GS_SCATTER_ABLATE & 8
                 const uint32_t o = tile_base + p + 13u + (d & 0u) < e ? tile_base + p + 13u : p;   // contiguous but misaligned
@@ -386,7 +389,8 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
 #if GS_SCATTER_ABLATE & 2
                 if (l == 0x12345678u && h == 0x9abcdef0u) out_lo[o] = l;   // keeps the pipeline alive, ~never taken
 #else
-                if constexpr (MOVE_LO) out_lo[o] = l;
+                if constexpr (LO_OUT == 4) out_lo[o] = l;
+                else if constexpr (LO_OUT == 2) reinterpret_cast<uint16_t*>(out_lo)[o] = (uint16_t)(LO_IN == 4 ? l >> 16 : l);
                 if constexpr (HI16) reinterpret_cast<uint16_t*>(out_hi)[o] = (uint16_t)h;
                 else out_hi[o] = h;
                 out_id[o] = s_id[p];
@@ -409,23 +413,37 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
         const int dst = src ^ 1;
         const bool tile_pass = shift >= 32u;
         const uint32_t* word = tile_pass ? sb.hi[src] : sb.lo[src];
+        // 16-bit words: the tile ids of a band (hi16) and, in a frame, the upper half of the depth word once the
+        // lower half is consumed (passes 4-7, see k_scatter)
+        int cin, cout;
+        scatter_depth_bytes(shift, first_bit, drop_depth_payload, &cin, &cout);
+        const bool lo16 = !tile_pass && cin == 2;
+        const bool word16 = kHi16Supported && ((tile_pass && hi16) || lo16);
         if constexpr (kHi16Supported) {
-            if (tile_pass && hi16)
+            if (word16)
                 hipLaunchKernelGGL((k_count<0, true>), dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
-                                   word, sb.table, sb.seg_sum, shift & 31u, 0u);
+                                   word, sb.table, sb.seg_sum, lo16 ? shift - 16u : shift & 31u, 0u);
         }
-        if (!(kHi16Supported && tile_pass && hi16))
+        if (!word16)
             hipLaunchKernelGGL((k_count<0, false>), dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
                                word, sb.table, sb.seg_sum, shift & 31u, tile_pass ? tile_bias : 0u);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, sb.seg_sum);
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass], stream);
-        const bool move_lo = !(tile_pass && drop_depth_payload);
-#define GS_LAUNCH_SCATTER(MOVE_LO, HI16)                                                                    \
-        hipLaunchKernelGGL((k_scatter<MOVE_LO, HI16>), dim3(sgrid), dim3(kSortThreads), 0, stream, sb.params, \
-                           sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],           \
+        // bytes of the depth word read / written by this pass (see k_scatter)
+        int lo_in, lo_out;
+        scatter_depth_bytes(shift, first_bit, drop_depth_payload, &lo_in, &lo_out);
+#define GS_LAUNCH_SCATTER(LO_IN, LO_OUT, HI16)                                                                       \
+        hipLaunchKernelGGL((k_scatter<LO_IN, LO_OUT, HI16>), dim3(sgrid), dim3(kSortThreads), 0, stream, sb.params, \
+                           sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],                  \
                            sb.table, sb.seg_sum, shift, tile_bias)
-        if (move_lo) { if (hi16) GS_LAUNCH_SCATTER(true, true); else GS_LAUNCH_SCATTER(true, false); }
-        else         { if (hi16) GS_LAUNCH_SCATTER(false, true); else GS_LAUNCH_SCATTER(false, false); }
+#define GS_LAUNCH_SCATTER_H(LO_IN, LO_OUT) \
+        do { if (hi16) GS_LAUNCH_SCATTER(LO_IN, LO_OUT, true); else GS_LAUNCH_SCATTER(LO_IN, LO_OUT, false); } while (0)
+        if (lo_in == 4 && lo_out == 4) GS_LAUNCH_SCATTER_H(4, 4);
+        else if (lo_in == 4 && lo_out == 2) GS_LAUNCH_SCATTER_H(4, 2);
+        else if (lo_in == 2 && lo_out == 2) GS_LAUNCH_SCATTER_H(2, 2);
+        else if (lo_in == 2 && lo_out == 0) GS_LAUNCH_SCATTER_H(2, 0);
+        else GS_LAUNCH_SCATTER_H(0, 0);
+#undef GS_LAUNCH_SCATTER_H
 #undef GS_LAUNCH_SCATTER
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass + 1], stream);
         src = dst;                                                            // RadixSort.cpp:638-641
