@@ -221,6 +221,26 @@ __device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
     }
 }
 
+// ScanAdd inputs of one group for this wave's four digits: the lane's share of the per-group counts of the earlier
+// groups of the segment, and the scanned segment base.
+struct ScanAddRegs {
+    uint32_t pre[kBins / kSortWaves], base[kBins / kSortWaves];
+};
+
+__device__ __forceinline__ void scan_add_load(const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base,
+                                              uint32_t grp, uint32_t G, uint32_t K, int wave, int lane, ScanAddRegs& sa) {
+    const uint32_t seg = grp / K, j = grp - seg * K;   // j < K (K <= 64 up to 134 M elements)
+#pragma unroll
+    for (int q = 0; q < kBins / kSortWaves; ++q) {
+        const int d = wave * (kBins / kSortWaves) + q;
+        uint32_t pre = 0;
+        for (uint32_t l0 = 0; l0 < j; l0 += 64)
+            pre += l0 + (uint32_t)lane < j ? table[d * G + seg * K + l0 + lane] : 0u;
+        sa.pre[q] = pre;
+        sa.base[q] = seg_base[d * kSegments + seg];
+    }
+}
+
 // GS_SCATTER_ABLATE: timing-only builds (tools/build_variants.sh), never shipped.  bit 0: stores go to
 // the tile's own range (no scatter pattern); bit 1: no global stores; bit 2: no ranking.
 // Measured at E = 13.1 M (MI355X): full 71.7 us; identity stores 55.4; no stores 44.5; no ranking +
@@ -270,6 +290,8 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
     ScatterKeys nxt;
     scatter_load<LO_IN, HI16>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, nxt);
 #endif
+    ScanAddRegs sa_nxt;
+    scan_add_load(table, seg_base, grp, G, K, wave, lane, sa_nxt);
 
     for (; grp < G; grp += gridDim.x) {
 #if GS_SCATTER_PREFETCH
@@ -280,24 +302,20 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
         ScatterKeys k;
         scatter_load<LO_IN, HI16>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, k);
 #endif
+        const ScanAddRegs sa = sa_nxt;
+        if (grp + gridDim.x < G) scan_add_load(table, seg_base, grp + gridDim.x, G, K, wave, lane, sa_nxt);
         const uint32_t tile_base = grp * kSortTile;
         const uint32_t base = tile_base + wave_off;
 
         // ---- ScanAdd: keys of digit d in all groups before this one = scanned segment base +
-        //      counts of the earlier groups of the same segment (wave w: digits 4w..4w+3)
-        {
-            const uint32_t seg = grp / K, j = grp - seg * K;   // j < K (K <= 64 up to 134 M elements)
+        //      counts of the earlier groups of the same segment (wave w: digits 4w..4w+3).  The table
+        //      reads were issued one group ahead (scan_add_load), only the wave sums happen here.
 #pragma unroll
-            for (int q = 0; q < kBins / kSortWaves; ++q) {
-                const int d = wave * (kBins / kSortWaves) + q;
-                uint32_t pre = 0;
-                for (uint32_t l0 = 0; l0 < j; l0 += 64)
-                    pre += l0 + (uint32_t)lane < j ? table[d * G + seg * K + l0 + lane] : 0u;
-                pre = wave_sum_to_lane63(pre);
-                if (lane == 63) s_gpre[d] = pre + seg_base[d * kSegments + seg];
-            }
+        for (int q = 0; q < kBins / kSortWaves; ++q) {
+            const int d = wave * (kBins / kSortWaves) + q;
+            const uint32_t pre = wave_sum_to_lane63(sa.pre[q]);
+            if (lane == 63) s_gpre[d] = pre + sa.base[q];
         }
-
         // ---- stable rank inside the wave.  Per round: 4 ballots give every lane the mask of lanes
         //      holding the same digit; lane d (d < 16) keeps the wave's running count of digit d.
         uint32_t rank[kSortKeysPerThread];
@@ -405,7 +423,6 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
                       hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit, uint32_t tile_bias,
                       bool drop_depth_payload, bool hi16) {
     const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
-    const uint32_t sgrid = max_groups < (uint32_t)GS_SCATTER_GRID ? max_groups : (uint32_t)GS_SCATTER_GRID;
     if (hi16) tile_bias = 0;   // 16-bit tile words are stored relative to the band already
     int src = 0;
     uint32_t pass = 0;
@@ -432,8 +449,9 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
         // bytes of the depth word read / written by this pass (see k_scatter)
         int lo_in, lo_out;
         scatter_depth_bytes(shift, first_bit, drop_depth_payload, &lo_in, &lo_out);
+        const uint32_t pgrid = max_groups < (uint32_t)GS_SCATTER_GRID ? max_groups : (uint32_t)GS_SCATTER_GRID;
 #define GS_LAUNCH_SCATTER(LO_IN, LO_OUT, HI16)                                                                       \
-        hipLaunchKernelGGL((k_scatter<LO_IN, LO_OUT, HI16>), dim3(sgrid), dim3(kSortThreads), 0, stream, sb.params, \
+        hipLaunchKernelGGL((k_scatter<LO_IN, LO_OUT, HI16>), dim3(pgrid), dim3(kSortThreads), 0, stream, sb.params, \
                            sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],                  \
                            sb.table, sb.seg_sum, shift, tile_bias)
 #define GS_LAUNCH_SCATTER_H(LO_IN, LO_OUT) \
