@@ -675,3 +675,28 @@ def test_shared_scene_frames_in_flight(oracle_mod, small_cloud):
     for r in reversed(slots):
         r.setStream(None)
         r.cleanup()
+
+
+def test_grid_beyond_16_bit_tile_ids(oracle_mod):
+    """More than 65535 tiles: tile ids no longer fit the 16-bit sort-list words, so the frame falls back to 32-bit
+    tile words (gs_scene_info.tile_word_bytes == 4); a half-frame band of the same grid fits again (== 2).  Keys,
+    ranges and pixels equal the oracle's in both layouts."""
+    w, h = 4096, 4112                                          # 256 x 257 = 65792 tiles
+    aos = synth.generate(600, w, h, -3.5, seed=5)
+    sc = make_scene(aos, w, h)
+    r = make_renderer(sc, w, h)
+    assert r.sceneInfo().tile_word_bytes == 4
+    img = r.draw(sc)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    assert ref["e"] > 30000
+    assert_frame_equals_oracle(r, img, ref)
+    r.setTileRows(100, 200)
+    assert r.sceneInfo().tile_word_bytes == 2
+    band_img = r.draw(sc)
+    _, band = oracle_run(oracle_mod, sc, w, h, row_begin=100, row_end=200)
+    e = band["e"]
+    assert np.array_equal(r.debugRead(gs.BUF_SORTED_TILE), band["tile"][:e])
+    assert np.array_equal(r.debugRead(gs.BUF_SORTED_DEPTH), band["depth"][:e])
+    assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), band["id"][:e])
+    assert np.array_equal(band_img[1600:3200], band["image"][1600:3200])
+    r.cleanup()
