@@ -13,7 +13,10 @@ for name in (sys.argv[1:] or ["C"]):
     sc = gs.Scene(rm, aspect_ratio=w / h); cam = sc.getCamera(); cam.setPosition((0, 0, 0)); cam.setRotation(0, 0); cam.recalculate()
     def make():
         r = gs.Renderer(w, h, record_timings=0, warmup_frames=0); r.init(rm); r.initForScene(sc); return r
-    rs = [make() for _ in range(3)]
+    def make_shared(owner):
+        r = gs.Renderer(w, h, record_timings=0, warmup_frames=0); r.init(rm); r.initForScene(sc, share_with=owner); return r
+    nslots = int(os.environ.get("SLOTS", "3"))
+    rs = [make()] ; rs += [make_shared(rs[0]) for _ in range(nslots - 1)]
     def run(k, n):
         for i in range(20): rs[i % k].drawDevice(sc, None, sync=False)
         for r in rs: r.synchronize()
@@ -25,6 +28,6 @@ for name in (sys.argv[1:] or ["C"]):
     for R in (1, 2, 4, 8):
         b, e = dist.tile_row_partition(ty, R)[R // 2]
         for r in rs: r.setTileRows(b, e)
-        res = [min(run(k, 300) for _ in range(2)) for k in (1, 2, 3)]
-        print(f"config {name} R={R} rows [{b},{e}): 1 / 2 / 3 frames in flight: " + " / ".join(f"{x:.4f}" for x in res) + " ms per frame", flush=True)
-    for r in rs: r.cleanup()
+        res = [min(run(k, 300) for _ in range(2)) for k in range(1, nslots + 1)]
+        print(f"config {name} R={R} rows [{b},{e}): 1..{nslots} frames in flight: " + " / ".join(f"{x:.4f}" for x in res) + " ms per frame", flush=True)
+    for r in reversed(rs): r.cleanup()
