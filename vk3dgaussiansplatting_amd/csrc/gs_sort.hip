@@ -35,7 +35,9 @@ constexpr int kSortWaves = kSortThreads / 64;
 // Count + Reduce
 // ---------------------------------------------------------------------------------------------
 #ifndef GS_SCATTER_GRID
-#define GS_SCATTER_GRID 1024    // persistent workgroups of k_scatter (4 per CU: 24.6 KB LDS each)
+#define GS_SCATTER_GRID 1048576 // cap on k_scatter's grid: above it workgroups walk several groups.  One workgroup per
+                                // group (no cap in practice) measured faster than 1024 persistent ones once the
+                                // payload shrank: 39.8 / 45.4 / 52.3 us against 45.3 / 50.9 / 58.7 for the 12 / 16 / 20-byte passes
 #endif
 
 // Count + Reduce.  Persistent workgroups walk the groups (tiles) with a stride of gridDim and
@@ -250,10 +252,11 @@ __device__ __forceinline__ void scan_add_load(const uint32_t* __restrict__ table
 #define GS_SCATTER_ABLATE 0
 #endif
 #ifndef GS_SCATTER_PREFETCH
-#define GS_SCATTER_PREFETCH 1   // keep the next group's keys in registers while working on the current one
+#define GS_SCATTER_PREFETCH 0   // 1: keep the next group's keys in registers while working on the current one (only
+                                // useful with a persistent grid, see GS_SCATTER_GRID)
 #endif
 #ifndef GS_SCATTER_MINWAVES
-#define GS_SCATTER_MINWAVES 4
+#define GS_SCATTER_MINWAVES 5
 #endif
 // LO_IN / LO_OUT = bytes of the depth word read / written per element (4, 2 or 0).  The stand-alone sorter
 // (gs_sort_host) and GS_SORT_TILE_BUCKET use <4, 4>: everything moves.  In a frame the depth word is needed only as a
