@@ -700,3 +700,28 @@ def test_grid_beyond_16_bit_tile_ids(oracle_mod):
     assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), band["id"][:e])
     assert np.array_equal(band_img[1600:3200], band["image"][1600:3200])
     r.cleanup()
+
+
+@pytest.mark.parametrize("sort", [gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET])
+def test_camera_sequence_has_no_frame_to_frame_state(oracle_mod, small_cloud, sort):
+    """Poses A, B, C, A, B through ONE context (graph replay of the radix passes, reused 16-bit / shrunken sort-list
+    buffers, raster records of earlier frames still in memory): every frame equals the oracle's frame of its pose,
+    also when the tile-row band changes in between."""
+    w, h = 320, 180
+    poses = [((0.0, 0.0, 0.0), 0.0, 0.0), ((0.4, -0.2, -1.0), 0.25, -0.1), ((-0.6, 0.1, 0.5), -0.3, 0.15)]
+    scenes = [make_scene(small_cloud, w, h, pos=p, yaw=y, pitch=pt) for p, y, pt in poses]
+    refs = [oracle_run(oracle_mod, sc, w, h)[1] for sc in scenes]
+    assert len({int(r["e"]) for r in refs}) == 3
+    r = make_renderer(scenes[0], w, h, sort=sort)
+    for k in (0, 1, 2, 0, 1):
+        img = r.draw(scenes[k])
+        assert_frame_equals_oracle(r, img, refs[k])
+    r.setTileRows(2, 9)
+    _, band = oracle_run(oracle_mod, scenes[2], w, h, row_begin=2, row_end=9)
+    img = r.draw(scenes[2])
+    assert np.array_equal(img[32:144], band["image"][32:144])
+    assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), band["id"][:band["e"]])
+    r.setTileRows(0, r.sceneInfo().tiles_y)
+    img = r.draw(scenes[1])
+    assert_frame_equals_oracle(r, img, refs[1])
+    r.cleanup()
