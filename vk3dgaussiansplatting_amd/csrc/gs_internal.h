@@ -27,7 +27,7 @@ constexpr int kSortThreads = GS_SORT_THREADS;
 #define GS_SORT_KPT 8
 #endif
 constexpr int kSortKeysPerThread = GS_SORT_KPT;
-constexpr bool kHi16Supported = GS_SORT_KPT == 8;   // the 16-bit tile-word Count path loads 8 keys as one uint4
+constexpr bool kHi16Supported = GS_SORT_KPT % 8 == 0;   // the 16-bit Count path loads 8 keys per 16-byte access
 constexpr int kSortTile = kSortThreads * kSortKeysPerThread; // 2048 keys
 #ifndef GS_SEGMENTS
 #define GS_SEGMENTS 1024

@@ -55,19 +55,25 @@ __device__ __forceinline__ void count_load(const uint32_t* __restrict__ word, ui
                                            int tid, uint4 (&v)[kCountVec]) {
     const uint32_t tile_base = grp * kSortTile;
     if constexpr (HI16) {
-        static_assert(kSortKeysPerThread == 8, "HI16 count path: 8 keys = one uint4 per thread");
+        static_assert(kSortKeysPerThread % 8 == 0, "16-bit count path: 8 keys per 16-byte load");
+        constexpr int V16 = kSortKeysPerThread / 8;   // 16-byte loads per thread, kept in v[0..V16)
         const uint16_t* h = reinterpret_cast<const uint16_t*>(word);
         if (tile_base + kSortTile <= e) {
-            v[0] = reinterpret_cast<const uint4*>(h + tile_base)[tid];
-        } else {
-            uint32_t w[4];
+            const uint4* w4 = reinterpret_cast<const uint4*>(h + tile_base);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t i0 = tile_base + (uint32_t)tid * 8u + (uint32_t)q * 2u;
-                const uint32_t a = i0 < e ? h[i0] : 0u, b = i0 + 1 < e ? h[i0 + 1] : 0u;
-                w[q] = a | (b << 16);
+            for (int r = 0; r < V16; ++r) v[r] = w4[r * kSortThreads + tid];
+        } else {
+#pragma unroll
+            for (int r = 0; r < V16; ++r) {
+                uint32_t w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t i0 = tile_base + (uint32_t)(r * kSortThreads + tid) * 8u + (uint32_t)q * 2u;
+                    const uint32_t a = i0 < e ? h[i0] : 0u, b = i0 + 1 < e ? h[i0 + 1] : 0u;
+                    w[q] = a | (b << 16);
+                }
+                v[r] = make_uint4(w[0], w[1], w[2], w[3]);
             }
-            v[0] = make_uint4(w[0], w[1], w[2], w[3]);
         }
         return;
     }
@@ -116,15 +122,18 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
 #pragma unroll
             for (int r = 0; r < kCountVec; ++r) c0 += v[r].x ^ v[r].y ^ v[r].z ^ v[r].w;
         } else if constexpr (HI16) {
-            const uint32_t k[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const uint32_t key = (k[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
-                const uint32_t d = digit_of(key - bias, sh);
-                const bool ok = full || tile_base + (uint32_t)tid * 8u + (uint32_t)q < e;
-                const uint64_t inc = ok ? 1ull << ((d & 7u) * 8u) : 0ull;
-                c0 += (d & 8u) ? 0ull : inc;
-                c1 += (d & 8u) ? inc : 0ull;
+            for (int r = 0; r < kSortKeysPerThread / 8; ++r) {
+                const uint32_t k[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t key = (k[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                    const uint32_t d = digit_of(key - bias, sh);
+                    const bool ok = full || tile_base + (uint32_t)(r * kSortThreads + tid) * 8u + (uint32_t)q < e;
+                    const uint64_t inc = ok ? 1ull << ((d & 7u) * 8u) : 0ull;
+                    c0 += (d & 8u) ? 0ull : inc;
+                    c1 += (d & 8u) ? inc : 0ull;
+                }
             }
         } else
 #pragma unroll
