@@ -117,10 +117,13 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
         if (grp + 1 < grp_end) count_load<HI16>(word, grp + 1, e, tid, nxt);   // prefetch
         const uint32_t tile_base = grp * kSortTile;
         const bool full = tile_base + kSortTile <= e;
-        uint64_t c0 = 0, c1 = 0;   // digits 0-7 / 8-15, one byte each
+        // per-lane counters: one 4-bit field per digit in a single 64-bit register (a lane sees at most
+        // kSortKeysPerThread <= 15 keys of a group), so a key costs one shift and one 64-bit add
+        static_assert(kSortKeysPerThread <= 15, "4-bit per-lane digit counters");
+        uint64_t c = 0;
         if (ABLATE & 4) {
 #pragma unroll
-            for (int r = 0; r < kCountVec; ++r) c0 += v[r].x ^ v[r].y ^ v[r].z ^ v[r].w;
+            for (int r = 0; r < kCountVec; ++r) c += v[r].x ^ v[r].y ^ v[r].z ^ v[r].w;
         } else if constexpr (HI16) {
 #pragma unroll
             for (int r = 0; r < kSortKeysPerThread / 8; ++r) {
@@ -130,9 +133,7 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
                     const uint32_t key = (k[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
                     const uint32_t d = digit_of(key - bias, sh);
                     const bool ok = full || tile_base + (uint32_t)(r * kSortThreads + tid) * 8u + (uint32_t)q < e;
-                    const uint64_t inc = ok ? 1ull << ((d & 7u) * 8u) : 0ull;
-                    c0 += (d & 8u) ? 0ull : inc;
-                    c1 += (d & 8u) ? inc : 0ull;
+                    c += (uint64_t)(ok ? 1u : 0u) << (d * 4u);
                 }
             }
         } else
@@ -143,15 +144,13 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
             for (int q = 0; q < 4; ++q) {
                 const uint32_t d = digit_of(k[q] - bias, sh);
                 const bool ok = full || tile_base + (uint32_t)(r * kSortThreads + tid) * 4u + q < e;
-                const uint64_t inc = ok ? 1ull << ((d & 7u) * 8u) : 0ull;
-                c0 += (d & 8u) ? 0ull : inc;
-                c1 += (d & 8u) ? inc : 0ull;
+                c += (uint64_t)(ok ? 1u : 0u) << (d * 4u);
             }
         }
-        // widen to 16-bit fields (a wave total is at most 64 * kSortKeysPerThread < 65536):
-        // word 0/1 = digits {0,2} / {4,6}, word 2/3 = {1,3} / {5,7}, words 4..7 the same for digits 8..15
-        const uint64_t m = 0x00FF00FF00FF00FFull;
-        const uint64_t a[4] = {c0 & m, (c0 >> 8) & m, c1 & m, (c1 >> 8) & m};
+        // widen to 16-bit fields (a wave total is at most 64 * kSortKeysPerThread < 65536): a[j] holds digits
+        // j, j+4, j+8, j+12 in its four 16-bit fields
+        const uint64_t m = 0x000F000F000F000Full;
+        const uint64_t a[4] = {c & m, (c >> 4) & m, (c >> 8) & m, (c >> 12) & m};
         uint32_t w[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -164,9 +163,9 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
         }
         __syncthreads();   // s_pack is double-buffered, so one barrier per group is enough
         if (tid < kBins) {
-            // digit d sits in u64 a[(d >> 3) * 2 + (d & 1)], 16-bit field (d & 7) >> 1
-            const int word = ((tid >> 3) * 2 + (tid & 1)) * 2 + (((tid & 7) >> 1) >> 1);
-            const int half = ((tid & 7) >> 1) & 1;
+            // digit d sits in u64 a[d & 3], 16-bit field d >> 2
+            const int word = (tid & 3) * 2 + (tid >> 3);
+            const int half = (tid >> 2) & 1;
             uint32_t t = 0;
 #pragma unroll
             for (int k = 0; k < kSortWaves; ++k) t += (s_pack[it][k][word] >> (16 * half)) & 0xFFFFu;
