@@ -89,7 +89,7 @@ void free_scene(gs_ctx* c) {
         c->scene = SceneBuffers{};
     }
     free_dev(c->scene.pos); free_dev(c->scene.scale); free_dev(c->scene.rot);
-    free_dev(c->scene.sh); free_dev(c->scene.opacity);
+    free_dev(c->scene.sh); free_dev(c->scene.opacity); free_dev(c->scene.sig2);
     free_dev(c->scratch.raster); free_dev(c->scratch.depth_key); free_dev(c->scratch.tiles_touched);
     free_dev(c->scratch.extents); free_dev(c->scratch.block_sums); free_dev(c->scratch.block_offsets);
     c->n = 0;
@@ -161,6 +161,9 @@ FrameParams make_frame_params(const gs_ctx* c, const float* view, const float* p
     fp.tan_fov_y = (float)std::tan((double)(c->cfg.fov_y * 0.5f));   // Common.glsl:53, host-folded
     fp.hi16 = c->hi16 ? 1u : 0u;
     fp.tile_bias = c->band_tile_bias;
+    fp.w_frob2 = 0.0f;
+    for (int col = 0; col < 3; ++col)
+        for (int row = 0; row < 3; ++row) fp.w_frob2 += view[col * 4 + row] * view[col * 4 + row];
     return fp;
 }
 
@@ -457,6 +460,7 @@ int gs_upload_gaussians(gs_ctx* c, const void* aos336, uint32_t n) {
     HIP_TRY(c, hipMalloc((void**)&c->scene.rot, 4 * N * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->scene.sh, 48 * N * sizeof(float)));
     HIP_TRY(c, hipMalloc((void**)&c->scene.opacity, N * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void**)&c->scene.sig2, N * sizeof(float)));
     if (int r = alloc_scratch(c, n)) { free_scene(c); return r; }
 
     // AoS -> SoA on the device, through a bounded staging buffer

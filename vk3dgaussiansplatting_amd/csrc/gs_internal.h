@@ -54,6 +54,7 @@ struct FrameParams {
     float tan_fov_y;      // tan(FOV_Y*0.5f), folded on the host (Common.glsl:53)
     uint32_t hi16;        // sort list stores tile ids as uint16 relative to tile_bias (band of <= 65535 tiles)
     uint32_t tile_bias;   // first tile of the band = row_begin * grid_w
+    float w_frob2;        // squared Frobenius norm of the upper-left 3x3 of view (host-folded, for the band bound)
 };
 
 // Device-side dispatch record: the role of RadixIndirectDispatch (ShaderStructs.h:45-57) +
@@ -86,6 +87,8 @@ struct SceneBuffers {
     float* rot;      // [4][N]
     float* sh;       // [48][N], plane index = coeff*3 + channel
     float* opacity;  // [N]   shCoeffs[0].w
+    float* sig2;     // [N]   upper bound of the largest eigenvalue of the 3-D covariance: |R|_F^2 * max(scale)^2,
+                     //       computed at upload; lets a tile-row band skip far-away splats early (k_project)
 };
 
 // Per-splat scratch of one frame.

@@ -185,7 +185,27 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
                 float nd = (-vp[2] - fp.near_plane) / (fp.far_plane - fp.near_plane);
                 nd = clampf(nd, 0.0f, 1.0f);
                 const uint32_t depth_key = f2u_sat(nd * 4294967296.0f);
+                bool band_skip = false;
 
+                // A context that owns a tile-row band can often tell from the position alone that a splat cannot
+                // reach the band: radius = ceil(3 sqrt(lambda_max(Sigma'))) and lambda_max(Sigma') <=
+                // |J|_F^2 |W|_F^2 lambda_max(Sigma) + 0.3, with lambda_max(Sigma) <= sig2 from the upload and J, W as in
+                // getCovarianceMatrix (Common.glsl:49-69).  Widened by 2 % + 2 px and two whole tile rows; a NaN or
+                // infinity anywhere makes the comparison false, i.e. the splat takes the normal path.
+                if (fp.row_begin != 0u || fp.row_end != fp.grid_h) {
+                    const float wdt = (float)fp.width, hgt = (float)fp.height;
+                    const float tfx = fp.tan_fov_y * wdt / hgt;
+                    const float fx = wdt / (2.0f * tfx), fy = hgt / (2.0f * fp.tan_fov_y);
+                    const float tx = clampf(vp[0] / vp[2], -tfx * fp.in_view_limit, tfx * fp.in_view_limit);
+                    const float ty = clampf(vp[1] / vp[2], -fp.tan_fov_y * fp.in_view_limit, fp.tan_fov_y * fp.in_view_limit);
+                    const float j2 = (fx * fx * (1.0f + tx * tx) + fy * fy * (1.0f + ty * ty)) / (vp[2] * vp[2]);
+                    const float lam = j2 * fp.w_frob2 * scene.sig2[g] * 1.02f + 0.31f;
+                    const float rmax = 3.0f * sqrtf(lam) + 2.0f;
+                    const float sy_b = (1.0f - ndc_y) * 0.5f * hgt;          // screen y as below, to a rounding
+                    const float band_top = 16.0f * (float)fp.row_begin - 32.0f, band_bot = 16.0f * (float)fp.row_end + 32.0f;
+                    if (sy_b + rmax < band_top || sy_b - rmax > band_bot) band_skip = true;
+                }
+                if (!band_skip) {
                 float scale[3], rot[4], cov[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) scale[a] = scene.scale[a * (size_t)n + g];
@@ -264,6 +284,7 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
                     sc.extents[g] = make_uint2((uint32_t)min_x | ((uint32_t)y0 << 16),
                                                (uint32_t)max_x | ((uint32_t)y1 << 16));
                 }
+                }   // !band_skip
             }
         }
         sc.tiles_touched[g] = count;

@@ -29,6 +29,20 @@ __global__ __launch_bounds__(256) void k_aos_to_soa(const float* __restrict__ ch
                 s.sh[(size_t)k * n + g] = tile[r][12 + coeff * 4u + ch];
             } else s.opacity[g] = tile[r][12 + 3];
         }
+        if (part == 3u) {
+            // |R|_F^2 * max(scale)^2 >= largest eigenvalue of Sigma = (R S)(R S)^T, with R as Common.glsl:17-30
+            // builds it from the (not necessarily unit) quaternion
+            const float q0 = tile[r][8], x = tile[r][9], y = tile[r][10], z = tile[r][11];
+            const float e[9] = {1.0f - 2.0f * y * y - 2.0f * z * z, 2.0f * x * y - 2.0f * q0 * z, 2.0f * x * z + 2.0f * q0 * y,
+                                2.0f * x * y + 2.0f * q0 * z, 1.0f - 2.0f * x * x - 2.0f * z * z, 2.0f * y * z - 2.0f * q0 * x,
+                                2.0f * x * z - 2.0f * q0 * y, 2.0f * y * z + 2.0f * q0 * x, 1.0f - 2.0f * x * x - 2.0f * y * y};
+            float f2 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) f2 += e[k] * e[k];
+            const float s0 = fabsf(tile[r][4]), s1 = fabsf(tile[r][5]), s2 = fabsf(tile[r][6]);
+            const float sm = fmaxf(s0, fmaxf(s1, s2));
+            s.sig2[g] = f2 * sm * sm;
+        }
     }
 }
 
