@@ -16,9 +16,9 @@ constexpr int kBins = 1 << kRadixBits; // RS_BIN_COUNT
 // One workgroup (256 threads = 4 waves) owns kSortTile consecutive keys of the current pass.
 // The reference uses 64 keys per group (RS_WORK_GROUP_SIZE, RadixSort.h:38); a 2048-key tile
 // shrinks the histogram table 32x and makes every global access of a pass a >= 256-byte run.
-// 8 keys/thread with 4 workgroups/CU (24.6 KB LDS, <= 128 VGPRs, grid 1024) and 12 keys/thread with
-// 3/CU (grid 768) are within 3 % of each other on MI355X; 8 keys wins in whole frames at every
-// README shape (config C sort 1.078 vs 1.107 ms, D 2.68 vs 2.83 ms); 16 keys/thread is 20 % slower.
+// 8 keys per thread (24.6 KB LDS, 88-95 VGPRs, five Scatter workgroups per CU) is the measured optimum on MI355X:
+// 12 keys per thread was within 3 % while every pass still moved 24 bytes per element and loses the 16-bit word
+// paths (they load 8 keys per 16-byte access); 16 keys per thread is 10-20 % slower.
 #ifndef GS_SORT_THREADS
 #define GS_SORT_THREADS 256
 #endif

@@ -17,8 +17,10 @@
 //                       (RadixSortScanAdd.comp:34-66);
 //              Scatter: wave64 match-mask ranking (stable), LDS-staged local sort, run-wise
 //                       coalesced stores (RadixSortScatter.comp:58-171).
-// Count and Scatter are persistent (a few workgroups per CU walk the groups and prefetch the next
-// group's keys while working on the current one).
+// Count is persistent (1024 workgroups, each walking the groups of its segment and prefetching the next group's
+// keys); Scatter launches one workgroup per group (five resident per CU).  Inside a frame the words are narrower
+// than the reference's: 16-bit band-relative tile ids when they fit, and depth words that shrink as their digits are
+// consumed (see k_scatter); the stand-alone sorter (gs_sort_host) always moves three 32-bit words.
 // Output is bit-identical to a stable sort by the low num_sort_bits of the key.
 // Launch grids are fixed; the device-side element count (SortParams, the IndirectSetup record)
 // bounds every loop -- no host read-back inside a frame.
