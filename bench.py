@@ -1,125 +1,211 @@
 #!/usr/bin/env python3
-"""bench.py -- whole-frame throughput of the splat hot path on MI355X.
+"""bench.py -- the splat hot path on MI355X, measured the way the reference measures itself.
 
-A "step" is one frame (InitSortList -> 4-bit radix sort -> FindRanges -> RenderGaussians) of a
-synthetic gaussian cloud at a reference README shape, inputs resident in HBM, image left in HBM
-(the reference writes into the swapchain image; it never copies a frame to the host).
+A "step" is one frame (InitSortList -> 4-bit radix sort -> FindRanges -> RenderGaussians) of a synthetic gaussian
+cloud at a reference README shape, inputs resident in HBM, image left in HBM (the reference writes into the swapchain
+image; it never copies a frame to the host).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C|B|A|D] [--mode exact|fast]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config A|B|C|D|E] [--mode exact|fast]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; the frame is sharded by screen-tile
-rows and the RGBA8 strips are gathered to rank 0 over RCCL each step (strong scaling: the frame
-is fixed).  Rank 0 prints ONE JSON line.
+What `value` is: N_gaussians / ms_per_step with ONE frame slot -- frames run back to back on one HIP stream, nothing
+of frame f+1 overlaps frame f -- i.e. the GPU time of a frame, which is what the reference's "Total GPU time"
+(Renderer.cpp:458-497, README.md:58-67) is.  Throughput with three frames in flight (GfxSettings::FRAMES_IN_FLIGHT)
+and the wall clock of a frame with a host wait per frame (Renderer.cpp:459) are reported beside it, labelled.
+
+--gpus N > 1: this script starts its own N ranks (python -m torch.distributed.run, one process per GPU, RCCL) unless it
+already runs inside such a launch (WORLD_SIZE set); the frame is sharded by screen-tile rows and the RGBA8 strips are
+gathered to rank 0 every step (strong scaling: the frame is fixed).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-
-HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable by a float4 copy)
-REF_MSPLATS = {"C": 5_834_784 / 28.499 / 1000.0, "B": 559_263 / 8.581 / 1000.0}   # BASELINE.md (RTX 3080 Ti, real .ply)
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_GUIDE_COPY_GBPS = 6290.0  # MI355X_MICROARCH.md:36, float4 copy measured on MI355X
+REF_MS = {"C": (5_834_784, 28.499), "B": (559_263, 8.581)}   # RTX 3080 Ti, real .ply of this shape
+WORKLOADS = {"A": "synthetic 100k @ 640x360", "B": "Train-7k shape: 559,263 gaussians @ 1280x720",
+             "C": "Garden-30k shape: 5,834,784 gaussians @ 1920x1080",
+             "D": "Garden-30k shape: 5,834,784 gaussians @ 3840x2160",
+             "E": "stress: 50,000,000 synthetic gaussians @ 1920x1080",
+             "Chard": "Garden-30k shape, clustered / anisotropic / opaque cloud: 5,834,784 gaussians @ 1920x1080"}
+PMC_SCATTER_FILE = os.path.join(ROOT, "profiles", "r02_pmc_scatter.json")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(aos, cfg, budget_s=20.0):
-    """The oracle (a scalar C port of the same four stages) timed on this box's host cores, on a
-    bounded sample of the SAME workload: every k-th gaussian of the cloud, same camera/resolution."""
-    import oracle
-    n_sample = min(aos.shape[0], 200_000)
-    stride = max(1, aos.shape[0] // n_sample)
-    sub = np.ascontiguousarray(aos[::stride][:n_sample])
-    w, h = cfg["width"], cfg["height"]
-    view, proj = oracle.camera_matrices(np.zeros(3, np.float32), 0.0, 0.0, w / h)
-    p = oracle.make_params(w, h, view, proj, (0, 0, 0))
-    times, t_start = [], time.time()
-    while len(times) < 5 and (time.time() - t_start < budget_s or not times):
-        _, e, t = oracle.frame(p, sub)
-        times.append(float(t[4]))
-    ms = float(np.median(times))
-    out = {"value": round(sub.shape[0] / ms / 1000.0, 4), "unit": "Msplats/s", "cores": 1, "kind": "port",
-           "ms_per_frame": round(ms, 2), "host_cpus": os.cpu_count(),
-           "sample": f"every {stride}th gaussian of the workload cloud ({sub.shape[0]} splats, E={e}) at "
-                     f"{w}x{h}, same camera, {len(times)} frames, median, single thread (oracle/gs_oracle.c -O2)"}
-    # additionally the same port on the box's CPU share for one GPU (16 threads), on a 4x larger
-    # sample; reported beside the single-thread figure, which stays the `value`
-    threads = max(1, min(16, os.cpu_count() or 1))
-    n_mt = min(aos.shape[0], 800_000)
-    stride_mt = max(1, aos.shape[0] // n_mt)
-    sub_mt = np.ascontiguousarray(aos[::stride_mt][:n_mt])
-    times_mt, t_start = [], time.time()
-    while len(times_mt) < 3 and (time.time() - t_start < budget_s / 2 or not times_mt):
-        _, e_mt, t = oracle.frame_mt(p, sub_mt, threads)
-        times_mt.append(float(t[4]))
-    ms_mt = float(np.median(times_mt))
-    out["all_cores"] = {"value": round(sub_mt.shape[0] / ms_mt / 1000.0, 4), "unit": "Msplats/s", "cores": threads,
-                        "ms_per_frame": round(ms_mt, 2),
-                        "sample": f"every {stride_mt}th gaussian ({sub_mt.shape[0]} splats, E={e_mt}), {len(times_mt)} "
-                                  f"frames, median, gso_frame_mt on {threads} threads"}
-    return out
-
-
-def main():
-    # stdout carries exactly ONE JSON line: anything a library prints there meanwhile (gloo/RCCL banners)
-    # is sent to stderr by pointing fd 1 at fd 2 until the result is ready
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--config", default="C", choices=["A", "B", "C", "D", "E"])
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--config", default=None, choices=sorted(WORKLOADS),
+                    help="default: C (the headline shape) on one GPU, D (the 4K frame BASELINE.json names for the "
+                         "tile-row shard) on several")
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
     ap.add_argument("--sort", default="radix4", choices=["radix4", "bucket"],
                     help="radix4 = the contractual nine-stage sort (default); bucket = GS_SORT_TILE_BUCKET")
     ap.add_argument("--render-kernel", default="auto", choices=["auto", "1", "2", "4", "16"],
                     help="gs_config.render_kernel: auto, 1/2/4 = px per lane with independent waves, 16 = workgroup per tile")
-    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3],
-                    help="frame slots used round-robin in the timed region, each with its own stream and per-frame "
-                         "buffers over one shared copy of the scene (the reference: GfxSettings::FRAMES_IN_FLIGHT = 3)")
+    ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2, 3],
+                    help="frame slots of the TIMED region (default 1 = a frame's GPU time, like the reference's "
+                         "timestamps); the 3-slot throughput is always reported as an extra field")
+    ap.add_argument("--rows", default="contiguous", choices=["contiguous", "interleaved"],
+                    help="N > 1: how tile rows are dealt to ranks (interleaved = row r to rank r mod N, for scenes "
+                         "whose splat density varies over the height of the frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra pass with the other sort back-end")
+    ap.add_argument("--no-extras", action="store_true", help="skip the alternative sorter / frames-in-flight extras")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: the ranks run only the launcher / process-group / strip-gather plumbing on the CPU "
+                         "(gloo) with a fill pattern in place of the band render and print the JSON skeleton "
+                         "(tests/test_bench_launcher.py)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: every rank uses cuda:0 and the strip gather goes "
                          "through gloo on the host (RCCL needs one GPU per rank)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def launch_ranks(args):
+    """--gpus N outside a torch.distributed launch: start the N ranks ourselves.  This parent never imports torch or
+    touches HIP; the ranks are fresh child processes (never an exec of a process that has initialised the GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """The N-rank plumbing without a GPU: process group (gloo), ShardedFrame strips, gather, assembly -- every rank
+    fills its strip with a value that names (step, rank) and rank 0 checks each assembled frame."""
+    import torch
+    from vk3dgaussiansplatting_amd import dist as gsdist
+    tdist = None
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.init_process_group(backend="gloo")
+        assert tdist.get_world_size() == world
+    w, h = 256, 208                                   # 13 tile rows: ragged for 2, 3, 4 ranks
+    inter = args.rows == "interleaved" and world > 1
+    sf = gsdist.ShardedFrame(w, h, rank, world, device="cpu", n_strips=2, interleaved=inter)
+    ok = True
+    steps = max(1, min(args.steps, 6))
+    t0 = time.perf_counter()
+    for f in range(steps):
+        k = f % 2
+        sf.wait(k)
+        sf.strips[k].fill_((7 * f + rank) % 251)
+        strips = sf.gather(k)
+        if rank == 0:
+            img = sf.assemble(strips)
+            for r in range(world):
+                rows = gsdist.interleaved_rows(sf.tiles_y, r, world) if inter else range(*sf.bands[r])
+                for row in rows:
+                    ok = ok and bool((img[row * 16:min(row * 16 + 16, h)] == (7 * f + r) % 251).all())
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tdist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
+                          "rows": args.rows, "assembled_frames_ok": ok,
+                          "gloo_ranks": tdist.get_world_size() if world > 1 else 1}), flush=True)
+    if world > 1:
+        tdist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def cpu_baseline(aos, cfg, oracle):
+    """The oracle (a scalar C port of the same four stages, oracle/gs_oracle.c -O2) timed on this box's host cores on
+    the WHOLE workload: one frame on one thread (`value`), and the threaded port (gso_frame_mt) on the CPUs this
+    process may use.  Bounded: clouds beyond 8 M gaussians are sampled (every k-th gaussian, same camera/resolution)."""
+    import numpy as np
+    n = aos.shape[0]
+    stride = max(1, -(-n // 8_000_000))
+    sub = aos if stride == 1 else np.ascontiguousarray(aos[::stride])
+    what = "the whole workload cloud" if stride == 1 else f"every {stride}th gaussian of the workload cloud"
+    w, h = cfg["width"], cfg["height"]
+    view, proj = oracle.camera_matrices(np.zeros(3, np.float32), 0.0, 0.0, w / h)
+    p = oracle.make_params(w, h, view, proj, (0, 0, 0))
+    _, e, t = oracle.frame(p, sub)
+    ms = float(t[4])
+    out = {"value": round(sub.shape[0] / ms / 1000.0, 4), "unit": "Msplats/s", "cores": 1, "kind": "port",
+           "ms_per_frame": round(ms, 1), "buckets_ms": [round(float(x), 1) for x in t[:4]],
+           "host_cpus": os.cpu_count(),
+           "sample": f"{what} ({sub.shape[0]} splats, E={e}) at {w}x{h}, same camera, 1 frame, single thread"}
+    threads = oracle.host_threads()
+    times = []
+    for _ in range(3):
+        _, e_mt, t = oracle.frame_mt(p, sub, threads)
+        times.append(float(t[4]))
+    ms_mt = float(np.median(times))
+    out["all_cores"] = {"value": round(sub.shape[0] / ms_mt / 1000.0, 4), "unit": "Msplats/s", "cores": threads,
+                        "ms_per_frame": round(ms_mt, 1),
+                        "sample": f"{what} ({sub.shape[0]} splats, E={e_mt}), 3 frames, median, gso_frame_mt on "
+                                  f"{threads} threads"}
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"[bench] ERROR: --gpus {args.gpus} but this launch has WORLD_SIZE={world}; refusing to report a "
+            f"{world}-rank measurement as a {args.gpus}-GPU one")
+        sys.exit(2)
+    if args.config is None:
+        args.config = "C" if world == 1 else "D"
+    if args.dry_run:
+        sys.exit(dry_run(args, world, rank))
+
+    # stdout carries exactly ONE JSON line: anything a library prints there meanwhile (gloo/RCCL banners)
+    # is sent to stderr by pointing fd 1 at fd 2 until the result is ready
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    import numpy as np
     import torch
     import vk3dgaussiansplatting_amd as gs
     from vk3dgaussiansplatting_amd import dist as gsdist
     from vk3dgaussiansplatting_amd import synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if args.rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    tdist = None
     if world > 1:
         import torch.distributed as tdist
         if args.rehearse:
             tdist.init_process_group(backend="gloo")
         else:
             tdist.init_process_group(backend="nccl", device_id=device)
+        assert tdist.get_world_size() == world
     # one explicit HIP stream for the frame kernels AND the strip gather (torch orders RCCL after it)
     torch.cuda.set_stream(torch.cuda.Stream(device=device))
 
     cfg = dict(synth.CONFIGS[args.config])
     w, h, n = cfg["width"], cfg["height"], cfg["n"]
     t0 = time.time()
-    aos = synth.generate(n, w, h, cfg["mu"], cfg["seed"])
+    aos = synth.generate_config(args.config)[0]
     if rank == 0:
         log(f"[bench] config {args.config}: {n} gaussians @ {w}x{h} generated in {time.time() - t0:.1f}s")
 
@@ -131,8 +217,8 @@ def main():
     cam.setRotation(0.0, 0.0)
     cam.recalculate()
     mode = gs.GS_RENDER_EXACT if args.mode == "exact" else gs.GS_RENDER_FAST
-
     sort_ids = {"radix4": gs.GS_SORT_RADIX4, "bucket": gs.GS_SORT_TILE_BUCKET}
+    interleaved = args.rows == "interleaved" and world > 1
 
     def make(record, sort=None, share=None):
         r = gs.Renderer(w, h, device=local_rank, render_mode=mode, record_timings=record, warmup_frames=0,
@@ -142,174 +228,192 @@ def main():
         r.initForScene(scene, share_with=share)
         return r
 
-    F = args.frames_in_flight
-    sf = gsdist.ShardedFrame(w, h, rank, world, device=device, host_gather=args.rehearse, n_strips=F)
-    rb, re = sf.band
-    # the library addresses the FULL frame; hand it the strips shifted up by the band's first row
-    strip_ptrs = [s_.data_ptr() - rb * 16 * w * 4 for s_ in sf.strips]
-    strip_ptr = strip_ptrs[0]
+    def set_rows(r, sf):
+        if interleaved:
+            r.setTileRowsInterleaved(rank, world)
+        else:
+            r.setTileRows(*sf.band)
 
     class Ring:
-        """F frame slots: slot k = a context with its own per-frame buffers on its own stream, rendering into
-        strip k; the gaussian arrays are uploaded once and shared (gs_share_scene).  Frame f goes to slot f % F,
-        so up to F frames (and their strip gathers, on RCCL's stream) are in flight; the un-instrumented timed
-        region runs through this."""
+        """F frame slots: slot k = a context with its own per-frame buffers on its own stream, rendering into strip k;
+        the gaussian arrays are uploaded once and shared (gs_share_scene).  Frame f goes to slot f % F.  F = 1 is a
+        frame's GPU time (nothing overlaps); F = 3 is the reference's FRAMES_IN_FLIGHT."""
 
-        def __init__(self, sort=None):
-            self.rs, self.streams, self.n = [], [], 0
+        def __init__(self, F, sort=None, owner=None):
+            self.F, self.n = F, 0
+            self.sf = gsdist.ShardedFrame(w, h, rank, world, device=device, host_gather=args.rehearse, n_strips=F,
+                                          interleaved=interleaved)
+            rb = 0 if interleaved else self.sf.band[0]
+            # the library addresses the FULL frame; hand it the strips shifted up by the band's first row
+            self.ptrs = [s_.data_ptr() - rb * 16 * w * 4 for s_ in self.sf.strips] if not interleaved else \
+                        [s_.data_ptr() for s_ in self.sf.strips]
+            self.rs, self.streams = [], []
             for k in range(F):
-                rk = make(0, sort, share=self.rs[0] if k else None)
-                rk.setTileRows(rb, re)
+                rk = make(0, sort, share=owner if owner is not None else (self.rs[0] if k else None))
+                set_rows(rk, self.sf)
                 st = torch.cuda.Stream(device=device)
                 rk.setStream(st.cuda_stream)
                 self.rs.append(rk)
                 self.streams.append(st)
+            self.gather_s = 0.0
 
         def step(self):
-            k = self.n % F
+            k = self.n % self.F
             self.n += 1
             with torch.cuda.stream(self.streams[k]):
-                sf.wait(k)                       # the previous gather of strip k must have read it
-                self.rs[k].drawDevice(scene, strip_ptrs[k], sync=False)
+                self.sf.wait(k)                  # the previous gather of strip k must have read it
+                self.rs[k].drawDevice(scene, self.ptrs[k], sync=False, compact_rows=interleaved)
                 if world > 1:
-                    sf.gather_async(k)
+                    self.sf.gather_async(k)
 
-        def close(self):
+        def barrier(self):
+            self.sf.wait_all()
             torch.cuda.synchronize()
-            for rk in reversed(self.rs):         # borrowers first, the owner of the scene last
+            if world > 1:
+                tdist.barrier()
+                torch.cuda.synchronize()
+
+        def timed(self, steps, warmup):
+            # one untimed frame per slot first: the hipGraph of the radix passes is captured on a slot's first frame
+            # and kernels are loaded lazily, so the W warm-up and K timed steps are steady-state frames
+            for _ in range(self.F):
+                self.step()
+            self.barrier()
+            self.n = 0
+            for _ in range(warmup):
+                self.step()
+            self.barrier()
+            t_begin = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            self.barrier()
+            elapsed = time.perf_counter() - t_begin
+            el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else device)
+            if world > 1:
+                tdist.all_reduce(el, op=tdist.ReduceOp.MAX)
+            return float(el.item()) / steps * 1e3
+
+        def close(self, keep_owner=False):
+            torch.cuda.synchronize()
+            for rk in reversed(self.rs[1 if keep_owner else 0:]):   # borrowers first, the owner of the scene last
                 rk.setStream(None)
                 rk.cleanup()
-            self.rs = []
+            self.rs = self.rs[:1] if keep_owner else []
 
-    try:
-        ring = Ring()
-    except Exception as ex:  # noqa: BLE001 -- e.g. out of memory for the extra frame slots: time a single slot instead
-        if F == 1:
-            raise
-        log(f"[bench] {F} frame slots could not be set up ({ex}); falling back to one")
-        torch.cuda.synchronize()
-        F = 1
-        ring = Ring()
-    r = ring.rs[0]
-    step = ring.step
+    F = args.frames_in_flight
+    ring = Ring(F)
+    owner = ring.rs[0]
 
-    def barrier():
-        sf.wait_all()
-        torch.cuda.synchronize()
-        if world > 1:
-            tdist.barrier()
-            torch.cuda.synchronize()
-
-    # N > 1: the assembled frame must equal what one GPU renders alone (checked once, untimed)
-    sharded_ok = None
+    # N > 1: the assembled frame must equal what one GPU renders alone (checked once, untimed); the single-GPU
+    # render of the same frame is also timed (a few frames), so the line carries its own strong-scaling reference
+    sharded_ok, one_gpu_ms = None, None
     if world > 1:
         with torch.cuda.stream(ring.streams[0]):
-            sf.wait(0)
-            r.drawDevice(scene, strip_ptrs[0], sync=False)
-            strips = sf.gather(0)
+            ring.sf.wait(0)
+            owner.drawDevice(scene, ring.ptrs[0], sync=False, compact_rows=interleaved)
+            strips = ring.sf.gather(0)
         torch.cuda.synchronize()
         if rank == 0:
             full = torch.zeros((h, w, 4), dtype=torch.uint8, device=device)
-            rf = make(0)
+            rf = make(1, share=owner)
             rf.setStream(torch.cuda.current_stream().cuda_stream)
-            rf.drawDevice(scene, full.data_ptr(), sync=True)
+            tot = []
+            for i in range(13):
+                rf.drawDevice(scene, full.data_ptr(), sync=True)
+                if i >= 3:
+                    tot.append(rf.timings().total_ms)
+            one_gpu_ms = float(np.mean(tot))
             rf.setStream(None)
             rf.cleanup()
-            sharded_ok = bool(torch.equal(sf.assemble(strips).to(full.device), full))
-            log(f"[bench] sharded frame equals the single-GPU frame: {sharded_ok}")
-        barrier()
+            sharded_ok = bool(torch.equal(ring.sf.assemble(strips).to(full.device), full))
+            log(f"[bench] sharded frame equals the single-GPU frame: {sharded_ok}; one GPU alone: {one_gpu_ms:.3f} ms")
+        ring.barrier()
 
-    # one-time setup of every frame slot (the hipGraph of the radix passes is captured on a slot's first frame,
-    # kernels are loaded lazily): one untimed frame per slot, so that the W warm-up and K timed steps below are
-    # steady-state frames whatever W and K are
-    for _ in range(F):
-        step()
-    barrier()
-    ring.n = 0
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t_begin = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t_begin
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else device)
-    if world > 1:
-        tdist.all_reduce(el, op=tdist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    ms_per_step = elapsed / args.steps * 1e3
+    ms_per_step = ring.timed(args.steps, args.warmup)
     # every slot rendered the same camera: their strips must be identical
-    used = min(F, args.steps + args.warmup)
-    slots_ok = all(bool(torch.equal(sf.strips[0], sf.strips[k])) for k in range(1, used))
-    if not slots_ok:
-        log("[bench] ERROR: frame slots produced different images")
+    slots_ok = all(bool(torch.equal(ring.sf.strips[0], ring.sf.strips[k])) for k in range(1, F))
+    sf_main = ring.sf
+    ring.close(keep_owner=True)
 
-    # instrumented pass (same process, same data, same K): the reference's five buckets + one event
-    # pair around every Scatter launch, on the stream the kernels run on
-    ring.close()
-    ri = make(2)
-    ri.setTileRows(rb, re)
-    ri.setStream(torch.cuda.current_stream().cuda_stream)
-    buckets = np.zeros(5)
-    scat = 0.0
-    scat_tile = 0.0
-    k_inst = max(10, min(args.steps, 100))
-    for i in range(5 + k_inst):
-        ri.drawDevice(scene, strip_ptr, sync=True)
-        if i >= 5:
+    # ---- instrumented passes (same process, same data), one frame slot, host wait per frame as Renderer.cpp:459 ----
+    strip_ptr = ring.ptrs[0]
+
+    def instrumented(record, frames):
+        ri = make(record, share=owner)
+        set_rows(ri, sf_main)
+        ri.setStream(torch.cuda.current_stream().cuda_stream)
+        for _ in range(5):
+            ri.drawDevice(scene, strip_ptr, sync=True, compact_rows=interleaved)
+        buckets = np.zeros(5)
+        scat = scat_tile = 0.0
+        torch.cuda.synchronize()
+        t_b = time.perf_counter()
+        for _ in range(frames):
+            ri.drawDevice(scene, strip_ptr, sync=True, compact_rows=interleaved)
             t = ri.timings()
             buckets += [t.init_sort_list_ms, t.radix_sort_ms, t.find_ranges_ms, t.render_ms, t.total_ms]
             scat += t.scatter_ms_avg
             scat_tile += t.scatter_tile_ms_avg
-    buckets /= k_inst
-    scat /= k_inst
-    scat_tile /= k_inst
-    t = ri.timings()
-    e_rank = int(t.num_sort_elements)
-    passes_full = int(t.scatter_launches)
-    passes_tile = int(t.scatter_tile_launches)
-    passes = passes_full + passes_tile
-    info = ri.sceneInfo()
-    ri.setStream(None)
-    ri.cleanup()
+        wall = (time.perf_counter() - t_b) / frames * 1e3
+        t = ri.timings()
+        info = ri.sceneInfo()
+        host = ri.hostTimings()
+        ri.setStream(None)
+        ri.cleanup()
+        return buckets / frames, scat / frames, scat_tile / frames, wall, t, info, host
 
-    # extra pass: the same frame with the other sort back-end (identical output), for the record
-    alt = None
-    if not args.no_alt:
+    k_inst = max(10, min(args.steps, 200))
+    buckets, _, _, wall_wait, _, _, host_t = instrumented(1, k_inst)            # the reference's five buckets (graph replay as in production)
+    _, scat, scat_tile, _, t, info, _ = instrumented(2, max(10, min(args.steps, 50)))   # + one event pair around every Scatter launch
+    e_rank = int(t.num_sort_elements)
+    passes_full, passes_tile = int(t.scatter_launches), int(t.scatter_tile_launches)
+    moved_full, moved_tile = float(t.scatter_bytes_per_elem), float(t.scatter_tile_bytes_per_elem)
+
+    # ---- extras: three frames in flight; the other sort back-end (identical output) ----
+    extras = {}
+    if not args.no_extras:
+        if F != 3:
+            r3 = Ring(3, owner=owner)
+            ms3 = r3.timed(min(args.steps, 300), 20)
+            ok3 = all(bool(torch.equal(r3.sf.strips[0], r3.sf.strips[k])) for k in range(1, 3))
+            r3.close()
+            extras["frames_in_flight_3"] = {
+                "ms_per_step": round(ms3, 4), "value": round(n / ms3 / 1000.0, 2), "unit": "Msplats/s",
+                "frame_slots_identical": ok3,
+                "note": "throughput with GfxSettings::FRAMES_IN_FLIGHT = 3 frame slots overlapping on the GPU; the "
+                        "reference's published frame time is GPU time per frame, so this is NOT what vs_baseline uses"}
         other = "bucket" if args.sort == "radix4" else "radix4"
-        ring_a = Ring(other)
-        for _ in range(10):
-            ring_a.step()
-        barrier()
-        t_a = time.perf_counter()
-        for _ in range(args.steps):
-            ring_a.step()
-        barrier()
-        alt_ms = (time.perf_counter() - t_a) / args.steps * 1e3
-        ring_a.close()
-        alt = {"sort_algorithm": other, "ms_per_step": round(alt_ms, 4), "value": round(n / alt_ms / 1000.0, 2),
-               "note": "GS_SORT_TILE_BUCKET = tile-word radix passes + per-tile LDS depth sort; bit-identical output"}
+        ra = Ring(1, sort=other, owner=owner)
+        ms_a = ra.timed(min(args.steps, 300), 20)
+        ra.close()
+        extras["alt_sorter"] = {"sort_algorithm": other, "ms_per_step": round(ms_a, 4), "value": round(n / ms_a / 1000.0, 2),
+                                "note": "GS_SORT_TILE_BUCKET = tile-word radix passes + per-tile LDS depth sort behind the "
+                                        "GpuSort seam; bit-identical output; one frame slot"}
+    owner.setStream(None)
+    owner.cleanup()
 
     # per-rank numbers to rank 0
-    stats = torch.tensor([e_rank, scat, *buckets], dtype=torch.float64, device="cpu" if args.rehearse else device)
+    stats = torch.tensor([e_rank, scat, *buckets, local_rank if not args.rehearse else 0],
+                         dtype=torch.float64, device="cpu" if args.rehearse else device)
     if world > 1:
         allstats = [torch.zeros_like(stats) for _ in range(world)]
         tdist.all_gather(allstats, stats)
     else:
         allstats = [stats]
 
-    # measured device-to-device stream copy on this GPU (north_star: "measured HBM roofline")
-    copy_gbps = None
+    # measured device-to-device stream copy on this GPU (north_star: "measured HBM roofline"): best of the probe shapes
+    copy_gbps, copy_kind = None, None
     if rank == 0:
         try:
             import ctypes as C
             from vk3dgaussiansplatting_amd import _lib
             probe = C.c_void_p()
             if _lib.lib().gs_create(None, C.byref(probe)) == 0:
-                g_, ms_ = C.c_float(), C.c_float()
-                if _lib.lib().gs_membench(probe, 1, 1 << 30, 2048, 10, C.byref(g_), C.byref(ms_)) == 0:
-                    copy_gbps = float(g_.value)
+                for kind, blocks in ((1, 2048), (10, 4096), (11, 4096), (12, 4096), (11, 16384)):
+                    g_, ms_ = C.c_float(), C.c_float()
+                    if _lib.lib().gs_membench(probe, kind, 1 << 30, blocks, 10, C.byref(g_), C.byref(ms_)) == 0:
+                        if copy_gbps is None or g_.value > copy_gbps:
+                            copy_gbps, copy_kind = float(g_.value), f"kind {kind}, {blocks} workgroups"
                 _lib.lib().gs_destroy(probe)
         except Exception as ex:  # noqa: BLE001 -- the probe is informational
             log(f"[bench] stream-copy probe failed: {ex}")
@@ -317,87 +421,91 @@ def main():
     if rank == 0:
         e_total = int(sum(float(s[0]) for s in allstats))
         value = n / ms_per_step / 1000.0            # Msplats/s, whole job
-        # roofline of the dominant kernel (k_scatter): algorithmic bytes per launch =
-        # 24 B per element (read 12 B key+payload, write 12 B; SURVEY 8(d): Scatter share of B_sort)
-        # the launches that move key + payload (k_scatter<true>: the eight depth-word passes of the contractual
-        # sort, every pass of the tile-bucket sorter); the tile-word passes of the frame path leave the sorted
-        # depth words behind (k_scatter<false>, 16 B per element) and are reported beside them
-        # ALGORITHMIC bytes of a Scatter launch = SURVEY 8(d)'s figure: 12 B read + 12 B written per element.
-        # What this build really moves is less: tile ids travel as uint16 when the grid has <= 65535 tiles
-        # (tile_word_bytes), and the tile-word passes leave the sorted depth words behind; both are reported.
-        tw = int(info.tile_word_bytes)
-        moved_full = float(t.scatter_bytes_per_elem)        # depth word + tile word + id, read and written (mean over the launches)
-        moved_tile = float(t.scatter_tile_bytes_per_elem)
+        ref = REF_MS.get(args.config) if world == 1 else None
+        # Roofline of the dominant kernel, k_scatter's depth-word passes.  ALGORITHMIC bytes = SURVEY 8(d): 12 B read +
+        # 12 B written per element and launch.  This layout moves fewer (16-bit tile ids, depth words that shrink as
+        # their digits are consumed), so the rate on the bytes really moved is reported beside it, against the 8 TB/s
+        # datasheet peak and against the stream-copy rate measured on this GPU.
         alg_bytes = 24.0 * e_rank
         achieved = alg_bytes / (scat * 1e-3) / 1e9 if scat > 0 else 0.0
         achieved_moved = moved_full * e_rank / (scat * 1e-3) / 1e9 if scat > 0 else 0.0
-        tile_pass = None
-        if passes_tile:
-            tile_pass = {"kernel": "k_scatter<0, 0, .> (tile-word passes: depth words not carried)",
-                         "alg_bytes_per_launch": alg_bytes, "moved_bytes_per_element": moved_tile,
-                         "avg_launch_ms": round(scat_tile, 5),
-                         "achieved": round(alg_bytes / (scat_tile * 1e-3) / 1e9, 1) if scat_tile > 0 else 0.0,
-                         "achieved_on_moved_bytes": round(moved_tile * e_rank / (scat_tile * 1e-3) / 1e9, 1) if scat_tile > 0 else 0.0,
-                         "unit": "GB/s", "launches_per_frame": passes_tile}
-        # HBM bytes per Scatter launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE
-        # doubled per MI355X_MICROARCH.md; summary committed under profiles/), when measured at this E
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_scatter.json")) as f:
+            with open(PMC_SCATTER_FILE) as f:
                 pmc = json.load(f)
-            if pmc["elements"] == e_rank and pmc.get("tile_word_bytes", 4) == tw:
+            if pmc["elements"] == e_rank and pmc.get("tile_word_bytes", 4) == int(info.tile_word_bytes):
                 traffic = pmc["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
+        roofline = {
+            "bound": "hbm",
+            "kernel": "k_scatter, the depth-word passes (radix Scatter moving key + payload, one launch per 4-bit pass)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2, MI355X_MICROARCH.md) + WRITE_SIZE, "
+                            "separate passes, of this build at this E (profiles/r02_pmc_scatter.json); null when no "
+                            "matching profile is committed",
+            "alg_bytes_per_launch": alg_bytes, "alg_bytes_per_element": 24.0,
+            "avg_launch_ms": round(scat, 5), "launches_per_frame": passes_full,
+            "moved": {"bytes_per_element": moved_full, "achieved": round(achieved_moved, 1),
+                      "frac_of_peak": round(achieved_moved / HBM_PEAK_GBPS, 4),
+                      "frac_of_measured_copy": round(achieved_moved / copy_gbps, 4) if copy_gbps else None,
+                      "frac_of_guide_copy": round(achieved_moved / HBM_GUIDE_COPY_GBPS, 4)},
+            "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None, "measured_copy_probe": copy_kind,
+            "guide_copy_GBps": HBM_GUIDE_COPY_GBPS,
+            "note": "achieved/frac: SURVEY 8(d)'s algorithmic 24 B per element over the mean launch duration (HIP event "
+                    "pair around every such launch, on its stream); moved: the bytes this layout really reads + writes "
+                    "per element, over the same duration",
+        }
+        if passes_tile:
+            mv = moved_tile * e_rank / (scat_tile * 1e-3) / 1e9 if scat_tile > 0 else 0.0
+            roofline["tile_word_passes"] = {
+                "kernel": "k_scatter<0, 0, .> (tile-word passes: depth words not carried)",
+                "avg_launch_ms": round(scat_tile, 5), "launches_per_frame": passes_tile,
+                "moved": {"bytes_per_element": moved_tile, "achieved": round(mv, 1),
+                          "frac_of_peak": round(mv / HBM_PEAK_GBPS, 4),
+                          "frac_of_measured_copy": round(mv / copy_gbps, 4) if copy_gbps else None}}
         out = {
             "metric": "Msplats/s + total frame ms (InitSortList/RadixSort/FindRanges/Render split)",
             "value": round(value, 2), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong",
-            "vs_baseline": round(value / REF_MSPLATS[args.config], 3) if args.config in REF_MSPLATS else None,
+            "vs_baseline": round(value / (ref[0] / ref[1] / 1000.0), 3) if ref else None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": {"A": "synthetic 100k @ 640x360", "B": "Train-7k shape: 559,263 gaussians @ 1280x720",
-                             "C": "Garden-30k shape: 5,834,784 gaussians @ 1920x1080",
-                             "D": "Garden-30k shape: 5,834,784 gaussians @ 3840x2160",
-                             "E": "stress: 50,000,000 synthetic gaussians @ 1920x1080"}[args.config],
+                "workload": WORKLOADS[args.config],
                 "num_gaussians": n, "width": w, "height": h, "sort_elements": e_total,
-                "capacity": int(info.capacity), "radix_passes": passes, "render_mode": args.mode,
+                "capacity": int(info.capacity), "radix_passes": passes_full + passes_tile, "render_mode": args.mode,
                 "render_kernel": args.render_kernel,
                 "sort_algorithm": args.sort, "frames_in_flight": F,
-                "parallelism": f"tile-row shard x{world}" if world > 1 else "single GPU",
-                "baseline_note": "vs_baseline = Msplats/s over the reference README's RTX 3080 Ti figure for the "
-                                 "real scene of this shape (BASELINE.md); ours is a synthetic cloud with the same N and E",
+                "parallelism": (f"tile-row shard x{world} ({args.rows} rows), RGBA8 strips gathered to rank 0 over "
+                                f"{'gloo (rehearsal on one GPU)' if args.rehearse else 'RCCL'}") if world > 1 else "single GPU",
+                "baseline_note": "vs_baseline = the reference README's total GPU frame time on an RTX 3080 Ti for the real "
+                                 "scene of this shape (BASELINE.md) over ms_per_step; ours is a synthetic cloud with the "
+                                 "same N and E, one frame slot, so both sides are GPU time per frame",
             },
             "buckets_ms": {k: round(float(v), 4) for k, v in zip(
-                ["init_sort_list", "radix_sort", "find_ranges", "render", "total"], allstats[0][2:].tolist())},
-            "buckets_note": "rank 0, instrumented pass of ONE frame slot (hipEvents at the reference's 7 timestamp "
-                            "points) = the latency of a frame; ms_per_step is the un-instrumented wall clock per frame "
-                            "incl. the strip gather with config.frames_in_flight slots overlapping on the GPU "
-                            "(GfxSettings::FRAMES_IN_FLIGHT in the reference), so it can be below buckets_ms.total",
+                ["init_sort_list", "radix_sort", "find_ranges", "render", "total"], allstats[0][2:7].tolist())},
+            "buckets_note": "rank 0, hipEvents at the reference's 7 timestamp points (Renderer.cpp:557-622), mean of "
+                            f"{k_inst} frames with a host wait per frame",
+            "frame_wall_ms_with_host_wait": round(wall_wait, 4),
+            "host_ms": host_t,
             "frame_slots_identical": slots_ok,
-            "roofline": {"bound": "hbm", "kernel": "k_scatter, the depth-word passes (radix Scatter moving key + payload, one launch per 4-bit pass)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes, "alg_bytes_per_element": 24.0,
-                         "moved_bytes_per_element": moved_full, "achieved_on_moved_bytes": round(achieved_moved, 1),
-                         "avg_launch_ms": round(scat, 5),
-                         "launches_per_frame": passes_full,
-                         "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
-                         "frac_of_measured_copy": round(achieved_moved / copy_gbps, 4) if copy_gbps else None,
-                         "note": "achieved/frac use SURVEY 8(d)'s 24 B per element; frac_of_measured_copy uses the bytes "
-                                 "really moved against the stream-copy rate measured on this GPU"},
+            "roofline": roofline,
         }
-        if tile_pass is not None:
-            out["roofline"]["tile_word_passes"] = tile_pass
-        if alt is not None:
-            out["alt"] = alt
+        out.update(extras)
         if world > 1:
+            out["rccl_ranks"] = tdist.get_world_size()
+            out["rank_devices"] = [int(s[7]) for s in allstats]
             out["sharded_image_matches_single_gpu"] = sharded_ok
             out["per_rank_total_ms"] = [round(float(s[6]), 4) for s in allstats]
+            out["per_rank_buckets_ms"] = [[round(float(x), 4) for x in s[2:6]] for s in allstats]
             out["per_rank_sort_elements"] = [int(s[0]) for s in allstats]
+            out["one_gpu_same_frame_ms"] = round(one_gpu_ms, 4) if one_gpu_ms else None
+            out["speedup_vs_one_gpu_same_frame"] = round(one_gpu_ms / ms_per_step, 3) if one_gpu_ms else None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(aos, cfg)
+            import oracle
+            out["cpu_baseline"] = cpu_baseline(aos, cfg, oracle)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:

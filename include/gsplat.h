@@ -74,7 +74,8 @@ typedef struct gs_config {
     float fov_y;              /* 3.1415f*0.5f FOV_Y (the covariance one, not the projection's) */
     uint32_t sort_algorithm;  /* GS_SORT_* */
     uint32_t render_mode;     /* GS_RENDER_* */
-    uint32_t record_timings;  /* 1 = hipEvents at the reference's 7 timestamp points (RECORD_GPU_TIMES, Renderer.h:35);
+    uint32_t record_timings;  /* 0 (default, like the reference's commented-out RECORD_GPU_TIMES, GfxSettings.h:7) = no
+                                 events; 1 = hipEvents at the reference's 7 timestamp points (Renderer.cpp:557-622);
                                  2 = additionally one event pair around every Scatter launch (roofline measurement) */
     uint32_t render_kernel;   /* GS_RENDER_KERNEL_*: how a tile maps to waves in RenderGaussians; same pixels either way */
 } gs_config;
@@ -102,6 +103,19 @@ typedef struct gs_timings {
     float scatter_tile_bytes_per_elem;
 } gs_timings;
 
+/* RECORD_CPU_TIMES (GfxSettings.h:6; Renderer.cpp:299-314, 343-352, 399-456): host-side milliseconds of the last
+ * gs_render* call, always recorded (four clock reads per frame).  The reference's four figures map to:
+ * waitForFence -> wait_ms (host blocked until the GPU has finished the frame; 0 for the async variant),
+ * recordCommandBuffer -> record_ms (enqueueing the frame's launches), present -> present_ms (the copy of the frame to
+ * the host in gs_render; 0 for the device variants), CPU frame time -> cpu_frame_ms (entry of this call minus entry of
+ * the previous one). */
+typedef struct gs_host_timings {
+    float wait_ms;
+    float record_ms;
+    float present_ms;
+    float cpu_frame_ms;
+} gs_host_timings;
+
 /* Scene-derived sizes: Renderer.cpp:696-701 (tiles), :725 (capacity), RadixSort.cpp:203-204 (bits). */
 typedef struct gs_scene_info {
     uint32_t num_gaussians;
@@ -110,8 +124,11 @@ typedef struct gs_scene_info {
     uint32_t capacity;            /* C = ceilPow2(N + 64*16*T) */
     uint32_t num_sort_bits;       /* 4 * P */
     uint32_t row_begin, row_end;  /* tile-row band rendered by this context */
-    uint32_t tile_word_bytes;     /* how the frame's sort list stores a tile id: 2 (uint16 relative to the band's first
-                                     tile, bands of at most 65535 tiles) or 4; callers always see uint32 global ids */
+    uint32_t tile_word_bytes;     /* how the frame's sort list stores a tile id: 2 (uint16 index among the context's own
+                                     tiles, at most 65535 of them) or 4; callers always see uint32 global ids */
+    uint32_t row_stride;          /* the context renders tile rows first_row + k * row_stride < row_end, k < rows_owned */
+    uint32_t first_row;
+    uint32_t rows_owned;
 } gs_scene_info;
 
 /* buffers readable through gs_debug_read (state after the last gs_render*) */
@@ -144,7 +161,8 @@ int gs_upload_gaussians(gs_ctx* ctx, const void* aos336, uint32_t n);
  * Renderer.cpp:304-310, 514): `ctx` renders the gaussians already uploaded to `owner` -- the read-only arrays
  * are shared, everything a frame writes (sort lists, ranges, raster records, image, stream, timings) stays per
  * context, so F contexts on F streams keep F frames in flight on one GPU.  Follow with gs_set_resolution.
- * The owner refuses gs_destroy / gs_upload_gaussians / gs_load_ply while borrowers exist (GS_ERR_INVALID). */
+ * The arrays are reference-counted inside the library: the contexts may be destroyed in any order, and a new
+ * gs_upload_gaussians / gs_load_ply on one of them leaves the others rendering the arrays they hold. */
 int gs_share_scene(gs_ctx* ctx, gs_ctx* owner);
 
 /* ResourceManager::loadGaussians (ResourceManager.cpp:167-300): binary little-endian .ply with the
@@ -171,6 +189,12 @@ int gs_set_resolution(gs_ctx* ctx, uint32_t width, uint32_t height);
  * [row_begin,row_end) with GLOBAL tile ids, so keys, per-tile order and pixels equal the 1-GPU
  * result.  Default after gs_set_resolution: all rows. */
 int gs_set_tile_rows(gs_ctx* ctx, uint32_t row_begin, uint32_t row_end);
+/* Same extension, interleaved: this context owns tile rows phase, phase + stride, phase + 2 stride, ... of the whole
+ * grid (rank r of R: phase = r, stride = R), which evens out the per-rank load when the splat density varies over the
+ * height of the frame.  compact_output != 0: gs_render_device* address the image in compact rows -- the pixel rows of
+ * the k-th owned tile row start at row 16 k -- i.e. they write the strip a rank contributes to the gather
+ * (ceil(rows_owned) * 16 rows of `width` pixels); gs_render (host image) always writes the real rows. */
+int gs_set_tile_rows_interleaved(gs_ctx* ctx, uint32_t phase, uint32_t stride, uint32_t compact_output);
 int gs_get_scene_info(const gs_ctx* ctx, gs_scene_info* out);
 
 /* Renderer::draw (Renderer.cpp:297-515): updateUniformBuffer(view, proj) (:531-538), the push
@@ -193,6 +217,8 @@ int gs_synchronize(gs_ctx* ctx);
 
 /* computeDiffs buckets of the last synchronous frame (Renderer.cpp:463-475). */
 int gs_get_timings(const gs_ctx* ctx, gs_timings* out);
+/* RECORD_CPU_TIMES figures of the last gs_render* call (Renderer.cpp:399-456). */
+int gs_get_host_timings(const gs_ctx* ctx, gs_host_timings* out);
 
 /* No reference counterpart (its buffers are only visible in a GPU debugger): copies one device
  * buffer of the last frame to dst; bytes must not exceed the buffer's size. */
@@ -227,8 +253,9 @@ int gs_sort_bench(gs_ctx* ctx, uint32_t n, uint32_t num_tiles, uint32_t iters, u
 /* Stream-bandwidth probe on the context's GPU (the "measured HBM roofline" denominator): kind 0 =
  * read with 16-byte loads, 1 = device-to-device copy with 16-byte accesses, 2 = read with 4-byte
  * loads, 3 = copy with 4-byte accesses, 4..7 = copy in the radix-scatter write pattern (three arrays,
- * tiles of 3072 / 6144 / 12288 / 49152 dwords written as 16 runs each).  `bytes` per buffer; `blocks` workgroups of 256 threads
- * (0 = 2048).  Returns the mean over `iters` launches of bytes moved (read + written) per second. */
+ * tiles of 3072 / 6144 / 12288 / 49152 dwords written as 16 runs each), 10..12 = copies with four 16-byte loads in
+ * flight per lane (10 plain, 11 non-temporal stores, 12 non-temporal loads and stores).  `bytes` per buffer; `blocks`
+ * workgroups of 256 threads (0 = 2048).  Returns the mean over `iters` launches of bytes moved (read + written) per second. */
 int gs_membench(gs_ctx* ctx, int kind, size_t bytes, uint32_t blocks, uint32_t iters, float* gbytes_per_s,
                 float* ms_per_launch);
 

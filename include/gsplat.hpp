@@ -26,9 +26,13 @@ public:
     Renderer& operator=(const Renderer&) = delete;
     ~Renderer() { cleanup(); }
 
-    // Renderer::init (Renderer.cpp:688-694).  cfg == nullptr: the reference's constants.
+    // Renderer::init (Renderer.cpp:688-694).  cfg == nullptr: the reference's constants, with the GPU timestamps on
+    // (this class keeps the RECORD_GPU_TIMES averages; gs_default_config leaves them off like GfxSettings.h:7).
     int init(const gs_config* cfg = nullptr) {
-        cleanup();
+        const int rc_clean = cleanup();
+        if (rc_clean != GS_OK) return rc_clean;
+        gs_config def;
+        if (!cfg) { gs_default_config(&def); def.record_timings = 1; cfg = &def; }
         const int rc = gs_create(cfg, &ctx_);
         if (rc != GS_OK) error_ = gs_last_error(nullptr);
         return rc;
@@ -44,7 +48,8 @@ public:
         return rc;
     }
     // Frame slot (GfxSettings::FRAMES_IN_FLIGHT, GfxSettings.h:15): render the scene `owner` uploaded, with this
-    // renderer's own per-frame buffers and stream.  Clean this renderer up before the owner.
+    // renderer's own per-frame buffers and stream.  The arrays are reference-counted inside the library, so the two
+    // renderers may be cleaned up or destructed in any order.
     int initForSceneSharedWith(Renderer& owner) {
         int rc = gs_share_scene(ctx_, owner.ctx_);
         if (rc == GS_OK) rc = gs_set_resolution(ctx_, width_, height_);
@@ -76,10 +81,18 @@ public:
         return rc;
     }
 
-    // Renderer::cleanup (Renderer.cpp:230-270)
-    void cleanup() {
-        if (ctx_) { gs_destroy(ctx_); ctx_ = nullptr; }
+    // Renderer::cleanup (Renderer.cpp:230-270).  On failure the handle is kept (nothing leaks silently) and the
+    // status is returned with lastError() set.
+    int cleanup() {
+        if (!ctx_) return GS_OK;
+        const int rc = gs_destroy(ctx_);
+        if (rc != GS_OK) { error_ = gs_last_error(ctx_); return rc; }
+        ctx_ = nullptr;
+        return GS_OK;
     }
+
+    // RECORD_CPU_TIMES figures of the last draw (Renderer.cpp:399-456)
+    gs_host_timings hostTimings() const { gs_host_timings t{}; if (ctx_) gs_get_host_timings(ctx_, &t); return t; }
 
     const gs_timings& lastTimings() const { return last_; }
     // avgInitSortListMs, avgSortMs, avgFindRangesMs, avgRenderGaussiansMs, avgTotalGpuTimeMs (Renderer.h)

@@ -98,6 +98,10 @@ def lib() -> C.CDLL:
         L.gso_render_libm_exp.argtypes = [PP, vp, vp, vp, vp, vp, vp]
         L.gso_frame.argtypes = [PP, vp, u32, vp, vp]; L.gso_frame.restype = u32
         L.gso_frame_mt.argtypes = [PP, vp, u32, vp, vp, u32]; L.gso_frame_mt.restype = u32
+        L.gso_init_sort_list_mt.argtypes = [PP, vp, u32, u32, vp, vp, vp, vp, vp, vp, u32]
+        L.gso_init_sort_list_mt.restype = u64
+        L.gso_sort_stable_mt.argtypes = [vp, vp, vp, u32, u32]
+        L.gso_render_mt.argtypes = [PP, vp, vp, vp, vp, vp, vp, u32]
         L.gso_camera_matrices.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                           C.c_float, vp, vp]
         L.gso_morton.argtypes = [u32, u32, u32]; L.gso_morton.restype = u32
@@ -161,8 +165,18 @@ def morton(x, y, z):
     return int(lib().gso_morton(int(x), int(y), int(z)))
 
 
-def init_sort_list(p: Params, aos: np.ndarray, cap: int | None = None):
-    """Stage 1.  Returns dict(color, cov, splats, tile, depth, id, counter, capacity)."""
+def host_threads(limit: int = 64) -> int:
+    """Threads for the *_mt entry points: the CPUs this process may run on, capped."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    return max(1, min(n, limit))
+
+
+def init_sort_list(p: Params, aos: np.ndarray, cap: int | None = None, threads: int = 1, want_splats: bool = True):
+    """Stage 1.  Returns dict(color, cov, splats, tile, depth, id, counter, capacity).  threads > 1 runs
+    gso_init_sort_list_mt (same outputs)."""
     aos = np.ascontiguousarray(aos, dtype=np.float32).reshape(-1, FLOATS_PER_GAUSSIAN)
     n = aos.shape[0]
     gw, gh = grid(p.width, p.height, p.tile_size)
@@ -170,19 +184,28 @@ def init_sort_list(p: Params, aos: np.ndarray, cap: int | None = None):
         cap = capacity(n, gw * gh)
     color = np.zeros((n, 4), dtype=np.float32)
     cov = np.zeros((n, 4), dtype=np.float32)
-    splats = np.zeros(n, dtype=SPLAT_DTYPE)
+    splats = np.zeros(n, dtype=SPLAT_DTYPE) if want_splats else None
     tile = np.empty(cap, dtype=np.uint32)
     depth = np.empty(cap, dtype=np.uint32)
     ident = np.empty(cap, dtype=np.uint32)
-    counter = lib().gso_init_sort_list(C.byref(p), _ptr(aos), n, cap, _ptr(color), _ptr(cov),
-                                       _ptr(splats), _ptr(tile), _ptr(depth), _ptr(ident))
+    sp = _ptr(splats) if splats is not None else None
+    if threads > 1:
+        counter = lib().gso_init_sort_list_mt(C.byref(p), _ptr(aos), n, cap, _ptr(color), _ptr(cov), sp,
+                                              _ptr(tile), _ptr(depth), _ptr(ident), int(threads))
+    else:
+        counter = lib().gso_init_sort_list(C.byref(p), _ptr(aos), n, cap, _ptr(color), _ptr(cov),
+                                           sp, _ptr(tile), _ptr(depth), _ptr(ident))
     return dict(color=color, cov=cov, splats=splats, tile=tile, depth=depth, id=ident,
                 counter=int(counter), capacity=cap)
 
 
-def sort_stable(tile, depth, ident, e):
-    tile, depth, ident = tile.copy(), depth.copy(), ident.copy()
-    lib().gso_sort_stable(_ptr(tile), _ptr(depth), _ptr(ident), int(e))
+def sort_stable(tile, depth, ident, e, threads: int = 1, inplace: bool = False):
+    if not inplace:
+        tile, depth, ident = tile.copy(), depth.copy(), ident.copy()
+    if threads > 1:
+        lib().gso_sort_stable_mt(_ptr(tile), _ptr(depth), _ptr(ident), int(e), int(threads))
+    else:
+        lib().gso_sort_stable(_ptr(tile), _ptr(depth), _ptr(ident), int(e))
     return tile, depth, ident
 
 
@@ -200,14 +223,17 @@ def find_ranges(tile, n, num_tiles, literal=False):
     return ranges
 
 
-def render(p: Params, aos, color, cov, sorted_id, ranges, libm_exp=False, out=None):
+def render(p: Params, aos, color, cov, sorted_id, ranges, libm_exp=False, out=None, threads: int = 1):
     aos = np.ascontiguousarray(aos, dtype=np.float32)
     if out is None:
         out = np.zeros((p.height, p.width, 4), dtype=np.uint8)
-    fn = lib().gso_render_libm_exp if libm_exp else lib().gso_render
-    fn(C.byref(p), _ptr(aos), _ptr(np.ascontiguousarray(color)), _ptr(np.ascontiguousarray(cov)),
-       _ptr(np.ascontiguousarray(sorted_id, dtype=np.uint32)),
-       _ptr(np.ascontiguousarray(ranges, dtype=np.uint32)), _ptr(out))
+    args = (C.byref(p), _ptr(aos), _ptr(np.ascontiguousarray(color)), _ptr(np.ascontiguousarray(cov)),
+            _ptr(np.ascontiguousarray(sorted_id, dtype=np.uint32)),
+            _ptr(np.ascontiguousarray(ranges, dtype=np.uint32)), _ptr(out))
+    if threads > 1 and not libm_exp:
+        lib().gso_render_mt(*args, int(threads))
+    else:
+        (lib().gso_render_libm_exp if libm_exp else lib().gso_render)(*args)
     return out
 
 
@@ -229,16 +255,19 @@ def frame_mt(p: Params, aos, threads: int):
     return out, int(e), t
 
 
-def full_pipeline(p: Params, aos, literal_sort=False):
-    """All four stages with every intermediate kept (what the parity tests compare against)."""
-    s1 = init_sort_list(p, aos)
+def full_pipeline(p: Params, aos, literal_sort=False, threads: int = 1, want_splats: bool = True,
+                  keep_unsorted: bool = True):
+    """All four stages with every intermediate kept (what the parity tests compare against).  threads > 1:
+    the *_mt stage functions (same outputs); keep_unsorted = False sorts the stage-1 lists in place (large
+    configs: stage1["tile"/"depth"/"id"] then hold the SORTED list)."""
+    s1 = init_sort_list(p, aos, threads=threads, want_splats=want_splats)
     gw, gh = grid(p.width, p.height, p.tile_size)
     e = min(s1["counter"], s1["capacity"])
     if literal_sort:
         t, d, i = radix_sort_literal(s1["tile"], s1["depth"], s1["id"], s1["counter"],
                                      num_sort_bits(gw * gh))
     else:
-        t, d, i = sort_stable(s1["tile"], s1["depth"], s1["id"], e)
+        t, d, i = sort_stable(s1["tile"], s1["depth"], s1["id"], e, threads=threads, inplace=not keep_unsorted)
     ranges = find_ranges(t, e, gw * gh, literal=False)
-    img = render(p, aos, s1["color"], s1["cov"], i, ranges)
+    img = render(p, aos, s1["color"], s1["cov"], i, ranges, threads=threads)
     return dict(stage1=s1, e=e, tile=t, depth=d, id=i, ranges=ranges, image=img)

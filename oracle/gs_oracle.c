@@ -878,32 +878,27 @@ static void mt_render(mt_ctx* c, uint32_t tid) {
     }
 }
 
-uint32_t gso_frame_mt(const gso_params* p, const float* aos, uint32_t n, uint8_t* rgba_out,
-                      double* timings_ms, uint32_t threads) {
+static uint32_t clamp_threads(uint32_t threads) {
     if (threads < 1) threads = 1;
     if (threads > GSO_MAX_THREADS) threads = GSO_MAX_THREADS;
-    const uint32_t grid_w = gso_num_tiles_x(p->width, p->tile_size);
-    const uint32_t grid_h = gso_num_tiles_y(p->height, p->tile_size);
-    const uint32_t num_tiles = grid_w * grid_h;
+    return threads;
+}
+
+/* Stage 1 on several threads: same outputs as gso_init_sort_list (tests/test_oracle.py). */
+uint64_t gso_init_sort_list_mt(const gso_params* p, const float* aos, uint32_t n, uint32_t capacity,
+                               float* color, float* cov, gso_splat* splats, uint32_t* list_tile,
+                               uint32_t* list_depth, uint32_t* list_id, uint32_t threads) {
     mt_ctx c;
     memset(&c, 0, sizeof c);
-    c.p = p; c.aos = aos; c.n = n; c.threads = threads; c.rgba = rgba_out;
-    c.cap = gso_capacity(n, num_tiles);
-    c.bits = gso_num_sort_bits(num_tiles);
-    c.color = (float*)calloc((size_t)n * 4 + 4, 4);
-    c.cov = (float*)calloc((size_t)n * 4 + 4, 4);
-    c.splats = (gso_splat*)calloc((size_t)n + 1, sizeof(gso_splat));
+    c.p = p; c.aos = aos; c.n = n; c.threads = clamp_threads(threads);
+    c.cap = capacity; c.color = color; c.cov = cov;
+    c.splats = splats ? splats : (gso_splat*)calloc((size_t)n + 1, sizeof(gso_splat));
     c.offsets = (uint64_t*)malloc(((size_t)n + 1) * sizeof(uint64_t));
-    for (int k = 0; k < 2; ++k) {
-        c.t[k] = (uint32_t*)malloc((size_t)c.cap * 4);
-        c.d[k] = (uint32_t*)malloc((size_t)c.cap * 4);
-        c.i[k] = (uint32_t*)malloc((size_t)c.cap * 4);
-    }
-    c.hist = (uint32_t*)malloc((size_t)threads * 256 * sizeof(uint32_t));
-    uint32_t* ranges = (uint32_t*)malloc((size_t)num_tiles * 8);
-    pthread_mutex_init(&c.lock, NULL);
-
-    double t0 = now_ms();
+    c.t[0] = list_tile; c.d[0] = list_depth; c.i[0] = list_id;
+    /* Subrenderer.cpp:42-46: list <- 0xFFFFFFFF */
+    if (list_tile) memset(list_tile, 0xFF, (size_t)capacity * 4);
+    if (list_depth) memset(list_depth, 0xFF, (size_t)capacity * 4);
+    if (list_id) memset(list_id, 0xFF, (size_t)capacity * 4);
     mt_run(&c, mt_project);
     uint64_t counter = 0;
     for (uint32_t g = 0; g < n; ++g) {                            /* the scan that replaces the atomic */
@@ -914,14 +909,36 @@ uint32_t gso_frame_mt(const gso_params* p, const float* aos, uint32_t n, uint8_t
             counter += (uint64_t)(c.splats[g].max_x - c.splats[g].min_x) * (y1 - y0);
         }
     }
-    c.e = counter < c.cap ? (uint32_t)counter : c.cap;            /* IndirectSetup.comp:28 */
-    mt_run(&c, mt_emit);
-    double t1 = now_ms();
-    for (c.shift = 0; c.shift < c.bits; c.shift += 8) {           /* stable LSD, 8 bits per pass */
+    if (list_tile) mt_run(&c, mt_emit);
+    if (!splats) free(c.splats);
+    free(c.offsets);
+    return counter;
+}
+
+/* Stage 2a on several threads: stable LSD radix, 8 bits per pass over all 64 key bits (passes whose
+ * digit is the same for every element are skipped) == gso_sort_stable's order. */
+void gso_sort_stable_mt(uint32_t* tile, uint32_t* depth, uint32_t* id, uint32_t e, uint32_t threads) {
+    if (e == 0) return;
+    mt_ctx c;
+    memset(&c, 0, sizeof c);
+    c.threads = clamp_threads(threads);
+    c.e = e;
+    c.t[0] = tile; c.d[0] = depth; c.i[0] = id;
+    c.t[1] = (uint32_t*)malloc((size_t)e * 4);
+    c.d[1] = (uint32_t*)malloc((size_t)e * 4);
+    c.i[1] = (uint32_t*)malloc((size_t)e * 4);
+    c.hist = (uint32_t*)malloc((size_t)c.threads * 256 * sizeof(uint32_t));
+    for (c.shift = 0; c.shift < 64; c.shift += 8) {
         mt_run(&c, mt_hist);
-        uint32_t run = 0;
+        uint32_t run = 0, nonzero = 0;
+        for (uint32_t dg = 0; dg < 256; ++dg) {
+            uint32_t tot = 0;
+            for (uint32_t k = 0; k < c.threads; ++k) tot += c.hist[(size_t)k * 256 + dg];
+            nonzero += tot != 0;
+        }
+        if (nonzero <= 1) continue;                               /* nothing to reorder in this pass */
         for (uint32_t dg = 0; dg < 256; ++dg)
-            for (uint32_t k = 0; k < threads; ++k) {
+            for (uint32_t k = 0; k < c.threads; ++k) {
                 const uint32_t v = c.hist[(size_t)k * 256 + dg];
                 c.hist[(size_t)k * 256 + dg] = run;
                 run += v;
@@ -929,21 +946,58 @@ uint32_t gso_frame_mt(const gso_params* p, const float* aos, uint32_t n, uint8_t
         mt_run(&c, mt_scatter);
         c.src ^= 1;
     }
-    double t2 = now_ms();
-    gso_find_ranges(c.t[c.src], c.e, num_tiles, ranges, 0);
-    double t3 = now_ms();
+    if (c.src) {
+        memcpy(tile, c.t[1], (size_t)e * 4);
+        memcpy(depth, c.d[1], (size_t)e * 4);
+        memcpy(id, c.i[1], (size_t)e * 4);
+    }
+    free(c.t[1]); free(c.d[1]); free(c.i[1]); free(c.hist);
+}
+
+/* Stage 4 on several threads (tile rows handed out dynamically): same pixels as gso_render. */
+void gso_render_mt(const gso_params* p, const float* aos, const float* color, const float* cov,
+                   const uint32_t* sorted_id, const uint32_t* ranges, uint8_t* rgba_out, uint32_t threads) {
+    mt_ctx c;
+    memset(&c, 0, sizeof c);
+    c.p = p; c.aos = aos; c.threads = clamp_threads(threads); c.rgba = rgba_out;
+    c.color = (float*)color; c.cov = (float*)cov;
+    c.i[0] = (uint32_t*)sorted_id; c.src = 0;
     c.ranges = ranges;
     c.next_row = p->row_begin;
+    pthread_mutex_init(&c.lock, NULL);
     mt_run(&c, mt_render);
+    pthread_mutex_destroy(&c.lock);
+}
+
+uint32_t gso_frame_mt(const gso_params* p, const float* aos, uint32_t n, uint8_t* rgba_out,
+                      double* timings_ms, uint32_t threads) {
+    threads = clamp_threads(threads);
+    const uint32_t grid_w = gso_num_tiles_x(p->width, p->tile_size);
+    const uint32_t grid_h = gso_num_tiles_y(p->height, p->tile_size);
+    const uint32_t num_tiles = grid_w * grid_h;
+    const uint32_t cap = gso_capacity(n, num_tiles);
+    float* color = (float*)calloc((size_t)n * 4 + 4, 4);
+    float* cov = (float*)calloc((size_t)n * 4 + 4, 4);
+    uint32_t* lt = (uint32_t*)malloc((size_t)cap * 4);
+    uint32_t* ld = (uint32_t*)malloc((size_t)cap * 4);
+    uint32_t* li = (uint32_t*)malloc((size_t)cap * 4);
+    uint32_t* ranges = (uint32_t*)malloc((size_t)num_tiles * 8);
+
+    double t0 = now_ms();
+    const uint64_t counter = gso_init_sort_list_mt(p, aos, n, cap, color, cov, NULL, lt, ld, li, threads);
+    const uint32_t e = counter < cap ? (uint32_t)counter : cap;   /* IndirectSetup.comp:28 */
+    double t1 = now_ms();
+    gso_sort_stable_mt(lt, ld, li, e, threads);
+    double t2 = now_ms();
+    gso_find_ranges(lt, e, num_tiles, ranges, 0);
+    double t3 = now_ms();
+    gso_render_mt(p, aos, color, cov, li, ranges, rgba_out, threads);
     double t4 = now_ms();
     if (timings_ms) {
         timings_ms[0] = t1 - t0; timings_ms[1] = t2 - t1; timings_ms[2] = t3 - t2;
         timings_ms[3] = t4 - t3; timings_ms[4] = t4 - t0;
     }
-    const uint32_t e = c.e;
-    pthread_mutex_destroy(&c.lock);
-    free(c.color); free(c.cov); free(c.splats); free(c.offsets); free(c.hist); free(ranges);
-    for (int k = 0; k < 2; ++k) { free(c.t[k]); free(c.d[k]); free(c.i[k]); }
+    free(color); free(cov); free(lt); free(ld); free(li); free(ranges);
     return e;
 }
 

@@ -127,6 +127,17 @@ uint32_t gso_frame(const gso_params* p, const float* aos, uint32_t n, uint8_t* r
 uint32_t gso_frame_mt(const gso_params* p, const float* aos, uint32_t n, uint8_t* rgba_out,
                       double* timings_ms, uint32_t threads);
 
+/* The stages of gso_frame_mt one by one, for full-size parity tests (same outputs as the
+ * single-thread functions above; tests/test_oracle.py checks that). */
+uint64_t gso_init_sort_list_mt(const gso_params* p, const float* aos, uint32_t n, uint32_t capacity,
+                               float* color, float* cov, gso_splat* splats /* may be NULL */,
+                               uint32_t* list_tile, uint32_t* list_depth, uint32_t* list_id,
+                               uint32_t threads);
+void gso_sort_stable_mt(uint32_t* tile, uint32_t* depth, uint32_t* id, uint32_t e, uint32_t threads);
+void gso_render_mt(const gso_params* p, const float* aos, const float* color, const float* cov,
+                   const uint32_t* sorted_id, const uint32_t* ranges, uint8_t* rgba_out,
+                   uint32_t threads);
+
 /* Camera (Camera.cpp:7-48 over glm 0.9.9.8 lookAtRH / perspectiveRH_ZO). */
 void gso_camera_matrices(const float pos[3], float yaw, float pitch, float aspect,
                          float near_plane, float far_plane, float* view16, float* proj16);

@@ -45,3 +45,27 @@ def default_camera(oracle, width, height, pos=(0.0, 0.0, 0.0), yaw=0.0, pitch=0.
 def small_cloud():
     from vk3dgaussiansplatting_amd import synth
     return synth.generate(3000, 320, 180, -3.2, seed=11)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _cached_synth_clouds():
+    """Configs C and D are the same cloud (same N, aspect, mu, seed) and take ~40 s to generate: keep the last few
+    generated clouds for the session."""
+    import functools
+    from vk3dgaussiansplatting_amd import synth
+    orig = synth.generate
+    cache = {}
+
+    @functools.wraps(orig)
+    def cached(n, width, height, mu, seed, morton=True, chunk=400_000):
+        key = (n, round(width / height, 9), mu, seed, morton)
+        if n < 1_000_000 or n > 10_000_000:
+            return orig(n, width, height, mu, seed, morton, chunk)
+        if key not in cache:
+            cache.clear()                          # at most one big cloud alive
+            cache[key] = orig(n, width, height, mu, seed, morton, chunk)
+        return cache[key].copy()
+
+    synth.generate = cached
+    yield
+    synth.generate = orig

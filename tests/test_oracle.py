@@ -32,6 +32,46 @@ def test_committed_fixture_is_what_the_reference_code_produces():
     assert out == open(os.path.join(GOLDEN, "ref_glm_smath.json"), "rb").read()
 
 
+def test_common_glsl_cross_check(oracle_mod):
+    """CROSS-CHECK, not a pin: tests/golden/ref_common_glsl.npz is what the reference's own Common.glsl text returns
+    when compiled as C++ over its vendored glm (oracle/ref_glsl_xcheck.cpp) for the 600 golden splats.  The
+    oracle's covariance (getRotMat + getCovarianceMatrix, Common.glsl:17-78), screen position (:80-89) and colour in
+    all three SH modes (:94-170) are bit-identical to it for every splat that survives the culls -- which rules out
+    a shared misreading of constructors, product order or operand order.  (glm folds `tan(FOV_Y * 0.5f)` with tanf;
+    the oracle folds it in double: same float here.)  Where the reference is mounted the committed dump is
+    regenerated and compared first."""
+    from conftest import ROOT
+    g = np.load(os.path.join(GOLDEN, "small_scene.npz"))
+    x = np.load(os.path.join(GOLDEN, "ref_common_glsl.npz"))
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_glsl_xcheck")
+    if os.path.isdir("/root/reference/vkGaussianSplatting") and os.path.exists(exe):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("make_glsl_xcheck", os.path.join(GOLDEN, "make_glsl_xcheck.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        fresh = mod.run(g["aos"], g["view"], g["proj"], g["cam_pos"], int(g["width"]), int(g["height"]))
+        for k, v in fresh.items():
+            assert v.tobytes() == x[k].tobytes(), k
+    w, h = int(g["width"]), int(g["height"])
+    import ctypes
+    tan_oracle = np.array([oracle_mod.lib().gso_tan_half_fov(ctypes.c_float(3.1415 * 0.5))], np.float32)
+    assert tan_oracle.view(np.uint32)[0] == x["tan_half_fov"].view(np.uint32)[0]
+    for mode in (0, 1, 2):
+        p = oracle_mod.make_params(w, h, g["view"], g["proj"], g["cam_pos"], sh_mode=mode)
+        s1 = oracle_mod.init_sort_list(p, g["aos"])
+        vis = s1["splats"]["visible"].astype(bool)
+        assert vis.sum() > 400
+        assert np.array_equal(s1["color"][vis, :3].view(np.uint32), x["color"][mode][vis].view(np.uint32))
+        if mode == 0:
+            assert np.array_equal(s1["cov"][vis, :3].view(np.uint32), x["cov"][vis].view(np.uint32))
+            scr = np.stack([s1["splats"]["screen_x"], s1["splats"]["screen_y"]], axis=1)
+            assert np.array_equal(scr[vis].view(np.uint32), x["screen"][vis].view(np.uint32))
+    # for the record: glm's own mat4 * vec4 associates (m0 x + m1 y) + (m2 z + m3 w); the restatements (and the dump's
+    # inputs) use GLSL's textual left-to-right order.  They agree to a few ulp, not bit for bit.
+    a, b = x["viewpos_glm"].astype(np.float64), x["viewpos_in"].astype(np.float64)
+    assert np.all(np.abs(a - b) <= 4 * np.spacing(np.abs(x["viewpos_in"]).max(axis=1, keepdims=True)).astype(np.float64))
+
+
 def test_camera_matrices_match_reference_glm(oracle_mod, ref_golden):
     """view/proj bit-identical to glm::lookAt / glm::perspective run from /root/reference (Camera.cpp:7-48)."""
     for cam in ref_golden["cameras"]:
@@ -197,6 +237,40 @@ def test_threaded_frame_equals_single_thread_frame(oracle_mod, small_cloud, thre
     a, ea, _ = oracle_mod.frame(band, small_cloud)
     b, eb, _ = oracle_mod.frame_mt(band, small_cloud, threads)
     assert ea == eb and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("threads", [2, 5])
+def test_threaded_stage_functions_equal_single_thread(oracle_mod, small_cloud, threads):
+    """gso_init_sort_list_mt / gso_sort_stable_mt / gso_render_mt (what the full-size GPU parity tests check
+    against) give every intermediate of the single-thread stages: lists incl. the 0xFF tail, colour, covariance,
+    per-splat records, sorted order with heavy ties, ranges, pixels -- also with an overflowing list and a band."""
+    from vk3dgaussiansplatting_amd import synth
+    w, h = 320, 180
+    view, proj, pos = default_camera(oracle_mod, w, h)
+    big = synth.generate(500, w, h, -0.5, seed=5)             # large footprints: many equal (tile, depth) pairs
+    for aos, kw, cap in ((small_cloud, {}, None), (small_cloud, dict(row_begin=3, row_end=7), None), (big, {}, 1024)):
+        p = oracle_mod.make_params(w, h, view, proj, pos, **kw)
+        a = oracle_mod.init_sort_list(p, aos, cap=cap)
+        b = oracle_mod.init_sort_list(p, aos, cap=cap, threads=threads)
+        assert a["counter"] == b["counter"]
+        for k in ("tile", "depth", "id", "color", "cov"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+        assert a["splats"].tobytes() == b["splats"].tobytes()
+        e = min(a["counter"], a["capacity"])
+        sa = oracle_mod.sort_stable(a["tile"], a["depth"], a["id"], e)
+        sb = oracle_mod.sort_stable(a["tile"], a["depth"], a["id"], e, threads=threads)
+        for x, y in zip(sa, sb):
+            assert np.array_equal(x, y)
+        if cap is None:
+            gw, gh = oracle_mod.grid(w, h)
+            ranges = oracle_mod.find_ranges(sa[0], e, gw * gh)
+            ia = oracle_mod.render(p, aos, a["color"], a["cov"], sa[2], ranges)
+            ib = oracle_mod.render(p, aos, a["color"], a["cov"], sa[2], ranges, threads=threads)
+            assert np.array_equal(ia, ib)
+    r1 = oracle_mod.full_pipeline(oracle_mod.make_params(w, h, view, proj, pos), small_cloud)
+    r2 = oracle_mod.full_pipeline(oracle_mod.make_params(w, h, view, proj, pos), small_cloud, threads=threads,
+                                  want_splats=False, keep_unsorted=False)
+    assert r1["e"] == r2["e"] and np.array_equal(r1["image"], r2["image"]) and np.array_equal(r1["id"], r2["id"])
 
 
 def test_empty_view_is_black(oracle_mod, small_cloud):

@@ -105,6 +105,12 @@ def test_golden_fixture(sh_mode):
     emits[g["id"]] = True
     assert np.array_equal(r.debugRead(gs.BUF_COLOR)[emits].view(np.uint32), g[f"color_mode{sh_mode}"][emits].view(np.uint32))
     assert np.array_equal(img, g[f"image_mode{sh_mode}"])
+    # cross-check (not a pin): the same splats through the reference's own Common.glsl text compiled over its glm
+    # (tests/golden/ref_common_glsl.npz, oracle/ref_glsl_xcheck.cpp) -- colour and covariance straight from the HIP
+    # path, no oracle in between
+    x = np.load(os.path.join(GOLDEN, "ref_common_glsl.npz"))
+    assert np.array_equal(r.debugRead(gs.BUF_COLOR)[emits, :3].view(np.uint32), x["color"][sh_mode][emits].view(np.uint32))
+    assert np.array_equal(r.debugRead(gs.BUF_COV)[emits, :3].view(np.uint32), x["cov"][emits].view(np.uint32))
     r.cleanup()
 
 
@@ -278,59 +284,83 @@ def test_config_a_fast_mode_within_one_step(oracle_mod):
     r.cleanup()
 
 
-def test_config_b_full_size_keys_and_ranges(oracle_mod):
-    """BASELINE config B (Train-7k shape: 559,263 gaussians @ 1280x720, E = 3.48 M), both sort back-ends."""
-    aos, cfg = synth.generate_config("B")
+def full_size_parity(oracle_mod, name, sorts, capacity, sort_bits, pixel_tile_rows=None, e_readme=None):
+    """One BASELINE config at full size: element counter, sort keys, payload order and tile ranges bit-exact against
+    the oracle for every sorter in `sorts`; pixels bit-exact over the WHOLE frame (pixel_tile_rows = None) or on the
+    given tile rows.  The oracle runs its threaded stage functions (gso_*_mt: same outputs as the single-thread ones,
+    tests/test_oracle.py) on the box's host cores."""
+    aos, cfg = synth.generate_config(name)
     w, h = cfg["width"], cfg["height"]
     sc = make_scene(aos, w, h)
     cam = sc.getCamera()
+    threads = oracle_mod.host_threads()
+    gw, gh = oracle_mod.grid(w, h)
     p = oracle_mod.make_params(w, h, cam.getViewMatrix(), cam.getProjectionMatrix(), cam.getPosition())
-    s1 = oracle_mod.init_sort_list(p, aos)
-    e = s1["counter"]
-    assert abs(e / 3_487_911 - 1) < 0.01                   # README.md:76
-    ot, od, oi = oracle_mod.sort_stable(s1["tile"], s1["depth"], s1["id"], e)
-    oranges = oracle_mod.find_ranges(ot, e, 80 * 45)
-    band = oracle_mod.render(oracle_mod.make_params(w, h, cam.getViewMatrix(), cam.getProjectionMatrix(),
-                                                    cam.getPosition(), row_begin=20, row_end=22),
-                             aos, s1["color"], s1["cov"], oi, oranges)
-    for sort in (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET):
+    s1 = oracle_mod.init_sort_list(p, aos, threads=threads, want_splats=False)
+    e = min(s1["counter"], s1["capacity"])
+    assert s1["capacity"] == capacity and s1["counter"] <= capacity
+    if e_readme is not None:
+        assert abs(e / e_readme - 1) < 0.01                 # README "Elements To Sort" of the shape
+    ot, od, oi = oracle_mod.sort_stable(s1["tile"], s1["depth"], s1["id"], e, threads=threads, inplace=True)
+    oranges = oracle_mod.find_ranges(ot, e, gw * gh)
+    if pixel_tile_rows is None:
+        ref_img = oracle_mod.render(p, aos, s1["color"], s1["cov"], oi, oranges, threads=threads)
+        row_sel = slice(0, h)
+    else:
+        ref_img = np.zeros((h, w, 4), np.uint8)
+        for tr in pixel_tile_rows:
+            pb = oracle_mod.make_params(w, h, cam.getViewMatrix(), cam.getProjectionMatrix(), cam.getPosition(),
+                                        row_begin=tr, row_end=tr + 1)
+            oracle_mod.render(pb, aos, s1["color"], s1["cov"], oi, oranges, out=ref_img, threads=threads)
+        row_sel = np.concatenate([np.arange(tr * 16, min(tr * 16 + 16, h)) for tr in pixel_tile_rows])
+    for sort in sorts:
         r = make_renderer(sc, w, h, sort=sort)
         img = r.draw(sc)
-        assert r.sceneInfo().capacity == 2**23 and r.sceneInfo().num_sort_bits == 44
-        assert r.timings().num_sort_elements == e
-        assert np.array_equal(r.debugRead(gs.BUF_SORTED_TILE), ot[:e])
+        info, t = r.sceneInfo(), r.timings()
+        assert info.capacity == capacity and info.num_sort_bits == sort_bits
+        assert t.num_sort_elements == e and t.emitted_elements == s1["counter"] and t.overflowed == 0
+        tile = r.debugRead(gs.BUF_SORTED_TILE)
+        assert np.array_equal(tile, ot[:e])
         assert np.array_equal(r.debugRead(gs.BUF_SORTED_DEPTH), od[:e])
         assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), oi[:e])
-        assert np.array_equal(r.debugRead(gs.BUF_RANGES), oranges)
-        assert np.array_equal(img[320:352], band[320:352])
+        ranges = r.debugRead(gs.BUF_RANGES)
+        assert np.array_equal(ranges, oranges)
+        # size-independent invariants of the product's own output
+        lens = ranges[:, 1].astype(np.int64) - ranges[:, 0]
+        assert lens.sum() == e and np.all(lens >= 0)        # ranges partition [0, E)
+        assert np.array_equal(np.bincount(tile, minlength=ranges.shape[0]), lens)
+        assert np.array_equal(img[row_sel], ref_img[row_sel]), f"pixels differ (sorter {sort})"
+        assert np.all(img[..., 3] == 255)
         r.cleanup()
+        del tile, ranges, img
+    return e
 
 
-def test_config_d_4k_keys_and_ranges(oracle_mod):
-    """BASELINE config D shape (Garden-30k @ 3840x2160, 32,400 tiles, E = 33 M): keys/ranges bit-exact for the
-    contractual sorter; the alternative sorter must give the same bytes."""
-    aos, cfg = synth.generate_config("D")
-    w, h = cfg["width"], cfg["height"]
-    sc = make_scene(aos, w, h)
-    cam = sc.getCamera()
-    p = oracle_mod.make_params(w, h, cam.getViewMatrix(), cam.getProjectionMatrix(), cam.getPosition())
-    s1 = oracle_mod.init_sort_list(p, aos)
-    e = s1["counter"]
-    ot, od, oi = oracle_mod.sort_stable(s1["tile"], s1["depth"], s1["id"], e)
-    oranges = oracle_mod.find_ranges(ot, e, 240 * 135)
-    outs = []
-    for sort in (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET):
-        r = make_renderer(sc, w, h, sort=sort)
-        img = r.draw(sc)
-        assert r.sceneInfo().capacity == 2**26 and r.sceneInfo().num_sort_bits == 48
-        assert r.timings().num_sort_elements == e and r.timings().overflowed == 0
-        assert np.array_equal(r.debugRead(gs.BUF_SORTED_TILE), ot[:e])
-        assert np.array_equal(r.debugRead(gs.BUF_SORTED_DEPTH), od[:e])
-        assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), oi[:e])
-        assert np.array_equal(r.debugRead(gs.BUF_RANGES), oranges)
-        outs.append(img.copy())
-        r.cleanup()
-    assert np.array_equal(outs[0], outs[1])
+def test_config_b_full_frame(oracle_mod):
+    """BASELINE config B (Train-7k shape: 559,263 gaussians @ 1280x720, E = 3.48 M), both sort back-ends: keys, ranges
+    and EVERY pixel of the frame bit-exact (README.md:76)."""
+    full_size_parity(oracle_mod, "B", (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET), 2**23, 44, e_readme=3_487_911)
+
+
+def test_config_c_full_frame(oracle_mod):
+    """BASELINE config C, the headline (Garden-30k shape: 5,834,784 gaussians @ 1920x1080, E = 13.1 M, README.md:61):
+    keys, ranges and all 1920x1080 pixels bit-exact, both sort back-ends."""
+    full_size_parity(oracle_mod, "C", (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET), 2**24, 48, e_readme=13_098_506)
+
+
+def test_config_d_4k_full_frame(oracle_mod):
+    """BASELINE config D shape (Garden-30k @ 3840x2160, 32,400 tiles, E = 33 M): keys, ranges and all 3840x2160
+    pixels bit-exact, both sort back-ends."""
+    full_size_parity(oracle_mod, "D", (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET), 2**26, 48)
+
+
+def test_config_e_full_size(oracle_mod):
+    """BASELINE config E (stress: 50 M gaussians @ 1920x1080, capacity 2^26, E = 53 M): the whole frame through
+    k_project / k_emit at N = 5e7 and the 64-bit element counter; counter, keys, payload order, ranges bit-exact,
+    pixels bit-exact on six tile rows spread over the frame (a full-frame CPU blend of 6.5 k-entry tile lists
+    would take minutes)."""
+    e = full_size_parity(oracle_mod, "E", (gs.GS_SORT_RADIX4,), 2**26, 48, pixel_tile_rows=(0, 13, 27, 34, 50, 67))
+    assert e > 50_000_000
 
 
 def test_extreme_but_finite_inputs(oracle_mod):
@@ -408,45 +438,6 @@ def test_cpp_driver_runs(tmp_path):
     data = open(ppm, "rb").read()
     assert data.startswith(b"P6\n640 360\n255\n") and len(data) == 15 + 640 * 360 * 3
     assert max(data[15:]) > 0
-
-
-def test_config_c_full_size_properties(oracle_mod):
-    """BASELINE config C (Garden-30k shape: 5,834,784 gaussians @ 1920x1080): keys and ranges
-    bit-exact against the oracle, pixels bit-exact on a band of tile rows (the oracle's blend is
-    too slow for the whole frame), plus size-independent invariants."""
-    aos, cfg = synth.generate_config("C")
-    w, h = cfg["width"], cfg["height"]
-    sc = make_scene(aos, w, h)
-    r = make_renderer(sc, w, h)
-    img = r.draw(sc)
-    info = r.sceneInfo()
-    assert info.capacity == 2**24 and info.num_sort_bits == 48
-    e = r.timings().num_sort_elements
-    assert abs(e / 13_098_506 - 1) < 0.01                 # README.md:61 "Elements To Sort" shape
-    tile, depth, ident = (r.debugRead(b) for b in (gs.BUF_SORTED_TILE, gs.BUF_SORTED_DEPTH, gs.BUF_SORTED_ID))
-    key = (tile.astype(np.uint64) << np.uint64(32)) | depth.astype(np.uint64)
-    assert np.all(key[1:] >= key[:-1])                     # sortedness
-    ranges = r.debugRead(gs.BUF_RANGES).astype(np.int64)
-    lens = ranges[:, 1] - ranges[:, 0]
-    assert lens.sum() == e and np.all(lens >= 0)           # ranges partition [0, E)
-    assert np.array_equal(np.bincount(tile, minlength=ranges.shape[0]), lens)
-    # oracle: stages 1-3 at full size
-    cam = sc.getCamera()
-    p = oracle_mod.make_params(w, h, cam.getViewMatrix(), cam.getProjectionMatrix(), cam.getPosition())
-    s1 = oracle_mod.init_sort_list(p, aos)
-    assert s1["counter"] == r.timings().emitted_elements == e
-    ot, od, oi = oracle_mod.sort_stable(s1["tile"], s1["depth"], s1["id"], e)
-    assert np.array_equal(tile, ot[:e]) and np.array_equal(depth, od[:e]) and np.array_equal(ident, oi[:e])
-    oranges = oracle_mod.find_ranges(ot, e, ranges.shape[0])
-    assert np.array_equal(ranges, oranges)
-    # pixels: two bands of tile rows (top and middle)
-    for rb, re in ((0, 1), (33, 34)):
-        pb = oracle_mod.make_params(w, h, cam.getViewMatrix(), cam.getProjectionMatrix(), cam.getPosition(),
-                                    row_begin=rb, row_end=re)
-        band = oracle_mod.render(pb, aos, s1["color"], s1["cov"], oi, oranges)
-        rows = slice(rb * 16, re * 16)
-        assert np.array_equal(img[rows], band[rows])
-    r.cleanup()
 
 
 @pytest.mark.parametrize("n,w,h,mu", [
@@ -666,15 +657,108 @@ def test_shared_scene_frames_in_flight(oracle_mod, small_cloud):
     torch.cuda.synchronize()
     for img in imgs:
         assert np.array_equal(img.cpu().numpy(), ref["image"])
-    L = _lib.lib()
-    assert L.gs_destroy(owner._ctx.handle) == _lib.GS_ERR_INVALID          # still borrowed
-    assert b"shared" in L.gs_last_error(owner._ctx.handle)
-    g = np.ascontiguousarray(small_cloud, dtype=np.float32)
-    assert L.gs_upload_gaussians(owner._ctx.handle, g.ctypes.data_as(C.c_void_p), g.shape[0]) == _lib.GS_ERR_INVALID
-    assert L.gs_share_scene(slots[1]._ctx.handle, slots[2]._ctx.handle) == _lib.GS_ERR_INVALID   # a borrower cannot lend
-    for r in reversed(slots):
+    # the arrays are reference-counted: the context that uploaded them goes first, the others keep rendering them;
+    # a context that only shares can itself be shared from; a new upload on one leaves the others' arrays alone
+    for r in slots:
         r.setStream(None)
+    owner.cleanup()
+    third = gs.Renderer(w, h, warmup_frames=0)
+    third.init(sc.getResourceManager())
+    third.initForScene(sc, share_with=slots[1])
+    other = synth.generate(500, w, h, -3.0, seed=3)
+    g = np.ascontiguousarray(other, dtype=np.float32)
+    L = _lib.lib()
+    assert L.gs_upload_gaussians(slots[2]._ctx.handle, g.ctypes.data_as(C.c_void_p), g.shape[0]) == 0
+    for r in (slots[1], third):
+        assert np.array_equal(r.draw(sc), ref["image"])
+    slots[1].cleanup()
+    assert np.array_equal(third.draw(sc), ref["image"])
+    third.cleanup()
+    slots[2].cleanup()
+
+
+@pytest.mark.parametrize("sort", [gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_interleaved_tile_rows(oracle_mod, small_cloud, world, sort):
+    """gs_set_tile_rows_interleaved: rank r of R renders tile rows r, r + R, ...  Its sorted list is the full frame's
+    list restricted to its tiles (global tile ids, same per-tile order), its ranges the lengths of those tiles, and
+    the strips -- written packed, the way they are gathered -- assemble into the one-GPU image."""
+    import torch
+    from vk3dgaussiansplatting_amd import dist as gsdist
+    w, h = 320, 180                                            # 20 x 12 tiles, last row partial
+    sc = make_scene(small_cloud, w, h, pos=(0.2, 0.1, -1.0), yaw=0.1, pitch=-0.05)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    e, gw, gh = ref["e"], 20, 12
+    r = make_renderer(sc, w, h, sort=sort)
+    dev = torch.device("cuda:0")
+    strips = []
+    for rank in range(world):
+        r.setTileRowsInterleaved(rank, world)
+        info = r.sceneInfo()
+        rows = gsdist.interleaved_rows(gh, rank, world)
+        assert (info.row_stride, info.first_row, info.rows_owned) == (world, rank, len(rows))
+        sf = gsdist.ShardedFrame(w, h, rank, world, device=dev, n_strips=1, interleaved=True)
+        r.drawDevice(sc, sf.strips[0].data_ptr(), sync=True)
+        strips.append(sf.strips[0].clone())
+        mine = np.isin(ref["tile"][:e] // gw, rows)
+        assert r.timings().num_sort_elements == mine.sum()
+        assert np.array_equal(r.debugRead(gs.BUF_SORTED_TILE), ref["tile"][:e][mine])
+        assert np.array_equal(r.debugRead(gs.BUF_SORTED_DEPTH), ref["depth"][:e][mine])
+        assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), ref["id"][:e][mine])
+        rg = r.debugRead(gs.BUF_RANGES).astype(np.int64)
+        own_tiles = np.isin(np.arange(gw * gh) // gw, rows)
+        lens = ref["ranges"][:, 1].astype(np.int64) - ref["ranges"][:, 0]
+        assert np.array_equal((rg[:, 1] - rg[:, 0])[own_tiles], lens[own_tiles])
+        # the host-image path of the same context writes real rows
+        img = r.draw(sc)
+        for row in rows:
+            assert np.array_equal(img[row * 16:row * 16 + 16], ref["image"][row * 16:row * 16 + 16])
+    full = gsdist.ShardedFrame(w, h, 0, world, device=dev, n_strips=1, interleaved=True).assemble(strips)
+    assert np.array_equal(full.cpu().numpy(), ref["image"])
+    r.setTileRows(0, gh)                                       # back to the whole frame
+    assert np.array_equal(r.draw(sc), ref["image"])
+    r.cleanup()
+
+
+def test_band_block_cull_keeps_every_emitting_splat(oracle_mod):
+    """A context with a subset of the tile rows drops whole 256-splat workgroups from one bounding record (k_project):
+    on a Morton-ordered cloud most are dropped, and what is left must still be exactly the oracle's band list -- for
+    narrow bands, for a rotated camera, and with splats whose footprint spans many rows."""
+    w, h = 640, 360
+    aos = synth.generate(60_000, w, h, -3.4, seed=41)
+    aos[::97, 4:7] *= 40.0                                     # a few huge splats that reach far-away rows
+    for pos, yaw, pitch in (((0.0, 0.0, 0.0), 0.0, 0.0), ((0.5, -0.3, -1.5), 0.3, -0.2)):
+        sc = make_scene(aos, w, h, pos=pos, yaw=yaw, pitch=pitch)
+        r = make_renderer(sc, w, h)
+        for rb, re in ((0, 1), (11, 12), (5, 8), (22, 23)):
+            r.setTileRows(rb, re)
+            img = r.draw(sc)
+            _, band = oracle_run(oracle_mod, sc, w, h, row_begin=rb, row_end=re)
+            e = band["e"]
+            assert r.timings().num_sort_elements == e and e > 0
+            assert np.array_equal(r.debugRead(gs.BUF_SORTED_TILE), band["tile"][:e])
+            assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), band["id"][:e])
+            assert np.array_equal(r.debugRead(gs.BUF_RANGES), band["ranges"])
+            rows = slice(rb * 16, min(re * 16, h))
+            assert np.array_equal(img[rows], band["image"][rows])
         r.cleanup()
+
+
+def test_host_timers(small_cloud):
+    """RECORD_CPU_TIMES figures (Renderer.cpp:399-456) through gs_get_host_timings."""
+    w, h = 320, 180
+    sc = make_scene(small_cloud, w, h)
+    r = make_renderer(sc, w, h)
+    r.draw(sc)
+    r.draw(sc)
+    t = r.hostTimings()
+    assert t["record_commands"] > 0 and t["wait_for_gpu"] >= 0 and t["present"] > 0
+    assert t["cpu_frame"] >= t["record_commands"]              # entry to entry covers the whole previous call
+    r.drawDevice(sc, None, sync=False)
+    r.synchronize()
+    t = r.hostTimings()
+    assert t["wait_for_gpu"] == 0 and t["present"] == 0 and t["record_commands"] > 0
+    r.cleanup()
 
 
 def test_grid_beyond_16_bit_tile_ids(oracle_mod):

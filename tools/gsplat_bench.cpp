@@ -24,7 +24,7 @@ static float uni(uint64_t& s) { return (float)((sm(s) >> 40) * (1.0 / 16777216.0
 
 int main(int argc, char** argv) {
     std::string ply, scene = "origin", ppm;
-    uint32_t n_syn = 0, w = 1280, h = 720, warmup = 100, frames = 1000;   // window 1280x720: Engine.cpp:35
+    uint32_t n_syn = 0, w = 1280, h = 720, warmup = 1000, frames = 1000;   // window 1280x720: Engine.cpp:35; WAIT_ELAPSED_*_FRAMES_FOR_AVG: Renderer.h:142-143
     bool fast = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
 
     gs_config cfg; gs_default_config(&cfg);
     cfg.render_mode = fast ? GS_RENDER_FAST : GS_RENDER_EXACT;
+    cfg.record_timings = 1;                                  // RECORD_GPU_TIMES (GfxSettings.h:7) on: this is the benchmark build
     gs_ctx* ctx = nullptr;
     if (gs_create(&cfg, &ctx) != GS_OK) { fprintf(stderr, "[Log Error]: %s\n", gs_last_error(nullptr)); return 1; }
 
@@ -77,6 +78,7 @@ int main(int argc, char** argv) {
     gs_scene_info info; gs_get_scene_info(ctx, &info);
     printf("[Log]: Number of gaussians: %u   sort list capacity: %u   passes: %u\n", info.num_gaussians, info.capacity, info.num_sort_bits / 4);
     double avg[5] = {0, 0, 0, 0, 0};
+    double havg[4] = {0, 0, 0, 0};                           // RECORD_CPU_TIMES averages (Renderer.cpp:430-433)
     gs_timings t{};
     for (uint32_t f = 0; f < warmup + frames; ++f) {        // Engine.cpp:45-78 / Renderer.cpp:477-488
         int rc = gs_render_device(ctx, view, proj, pos, 0, nullptr);
@@ -86,12 +88,18 @@ int main(int argc, char** argv) {
             const double k = 1.0 / (double)(f - warmup + 1);
             const double v[5] = {t.init_sort_list_ms, t.radix_sort_ms, t.find_ranges_ms, t.render_ms, t.total_ms};
             for (int b = 0; b < 5; ++b) avg[b] = (1.0 - k) * avg[b] + k * v[b];
+            gs_host_timings ht{};
+            gs_get_host_timings(ctx, &ht);
+            const double hv[4] = {ht.wait_ms, ht.record_ms, ht.present_ms, ht.cpu_frame_ms};
+            for (int b = 0; b < 4; ++b) havg[b] = (1.0 - k) * havg[b] + k * hv[b];
         }
     }
     printf("elements to sort: %u%s\n", t.num_sort_elements, t.overflowed ? " (overflowed, truncated)" : "");
     printf("init sort list ms: %.3f\nsort ms: %.3f\nfind ranges ms: %.3f\nrender gaussians ms: %.3f\ntotal gpu time ms: %.3f\n",
            avg[0], avg[1], avg[2], avg[3], avg[4]);
     printf("Msplats/s: %.1f\n", info.num_gaussians / avg[4] / 1000.0);
+    printf("waitForFence ms: %.4f\nrecordCommandBuffer ms: %.4f\npresent ms: %.4f\nCPU frame time ms: %.4f\n",
+           havg[0], havg[1], havg[2], havg[3]);
     if (!ppm.empty()) {
         std::vector<uint8_t> img((size_t)w * h * 4);
         gs_debug_read(ctx, GS_BUF_IMAGE, img.data(), img.size());

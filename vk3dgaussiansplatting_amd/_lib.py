@@ -82,6 +82,19 @@ class GsSceneInfo(C.Structure):
         ("row_begin", C.c_uint32),
         ("row_end", C.c_uint32),
         ("tile_word_bytes", C.c_uint32),
+        ("row_stride", C.c_uint32),
+        ("first_row", C.c_uint32),
+        ("rows_owned", C.c_uint32),
+    ]
+
+
+class GsHostTimings(C.Structure):
+    """gs_host_timings: the RECORD_CPU_TIMES figures (Renderer.cpp:399-456)."""
+    _fields_ = [
+        ("wait_ms", C.c_float),
+        ("record_ms", C.c_float),
+        ("present_ms", C.c_float),
+        ("cpu_frame_ms", C.c_float),
     ]
 
 
@@ -92,6 +105,7 @@ EXPORTS = [
     "gs_get_scene_info", "gs_render", "gs_render_device", "gs_render_device_async",
     "gs_synchronize", "gs_get_timings", "gs_debug_read", "gs_debug_init_sort_list",
     "gs_set_stream", "gs_camera_matrices", "gs_sort_host", "gs_sort_bench", "gs_membench", "gs_write_image", "gs_share_scene",
+    "gs_get_host_timings", "gs_set_tile_rows_interleaved",
 ]
 
 
@@ -150,5 +164,7 @@ def lib() -> C.CDLL:
     L.gs_membench.argtypes = [ctxp, C.c_int, C.c_size_t, u32, u32, C.POINTER(f32), C.POINTER(f32)]
     L.gs_write_image.argtypes = [C.c_char_p, vp, u32, u32]
     L.gs_share_scene.argtypes = [ctxp, ctxp]
+    L.gs_get_host_timings.argtypes = [ctxp, C.POINTER(GsHostTimings)]
+    L.gs_set_tile_rows_interleaved.argtypes = [ctxp, u32, u32, u32]
     _lib = L
     return L

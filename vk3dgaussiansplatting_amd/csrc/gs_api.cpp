@@ -6,6 +6,8 @@
 #include "../../include/gsplat.h"
 #include "gs_internal.h"
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -16,6 +18,16 @@
 using namespace gs;
 
 static thread_local std::string g_create_error;
+
+// The uploaded gaussian arrays (read-only on the path), reference-counted so that the contexts that render them
+// (gs_share_scene: frame slots, tile-row bands) can be destroyed in any order.
+struct SharedScene {
+    SceneBuffers b{};
+    uint32_t n = 0;
+    std::atomic<uint32_t> refs{1};
+};
+
+using HostClock = std::chrono::steady_clock;
 
 struct gs_ctx {
     gs_config cfg{};
@@ -34,17 +46,18 @@ struct gs_ctx {
     SceneBuffers scene{};
     SplatScratch scratch{};
     uint32_t num_blocks = 0;
-    gs_ctx* scene_owner = nullptr;    // gs_share_scene: the gaussian arrays belong to that context
-    uint32_t borrowers = 0;           // contexts currently sharing this context's arrays
+    SharedScene* shared = nullptr;    // owner of `scene`'s arrays (this context holds one reference)
 
     // resolution-dependent
     uint32_t width = 0, height = 0, grid_w = 0, grid_h = 0;
-    uint32_t row_begin = 0, row_end = 0;
+    // tile rows of this context: first_row + k * row_stride < row_end, k < rows_owned (FrameParams)
+    uint32_t row_begin = 0, row_end = 0, row_stride = 1, first_row = 0, rows_owned = 0;
+    bool compact_out = false;
     uint32_t capacity = 0, num_sort_bits = 0;
-    // what the sort of the current tile-row band runs over: tile ids relative to the band's first tile, so
-    // ceil((32 + bits(T_band - 1)) / 4) passes (the reference's formula, RadixSort.cpp:203-204, for the band's T)
-    uint32_t band_sort_bits = 0, band_tile_bias = 0;
-    bool hi16 = false;   // the frame's sort list stores tile ids as uint16 relative to band_tile_bias (band <= 65535 tiles)
+    // what the sort of the owned tiles runs over: compact tile ids, so ceil((32 + bits(T_owned - 1)) / 4) passes
+    // (the reference's formula, RadixSort.cpp:203-204, for the context's own tile count)
+    uint32_t band_sort_bits = 0;
+    bool hi16 = false;   // the frame's sort list stores the compact tile ids as uint16 (at most 65535 owned tiles)
     SortBuffers sort{};
     uint32_t* ranges = nullptr;
     uint8_t* framebuffer = nullptr;
@@ -58,6 +71,9 @@ struct gs_ctx {
     bool depth_dropped = false;   // last frame's tile-word passes did not carry the depth words (see k_scatter)
 
     gs_timings timings{};
+    gs_host_timings host{};           // RECORD_CPU_TIMES (Renderer.cpp:299-456)
+    HostClock::time_point last_entry{};
+    bool have_entry = false;
     bool have_frame = false;
     bool unsorted_valid = false;   // last thing run was gs_debug_init_sort_list
 };
@@ -83,13 +99,16 @@ void free_dev(T*& p) {
 }
 
 void free_scene(gs_ctx* c) {
-    if (c->scene_owner) {             // borrowed arrays: hand them back, free only what is ours
-        if (c->scene_owner->borrowers) --c->scene_owner->borrowers;
-        c->scene_owner = nullptr;
-        c->scene = SceneBuffers{};
+    if (c->shared) {                  // drop this context's reference; the last one frees the arrays
+        if (c->shared->refs.fetch_sub(1) == 1) {
+            SceneBuffers& b = c->shared->b;
+            free_dev(b.pos); free_dev(b.scale); free_dev(b.rot);
+            free_dev(b.sh); free_dev(b.opacity); free_dev(b.sig2); free_dev(b.block_bounds);
+            delete c->shared;
+        }
+        c->shared = nullptr;
     }
-    free_dev(c->scene.pos); free_dev(c->scene.scale); free_dev(c->scene.rot);
-    free_dev(c->scene.sh); free_dev(c->scene.opacity); free_dev(c->scene.sig2);
+    c->scene = SceneBuffers{};
     free_dev(c->scratch.raster); free_dev(c->scratch.depth_key); free_dev(c->scratch.tiles_touched);
     free_dev(c->scratch.extents); free_dev(c->scratch.block_sums); free_dev(c->scratch.block_offsets);
     c->n = 0;
@@ -154,13 +173,14 @@ FrameParams make_frame_params(const gs_ctx* c, const float* view, const float* p
     fp.width = c->width; fp.height = c->height;
     fp.grid_w = c->grid_w; fp.grid_h = c->grid_h;
     fp.row_begin = c->row_begin; fp.row_end = c->row_end;
+    fp.row_stride = c->row_stride; fp.first_row = c->first_row; fp.rows_owned = c->rows_owned;
+    fp.compact_out = c->compact_out ? 1u : 0u;
     fp.num_gaussians = c->n;
     fp.capacity = c->capacity;
     fp.near_plane = c->cfg.near_plane; fp.far_plane = c->cfg.far_plane;
     fp.ndc_cull = c->cfg.ndc_cull; fp.in_view_limit = c->cfg.in_view_limit;
     fp.tan_fov_y = (float)std::tan((double)(c->cfg.fov_y * 0.5f));   // Common.glsl:53, host-folded
     fp.hi16 = c->hi16 ? 1u : 0u;
-    fp.tile_bias = c->band_tile_bias;
     fp.w_frob2 = 0.0f;
     for (int col = 0; col < 3; ++col)
         for (int row = 0; row < 3; ++row) fp.w_frob2 += view[col * 4 + row] * view[col * 4 + row];
@@ -174,7 +194,8 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     if (!c->capacity) return fail(c, GS_ERR_NO_SCENE, "gs_render: gs_set_resolution not called");
     if (!view || !proj || !cam_pos) return fail(c, GS_ERR_INVALID, "gs_render: null camera argument");
     if (sh_mode > 2u) return fail(c, GS_ERR_INVALID, "gs_render: sh_mode must be 0, 1 or 2");
-    const FrameParams fp = make_frame_params(c, view, proj, cam_pos, sh_mode);
+    FrameParams fp = make_frame_params(c, view, proj, cam_pos, sh_mode);
+    if (!out_dev) fp.compact_out = 0u;   // the internal framebuffer is always a whole frame in real rows
     const bool tm = c->cfg.record_timings != 0;
     hipStream_t st = c->stream;
 
@@ -198,7 +219,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
         bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
             c->sort_graph_result = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, nullptr,
-                                                     bucket ? 32u : 0u, c->band_tile_bias, !bucket, c->hi16);
+                                                     bucket ? 32u : 0u, !bucket, c->hi16);
             ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph != nullptr;
         }
         if (ok) ok = hipGraphInstantiate(&c->sort_graph, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -211,21 +232,19 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     } else {
         c->sorted_index = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st,
                                             per_pass_events ? c->scatter_ev : nullptr,
-                                            bucket ? 32u : 0u, c->band_tile_bias, !bucket, c->hi16);
+                                            bucket ? 32u : 0u, !bucket, c->hi16);
     }
     c->depth_dropped = !bucket;
     if (int r = check_launch(c, "RadixSort")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[3], st));
     // computeRanges (Subrenderer.cpp:172-216)
-    launch_find_ranges(c->sort.hi[c->sorted_index], c->sort.params, c->capacity, c->ranges, st,
-                       c->hi16 ? 1u : 0u, c->band_tile_bias);
+    launch_find_ranges(fp, c->sort.hi[c->sorted_index], c->sort.params, c->ranges, st);
     if (int r = check_launch(c, "FindRanges")) return r;
     if (bucket) {
         // second half of the alternative sorter: per-tile depth sort (needs the ranges)
         const int si = c->sorted_index;
         if (tm) HIP_TRY(c, hipEventRecord(c->alt_ev[0], st));
-        launch_tile_sort(c->ranges, c->row_begin * c->grid_w, (c->row_end - c->row_begin) * c->grid_w,
-                         c->sort.lo[si], c->sort.id[si], c->sort.lo[si ^ 1], c->sort.id[si ^ 1], st,
+        launch_tile_sort(fp, c->ranges, c->sort.lo[si], c->sort.id[si], c->sort.lo[si ^ 1], c->sort.id[si ^ 1], st,
                          c->helper_stream, c->fork_ev, c->join_ev);
         if (int r = check_launch(c, "TileSort")) return r;
         if (tm) HIP_TRY(c, hipEventRecord(c->alt_ev[1], st));
@@ -240,9 +259,26 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     return GS_OK;
 }
 
+double ms_since(HostClock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(HostClock::now() - t0).count();
+}
+
+// RECORD_CPU_TIMES (Renderer.cpp:299-314, 399-456): "CPU frame time" = entry of this draw - entry of the previous one
+void host_frame_begin(gs_ctx* c) {
+    const HostClock::time_point now = HostClock::now();
+    c->host.cpu_frame_ms = c->have_entry ? (float)std::chrono::duration<double, std::milli>(now - c->last_entry).count() : 0.0f;
+    c->last_entry = now;
+    c->have_entry = true;
+    c->host.wait_ms = 0.0f;
+    c->host.present_ms = 0.0f;
+}
+
 // Renderer.cpp:458-475: wait, read the timestamps, compute the five buckets.
 int finish_frame(gs_ctx* c) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const HostClock::time_point t_wait = HostClock::now();
+    hipError_t sync_err = hipStreamSynchronize(c->stream);
+    c->host.wait_ms = (float)ms_since(t_wait);       // the reference's waitForFences + waitIdle
+    HIP_TRY(c, sync_err);
     SortParams sp{};
     HIP_TRY(c, hipMemcpy(&sp, c->sort.params, sizeof(sp), hipMemcpyDeviceToHost));
     gs_timings t{};
@@ -309,7 +345,7 @@ void gs_default_config(gs_config* cfg) {
     cfg->fov_y = 3.1415f * 0.5f;    // Common.glsl:2
     cfg->sort_algorithm = GS_SORT_RADIX4;
     cfg->render_mode = GS_RENDER_EXACT;
-    cfg->record_timings = 1;
+    cfg->record_timings = 0;        // RECORD_GPU_TIMES is commented out in the reference (GfxSettings.h:7)
     cfg->render_kernel = GS_RENDER_KERNEL_AUTO;
 }
 
@@ -382,7 +418,6 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
 
 int gs_destroy(gs_ctx* c) {
     if (!c) return GS_OK;
-    if (c->borrowers) return fail(c, GS_ERR_INVALID, "gs_destroy: the scene is shared (gs_share_scene); destroy the borrowers first");
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_resolution(c);
@@ -429,44 +464,57 @@ static int alloc_scratch(gs_ctx* c, uint32_t n) {
 // on their own streams with their own per-frame buffers; only the read-only gaussian arrays are shared.
 int gs_share_scene(gs_ctx* c, gs_ctx* owner) {
     if (!c || !owner || c == owner) return GS_ERR_INVALID;
-    if (!owner->n) return fail(c, GS_ERR_NO_SCENE, "gs_share_scene: the owner has no gaussians uploaded");
-    if (owner->scene_owner) return fail(c, GS_ERR_INVALID, "gs_share_scene: the owner itself borrows its scene");
+    if (!owner->n || !owner->shared) return fail(c, GS_ERR_NO_SCENE, "gs_share_scene: the owner has no gaussians uploaded");
     if (owner->device != c->device) return fail(c, GS_ERR_INVALID, "gs_share_scene: contexts are on different devices");
-    if (c->borrowers) return fail(c, GS_ERR_INVALID, "gs_share_scene: this context's scene is shared with others");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    SharedScene* sh = owner->shared;
+    sh->refs.fetch_add(1);            // taken first: c may currently hold the same arrays
     free_resolution(c);
     free_scene(c);
-    if (int r = alloc_scratch(c, owner->n)) { free_scene(c); return r; }
+    c->shared = sh;
+    c->scene = sh->b;
+    if (int r = alloc_scratch(c, sh->n)) { free_scene(c); return r; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->scene = owner->scene;
-    c->scene_owner = owner;
-    ++owner->borrowers;
-    c->n = owner->n;
+    c->n = sh->n;
     return GS_OK;
 }
 
 int gs_upload_gaussians(gs_ctx* c, const void* aos336, uint32_t n) {
     if (!c) return GS_ERR_INVALID;
     if (!aos336 || n == 0) return fail(c, GS_ERR_INVALID, "gs_upload_gaussians: empty input");
-    if (c->borrowers) return fail(c, GS_ERR_INVALID, "gs_upload_gaussians: the current scene is shared (gs_share_scene); release the borrowers first");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_resolution(c);   // capacity depends on n (Renderer.cpp:725)
-    free_scene(c);
+    free_scene(c);        // contexts that share the previous arrays keep them
+    c->shared = new (std::nothrow) SharedScene();
+    if (!c->shared) return fail(c, GS_ERR_INVALID, "gs_upload_gaussians: out of host memory");
+    c->shared->n = n;
     const size_t N = n;
-    HIP_TRY(c, hipMalloc((void**)&c->scene.pos, 3 * N * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&c->scene.scale, 3 * N * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&c->scene.rot, 4 * N * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&c->scene.sh, 48 * N * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&c->scene.opacity, N * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void**)&c->scene.sig2, N * sizeof(float)));
+    {
+        SceneBuffers& b = c->shared->b;
+        hipError_t e = hipMalloc((void**)&b.pos, 3 * N * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&b.scale, 3 * N * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&b.rot, 4 * N * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&b.sh, 48 * N * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&b.opacity, N * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&b.sig2, N * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&b.block_bounds, (size_t)((n + kProjThreads - 1) / kProjThreads) * 8 * sizeof(float));
+        if (e != hipSuccess) {
+            free_scene(c);
+            return fail(c, GS_ERR_HIP, std::string("gs_upload_gaussians: ") + hipGetErrorString(e));
+        }
+        c->scene = b;
+    }
     if (int r = alloc_scratch(c, n)) { free_scene(c); return r; }
 
     // AoS -> SoA on the device, through a bounded staging buffer
     const uint32_t chunk = n < (1u << 20) ? n : (1u << 20);
     float* staging = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&staging, (size_t)chunk * GS_GAUSSIAN_RECORD_BYTES));
+    if (hipMalloc((void**)&staging, (size_t)chunk * GS_GAUSSIAN_RECORD_BYTES) != hipSuccess) {
+        free_scene(c);
+        return fail(c, GS_ERR_HIP, "gs_upload_gaussians: cannot allocate the staging buffer");
+    }
     const char* src = static_cast<const char*>(aos336);
     int rc = GS_OK;
     for (uint32_t first = 0; first < n && rc == GS_OK; first += chunk) {
@@ -481,6 +529,12 @@ int gs_upload_gaussians(gs_ctx* c, const void* aos336, uint32_t n) {
         if (e != hipSuccess) rc = fail(c, GS_ERR_HIP, std::string("gs_upload_gaussians: ") + hipGetErrorString(e));
     }
     (void)hipFree(staging);
+    if (rc == GS_OK) {
+        launch_block_bounds(n, c->scene, c->stream);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, GS_ERR_HIP, std::string("gs_upload_gaussians: ") + hipGetErrorString(e));
+    }
     if (rc != GS_OK) { free_scene(c); return rc; }
     c->n = n;
     return GS_OK;
@@ -498,17 +552,39 @@ int gs_set_resolution(gs_ctx* c, uint32_t width, uint32_t height) {
     const uint64_t want = (uint64_t)c->n + 64ull * 16ull * gw * gh;                       // Renderer.cpp:725
     if (want > (1ull << 31)) return fail(c, GS_ERR_INVALID, "gs_set_resolution: sort list would exceed 2^31 elements");
     c->width = width; c->height = height; c->grid_w = gw; c->grid_h = gh;
-    c->row_begin = 0; c->row_end = gh;
+    c->row_begin = 0; c->row_end = gh; c->row_stride = 1; c->first_row = 0; c->rows_owned = gh;
+    c->compact_out = false;
     c->capacity = ceil_pow2((uint32_t)want);
     c->num_sort_bits = num_sort_bits_for(gw * gh);
-    c->band_sort_bits = c->num_sort_bits; c->band_tile_bias = 0;
+    c->band_sort_bits = c->num_sort_bits;
     c->hi16 = kHi16Supported && (uint64_t)gw * gh <= 65535u;
     int rc = alloc_sort(c, c->sort, c->capacity);
     if (rc != GS_OK) { free_resolution(c); return rc; }
-    HIP_TRY(c, hipMalloc((void**)&c->ranges, (size_t)gw * gh * 2 * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void**)&c->framebuffer, (size_t)width * height * 4));
-    HIP_TRY(c, hipMemset(c->ranges, 0, (size_t)gw * gh * 2 * sizeof(uint32_t)));
-    HIP_TRY(c, hipMemset(c->framebuffer, 0, (size_t)width * height * 4));
+    // any failure from here on leaves the context without a resolution (capacity 0), never half set up
+    hipError_t e = hipMalloc((void**)&c->ranges, (size_t)gw * gh * 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->framebuffer, (size_t)width * height * 4);
+    if (e == hipSuccess) e = hipMemset(c->ranges, 0, (size_t)gw * gh * 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->framebuffer, 0, (size_t)width * height * 4);
+    if (e != hipSuccess) {
+        free_resolution(c);
+        return fail(c, GS_ERR_HIP, std::string("gs_set_resolution: ") + hipGetErrorString(e));
+    }
+    return GS_OK;
+}
+
+static int apply_tile_rows(gs_ctx* c, uint32_t row_begin, uint32_t row_end, uint32_t stride, uint32_t phase,
+                           bool compact_out) {
+    c->row_begin = row_begin; c->row_end = row_end; c->row_stride = stride;
+    c->first_row = row_begin + phase;
+    c->rows_owned = c->first_row < row_end ? (row_end - c->first_row + stride - 1u) / stride : 0u;
+    c->compact_out = compact_out;
+    const uint32_t owned_tiles = c->rows_owned * c->grid_w;
+    c->band_sort_bits = num_sort_bits_for(owned_tiles ? owned_tiles : 1u);
+    c->hi16 = kHi16Supported && owned_tiles <= 65535u;
+    if (c->sort_graph) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));   // the graph may still be executing
+        drop_sort_graph(c);
+    }
     return GS_OK;
 }
 
@@ -517,16 +593,15 @@ int gs_set_tile_rows(gs_ctx* c, uint32_t row_begin, uint32_t row_end) {
     if (!c->capacity) return fail(c, GS_ERR_NO_SCENE, "gs_set_tile_rows: gs_set_resolution not called");
     if (row_begin > row_end || row_end > c->grid_h)
         return fail(c, GS_ERR_INVALID, "gs_set_tile_rows: need row_begin <= row_end <= tiles_y");
-    c->row_begin = row_begin; c->row_end = row_end;
-    const uint32_t band_tiles = (row_end - row_begin) * c->grid_w;
-    c->band_sort_bits = num_sort_bits_for(band_tiles ? band_tiles : 1u);
-    c->band_tile_bias = row_begin * c->grid_w;
-    c->hi16 = kHi16Supported && band_tiles <= 65535u;
-    if (c->sort_graph) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));   // the graph may still be executing
-        drop_sort_graph(c);
-    }
-    return GS_OK;
+    return apply_tile_rows(c, row_begin, row_end, 1u, 0u, false);
+}
+
+int gs_set_tile_rows_interleaved(gs_ctx* c, uint32_t phase, uint32_t stride, uint32_t compact_output) {
+    if (!c) return GS_ERR_INVALID;
+    if (!c->capacity) return fail(c, GS_ERR_NO_SCENE, "gs_set_tile_rows_interleaved: gs_set_resolution not called");
+    if (stride == 0u || phase >= stride)
+        return fail(c, GS_ERR_INVALID, "gs_set_tile_rows_interleaved: need 0 <= phase < stride");
+    return apply_tile_rows(c, 0u, c->grid_h, stride, phase, compact_output != 0u);
 }
 
 int gs_get_scene_info(const gs_ctx* c, gs_scene_info* out) {
@@ -537,14 +612,19 @@ int gs_get_scene_info(const gs_ctx* c, gs_scene_info* out) {
     out->capacity = c->capacity; out->num_sort_bits = c->num_sort_bits;
     out->row_begin = c->row_begin; out->row_end = c->row_end;
     out->tile_word_bytes = c->hi16 ? 2u : 4u;
+    out->row_stride = c->row_stride; out->first_row = c->first_row; out->rows_owned = c->rows_owned;
     return GS_OK;
 }
 
 int gs_render_device_async(gs_ctx* c, const float view[16], const float proj[16],
                            const float cam_pos[3], uint32_t sh_mode, void* rgba_out_device) {
     if (!c) return GS_ERR_INVALID;
+    host_frame_begin(c);
     HIP_TRY(c, hipSetDevice(c->device));
-    return enqueue_frame(c, view, proj, cam_pos, sh_mode, static_cast<uint8_t*>(rgba_out_device));
+    const HostClock::time_point t_rec = HostClock::now();
+    const int rc = enqueue_frame(c, view, proj, cam_pos, sh_mode, static_cast<uint8_t*>(rgba_out_device));
+    c->host.record_ms = (float)ms_since(t_rec);      // recordCommandBuffer + submit
+    return rc;
 }
 
 int gs_render_device(gs_ctx* c, const float view[16], const float proj[16], const float cam_pos[3],
@@ -562,7 +642,10 @@ int gs_render(gs_ctx* c, const float view[16], const float proj[16], const float
     if (rc != GS_OK) return rc;
     rc = finish_frame(c);
     if (rc < 0) return rc;
-    HIP_TRY(c, hipMemcpy(rgba_out, c->framebuffer, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost));
+    const HostClock::time_point t_present = HostClock::now();
+    hipError_t e = hipMemcpy(rgba_out, c->framebuffer, (size_t)c->width * c->height * 4, hipMemcpyDeviceToHost);
+    c->host.present_ms = (float)ms_since(t_present);   // where the reference presents, this sink copies the frame out
+    HIP_TRY(c, e);
     return rc;
 }
 
@@ -598,13 +681,28 @@ int gs_get_timings(const gs_ctx* c, gs_timings* out) {
     return GS_OK;
 }
 
-// tile words stored as uint16 relative to the band's first tile -> the uint32 global tile ids callers expect
+int gs_get_host_timings(const gs_ctx* c, gs_host_timings* out) {
+    if (!c || !out) return GS_ERR_INVALID;
+    *out = c->host;
+    return GS_OK;
+}
+
+// The sort list holds compact tile ids (uint16 or uint32, FrameParams) -> the uint32 GLOBAL tile ids callers expect
 static int read_tile_words(gs_ctx* c, const uint32_t* dev, uint32_t num_elems, void* dst, size_t bytes) {
     if (bytes > (size_t)num_elems * sizeof(uint32_t)) return fail(c, GS_ERR_INVALID, "gs_debug_read: size exceeds buffer");
-    std::vector<uint16_t> h(num_elems);
-    if (num_elems) HIP_TRY(c, hipMemcpy(h.data(), dev, (size_t)num_elems * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    const size_t cnt = bytes / sizeof(uint32_t);
     uint32_t* out = static_cast<uint32_t*>(dst);
-    for (size_t i = 0; i < bytes / sizeof(uint32_t); ++i) out[i] = (uint32_t)h[i] + c->band_tile_bias;
+    if (c->hi16) {
+        std::vector<uint16_t> h(num_elems);
+        if (num_elems) HIP_TRY(c, hipMemcpy(h.data(), dev, (size_t)num_elems * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; ++i) out[i] = h[i];
+    } else if (cnt) {
+        HIP_TRY(c, hipMemcpy(out, dev, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    for (size_t i = 0; i < cnt; ++i) {
+        const uint32_t k = out[i] / c->grid_w, x = out[i] - k * c->grid_w;
+        out[i] = (c->first_row + k * c->row_stride) * c->grid_w + x;
+    }
     return GS_OK;
 }
 
@@ -621,8 +719,7 @@ int gs_debug_read(gs_ctx* c, int which, void* dst, size_t bytes) {
     const int si = c->sorted_index;
     switch (which) {
         case GS_BUF_SORTED_TILE:
-            if (c->hi16) return read_tile_words(c, c->sort.hi[si], sp.num_elems, dst, bytes);
-            src = c->sort.hi[si]; avail = e_bytes; break;
+            return read_tile_words(c, c->sort.hi[si], sp.num_elems, dst, bytes);
         case GS_BUF_SORTED_DEPTH:
             if (c->depth_dropped && c->have_frame && !c->unsorted_valid) {
                 // the frame path stops moving the depth words once they are sorted: rebuild them from the ids
@@ -649,8 +746,8 @@ int gs_debug_read(gs_ctx* c, int which, void* dst, size_t bytes) {
             // the list as emitted lives in ping-pong half 0 and is overwritten by the second pass
             if (!c->unsorted_valid)
                 return fail(c, GS_ERR_INVALID, "gs_debug_read: unsorted list only valid after gs_debug_init_sort_list");
-            if (which == GS_BUF_UNSORTED_TILE && c->hi16) return read_tile_words(c, c->sort.hi[0], sp.num_elems, dst, bytes);
-            src = which == GS_BUF_UNSORTED_TILE ? c->sort.hi[0] : which == GS_BUF_UNSORTED_DEPTH ? c->sort.lo[0] : c->sort.id[0];
+            if (which == GS_BUF_UNSORTED_TILE) return read_tile_words(c, c->sort.hi[0], sp.num_elems, dst, bytes);
+            src = which == GS_BUF_UNSORTED_DEPTH ? c->sort.lo[0] : c->sort.id[0];
             avail = e_bytes;
             break;
         case GS_BUF_COLOR:
@@ -838,7 +935,7 @@ int gs_debug_count_bench(gs_ctx* c, uint32_t n, int ablate, uint32_t grid, uint3
 }
 
 int gs_membench(gs_ctx* c, int kind, size_t bytes, uint32_t blocks, uint32_t iters, float* gbps, float* ms_out) {
-    if (!c || !gbps || bytes < 16 || iters == 0 || kind < 0 || kind > 9) return GS_ERR_INVALID;
+    if (!c || !gbps || bytes < 16 || iters == 0 || kind < 0 || kind > 12) return GS_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     bytes &= ~(size_t)15;
     if (blocks == 0) blocks = 2048;

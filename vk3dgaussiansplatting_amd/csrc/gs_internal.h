@@ -46,14 +46,21 @@ struct FrameParams {
     uint32_t sh_mode;     // integer, not float
     uint32_t width, height;
     uint32_t grid_w, grid_h;
-    uint32_t row_begin, row_end;  // tile-row band of this context
+    // Tile rows of this context (multi-GPU): rows first_row + k * row_stride < row_end, k = 0 .. rows_owned - 1, with
+    // first_row = row_begin + row_phase.  One GPU: [0, grid_h), stride 1.  A contiguous band: [row_begin, row_end), stride 1.
+    // Interleaved: every row_stride-th row of the whole grid starting at row_phase.  Inside a frame the sort list holds
+    // COMPACT tile ids k * grid_w + x (k = index among the owned rows): same order as the global ids of the owned
+    // tiles, no gaps, fewest key bits.
+    uint32_t row_begin, row_end;
+    uint32_t row_stride, first_row, rows_owned;
+    uint32_t compact_out;         // image addressed in compact rows (pixel row of owned row k starts at 16 k): the strip
+                                  // a rank contributes to the gather
     uint32_t num_gaussians;
     uint32_t capacity;
     float near_plane, far_plane;
     float ndc_cull, in_view_limit;
     float tan_fov_y;      // tan(FOV_Y*0.5f), folded on the host (Common.glsl:53)
-    uint32_t hi16;        // sort list stores tile ids as uint16 relative to tile_bias (band of <= 65535 tiles)
-    uint32_t tile_bias;   // first tile of the band = row_begin * grid_w
+    uint32_t hi16;        // sort list stores the compact tile ids as uint16 (at most 65535 owned tiles)
     float w_frob2;        // squared Frobenius norm of the upper-left 3x3 of view (host-folded, for the band bound)
 };
 
@@ -89,6 +96,8 @@ struct SceneBuffers {
     float* opacity;  // [N]   shCoeffs[0].w
     float* sig2;     // [N]   upper bound of the largest eigenvalue of the 3-D covariance: |R|_F^2 * max(scale)^2,
                      //       computed at upload; lets a tile-row band skip far-away splats early (k_project)
+    float* block_bounds; // [ceil(N / kProjThreads)][8]  per project workgroup: min xyz, max xyz of its splats' positions,
+                     //       max sig2, pad -- a band context drops a whole workgroup with one record (k_project)
 };
 
 // Per-splat scratch of one frame.
@@ -129,25 +138,26 @@ void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffer
                  hipStream_t stream);
 // Sorts buffers [0] -> result index returned (0 or 1) after num_sort_bits/4 passes.
 // scatter_events: optional 2*passes events recorded right before / after every Scatter launch.
-// Passes run over key bits [first_bit, num_sort_bits) of (tile - tile_bias) << 32 | depth: a context that
-// owns a tile-row band sorts on tile ids relative to its first tile (same order, fewer significant bits).
+// Passes run over key bits [first_bit, num_sort_bits) of tile << 32 | depth (in a frame the tile word is the compact
+// tile id of FrameParams: a context that owns a subset of the tile rows sorts over fewer significant bits).
 // drop_depth_payload: the tile-word passes (bits >= 32) do not carry the depth words (frame path only).
-// hi16: the hi arrays hold 16-bit tile ids relative to the band (frame path, bands of at most 65535 tiles).
+// hi16: the hi arrays hold 16-bit tile ids (frame path, at most 65535 owned tiles).
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events = nullptr, uint32_t first_bit = 0,
-                      uint32_t tile_bias = 0, bool drop_depth_payload = false, bool hi16 = false);
-// GS_SORT_TILE_BUCKET: per-tile depth sort of tiles [tile0, tile0 + num_tiles) (gs_tilesort.hip)
+                      bool drop_depth_payload = false, bool hi16 = false);
+// GS_SORT_TILE_BUCKET: per-tile depth sort of the owned tiles (gs_tilesort.hip)
 int init_tile_sort();
-void launch_tile_sort(const uint32_t* ranges, uint32_t tile0, uint32_t num_tiles, uint32_t* lo, uint32_t* id,
+void launch_tile_sort(const FrameParams& fp, const uint32_t* ranges, uint32_t* lo, uint32_t* id,
                       uint32_t* lo_alt, uint32_t* id_alt, hipStream_t stream, hipStream_t helper = nullptr,
                       hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
-void launch_find_ranges(const uint32_t* sorted_tile, const SortParams* params, uint32_t capacity,
-                        uint32_t* ranges, hipStream_t stream, uint32_t hi16 = 0, uint32_t tile_bias = 0);
+void launch_find_ranges(const FrameParams& fp, const uint32_t* sorted_tile, const SortParams* params,
+                        uint32_t* ranges, hipStream_t stream);
 void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
                    const uint32_t* ranges, uint8_t* rgba, uint32_t render_mode, uint32_t render_kernel,
                    hipStream_t stream);
 void launch_aos_to_soa(const float* chunk, uint32_t first, uint32_t count, uint32_t n,
                        const SceneBuffers& s, hipStream_t stream);
+void launch_block_bounds(uint32_t n, const SceneBuffers& s, hipStream_t stream);
 void launch_stream_probe(int kind, const void* src, void* dst, size_t bytes, uint32_t blocks, hipStream_t stream);
 void launch_count_ablate(int ablate, const SortBuffers& sb, uint32_t capacity, uint32_t grid, hipStream_t stream);
 void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <limits>
 #include <numeric>
@@ -23,6 +24,8 @@
 #include <vector>
 
 namespace {
+
+thread_local std::string g_ply_error;
 
 struct Prop { std::string name; std::string type; size_t size; bool is_list; };
 
@@ -103,6 +106,17 @@ int convert(const char* path, std::vector<float>& records, uint32_t& n_out, std:
     }
 
     const size_t n = count;
+    // The header's element count is untrusted: before anything of that size is allocated, a binary file must really
+    // hold count rows (an ascii row needs at least two bytes per property).
+    {
+        const std::streampos data_pos = in.tellg();
+        in.seekg(0, std::ios::end);
+        const std::streampos end_pos = in.tellg();
+        in.seekg(data_pos);
+        const uint64_t remaining = end_pos > data_pos ? (uint64_t)(end_pos - data_pos) : 0ull;
+        const uint64_t need = (uint64_t)n * (ascii ? 2ull * props.size() : (uint64_t)row_bytes);
+        if (!in || need > remaining) { err = "ply data truncated: the header announces more rows than the file holds"; return GS_ERR_FORMAT; }
+    }
     std::vector<std::vector<float>> v(names.size(), std::vector<float>(n));
     if (ascii) {
         std::vector<double> row(props.size());
@@ -167,17 +181,28 @@ int convert(const char* path, std::vector<float>& records, uint32_t& n_out, std:
     return GS_OK;
 }
 
-thread_local std::string g_ply_error;
-
 } // namespace
 
 extern "C" {
+
+// nothing may leave an extern "C" function as an exception (std::bad_alloc / length_error on a hostile header)
+static int convert_noexcept(const char* path, std::vector<float>& rec, uint32_t& n) {
+    try {
+        return convert(path, rec, n, g_ply_error);
+    } catch (const std::exception& ex) {
+        g_ply_error = std::string("ply conversion failed: ") + ex.what();
+        return GS_ERR_FORMAT;
+    } catch (...) {
+        g_ply_error = "ply conversion failed";
+        return GS_ERR_FORMAT;
+    }
+}
 
 int gs_convert_ply(const char* path, void* aos336_out, uint32_t max_records, uint32_t* n_out) {
     if (!path || !n_out) return GS_ERR_INVALID;
     std::vector<float> rec;
     uint32_t n = 0;
-    int rc = convert(path, rec, n, g_ply_error);
+    int rc = convert_noexcept(path, rec, n);
     if (rc != GS_OK) return rc;
     *n_out = n;
     if (aos336_out) {
@@ -192,7 +217,7 @@ int gs_load_ply(gs_ctx* ctx, const char* path) {
     if (!ctx || !path) return GS_ERR_INVALID;
     std::vector<float> rec;
     uint32_t n = 0;
-    int rc = convert(path, rec, n, g_ply_error);
+    int rc = convert_noexcept(path, rec, n);
     if (rc != GS_OK) return rc;   // message retrievable with gs_ply_last_error()
     if (n == 0) return GS_ERR_FORMAT;
     return gs_upload_gaussians(ctx, rec.data(), n);

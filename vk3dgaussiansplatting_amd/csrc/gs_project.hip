@@ -157,6 +157,42 @@ __device__ __forceinline__ void sh_eval4(float dx, float dy, float dz, float sh[
     sh[9] = fTmpC * fS0;
 }
 
+// Number of owned tile rows (FrameParams: first_row + k * row_stride) below row y, i.e. the compact index of the first
+// owned row >= y.
+__device__ __forceinline__ int owned_rows_below(const FrameParams& fp, int y) {
+    const int first = (int)fp.first_row;
+    if (y <= first) return 0;
+    return fp.row_stride == 1u ? y - first : (y - first + (int)fp.row_stride - 1) / (int)fp.row_stride;
+}
+
+__device__ __forceinline__ bool owns_every_row(const FrameParams& fp) {
+    return fp.row_begin == 0u && fp.row_end == fp.grid_h && fp.row_stride == 1u;
+}
+
+// Conservative bound on a splat's radius in pixels from its view-space position and the upload-time bound sig2 on the
+// largest eigenvalue of its 3-D covariance: radius = ceil(3 sqrt(lambda_max(Sigma'))) and lambda_max(Sigma') <=
+// |J|_F^2 |W|_F^2 lambda_max(Sigma) + 0.3, with J, W as in getCovarianceMatrix (Common.glsl:49-69; tx, ty = the clamped
+// x/z, y/z).  Widened by 2 % + 2 px.
+__device__ __forceinline__ float radius_bound(const FrameParams& fp, float tx, float ty, float vz, float sig2) {
+    const float wdt = (float)fp.width, hgt = (float)fp.height;
+    const float tfx = fp.tan_fov_y * wdt / hgt;
+    const float fx = wdt / (2.0f * tfx), fy = hgt / (2.0f * fp.tan_fov_y);
+    const float j2 = (fx * fx * (1.0f + tx * tx) + fy * fy * (1.0f + ty * ty)) / (vz * vz);
+    const float lam = j2 * fp.w_frob2 * sig2 * 1.02f + 0.31f;
+    return 3.0f * sqrtf(lam) + 2.0f;
+}
+
+// True when no owned tile row can intersect the pixel rows [ylo, yhi] (widened by two tile rows on either side); a NaN
+// anywhere gives false, i.e. the caller takes the normal path.
+__device__ __forceinline__ bool misses_owned_rows(const FrameParams& fp, float ylo, float yhi) {
+    if (!(ylo == ylo) || !(yhi == yhi) || !(ylo <= yhi)) return false;
+    const float lo_row = floorf(ylo * (1.0f / 16.0f)) - 2.0f, hi_row = floorf(yhi * (1.0f / 16.0f)) + 3.0f;   // [lo, hi)
+    const int y0 = lo_row < (float)fp.row_begin ? (int)fp.row_begin : (lo_row > 1e6f ? 1000000 : (int)lo_row);
+    const int y1 = hi_row > (float)fp.row_end ? (int)fp.row_end : (hi_row < -1e6f ? -1000000 : (int)hi_row);
+    if (y1 <= y0) return true;
+    return owned_rows_below(fp, y1) - owned_rows_below(fp, y0) <= 0;
+}
+
 __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
                                                            const SceneBuffers scene,
                                                            const SplatScratch sc) {
@@ -170,6 +206,42 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
     const uint32_t g = blockIdx.x * kProjThreads + threadIdx.x;
     uint32_t count = 0;
     float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0;   // culled splats: zero record
+    const bool band = !owns_every_row(fp);
+
+    // A context that owns a subset of the tile rows first tests the workgroup as a whole: the box around its 256 splat
+    // positions (Morton order keeps it small) and their largest sig2, from the upload.  If all eight corners are beyond
+    // the near plane, every splat's screen y lies between the corners' extremes and its radius is below the bound taken
+    // at the nearest corner depth; when that range misses every owned row the workgroup emits nothing: one 32-byte read
+    // instead of 256 positions (and everything after).  Nothing is written for the splats but the workgroup's zero
+    // count -- k_emit never looks at the per-splat arrays of an empty workgroup, RenderGaussians never at its records.
+    if (band) {
+        const float4 b0 = reinterpret_cast<const float4*>(scene.block_bounds)[blockIdx.x * 2 + 0];
+        const float4 b1 = reinterpret_cast<const float4*>(scene.block_bounds)[blockIdx.x * 2 + 1];
+        const float lo[3] = {b0.x, b0.y, b0.z}, hi[3] = {b0.w, b1.x, b1.y};
+        const float hgt = (float)fp.height;
+        const float tfx = fp.tan_fov_y * (float)fp.width / hgt;
+        float ymin = 3.0e38f, ymax = -3.0e38f, zmin = 3.0e38f;
+        bool in_front = true;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float vp[4], q[4];
+            mat4_mul_vec4(fp.view, (c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2], 1.0f, vp);
+            mat4_mul_vec4(fp.proj, vp[0], vp[1], vp[2], vp[3], q);
+            const float depth = -vp[2];
+            in_front = in_front && depth > fp.near_plane && q[3] > 0.0f;
+            const float sy = (1.0f - q[1] / q[3]) * 0.5f * hgt;
+            in_front = in_front && (sy - sy == 0.0f);               // finite (a NaN / infinite corner keeps the workgroup)
+            ymin = fminf(ymin, sy); ymax = fmaxf(ymax, sy); zmin = fminf(zmin, depth);
+        }
+        if (in_front) {
+            const float rmax = radius_bound(fp, tfx * fp.in_view_limit, fp.tan_fov_y * fp.in_view_limit, zmin, b1.z);
+            // 1 px of slack for the rounding of the corner projections against the per-splat ones
+            if (misses_owned_rows(fp, ymin - rmax - 1.0f, ymax + rmax + 1.0f)) {
+                if (threadIdx.x == 0) sc.block_sums[blockIdx.x] = 0u;
+                return;
+            }
+        }
+    }
 
     if (g < n) {
         const float px = scene.pos[g], py = scene.pos[(size_t)n + g], pz = scene.pos[2 * (size_t)n + g];
@@ -192,18 +264,14 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
                 // |J|_F^2 |W|_F^2 lambda_max(Sigma) + 0.3, with lambda_max(Sigma) <= sig2 from the upload and J, W as in
                 // getCovarianceMatrix (Common.glsl:49-69).  Widened by 2 % + 2 px and two whole tile rows; a NaN or
                 // infinity anywhere makes the comparison false, i.e. the splat takes the normal path.
-                if (fp.row_begin != 0u || fp.row_end != fp.grid_h) {
-                    const float wdt = (float)fp.width, hgt = (float)fp.height;
-                    const float tfx = fp.tan_fov_y * wdt / hgt;
-                    const float fx = wdt / (2.0f * tfx), fy = hgt / (2.0f * fp.tan_fov_y);
+                if (band) {
+                    const float hgt = (float)fp.height;
+                    const float tfx = fp.tan_fov_y * (float)fp.width / hgt;
                     const float tx = clampf(vp[0] / vp[2], -tfx * fp.in_view_limit, tfx * fp.in_view_limit);
                     const float ty = clampf(vp[1] / vp[2], -fp.tan_fov_y * fp.in_view_limit, fp.tan_fov_y * fp.in_view_limit);
-                    const float j2 = (fx * fx * (1.0f + tx * tx) + fy * fy * (1.0f + ty * ty)) / (vp[2] * vp[2]);
-                    const float lam = j2 * fp.w_frob2 * scene.sig2[g] * 1.02f + 0.31f;
-                    const float rmax = 3.0f * sqrtf(lam) + 2.0f;
+                    const float rmax = radius_bound(fp, tx, ty, vp[2], scene.sig2[g]);
                     const float sy_b = (1.0f - ndc_y) * 0.5f * hgt;          // screen y as below, to a rounding
-                    const float band_top = 16.0f * (float)fp.row_begin - 32.0f, band_bot = 16.0f * (float)fp.row_end + 32.0f;
-                    if (sy_b + rmax < band_top || sy_b - rmax > band_bot) band_skip = true;
+                    band_skip = misses_owned_rows(fp, sy_b - rmax, sy_b + rmax);
                 }
                 if (!band_skip) {
                 float scale[3], rot[4], cov[3];
@@ -234,11 +302,12 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
                 const int max_x = clampi(tx == 2147483647 ? tx : tx + 1, 0, gw);
                 const int max_y = clampi(ty == 2147483647 ? ty : ty + 1, 0, gh);
 
-                // tile-row band of this context (multi-GPU); identity for [0, grid_h)
+                // tile rows of this context (multi-GPU) as compact indices [k0, k1); identity for [0, grid_h)
                 int y0 = min_y > (int)fp.row_begin ? min_y : (int)fp.row_begin;
                 int y1 = max_y < (int)fp.row_end ? max_y : (int)fp.row_end;
                 if (y1 < y0) y1 = y0;
-                count = (uint32_t)(max_x - min_x) * (uint32_t)(y1 - y0);   // :130
+                const int k0 = owned_rows_below(fp, y0), k1 = owned_rows_below(fp, y1);
+                count = (uint32_t)(max_x - min_x) * (uint32_t)(k1 - k0);   // :130
 
                 // :126-127.  The reference stores colour + covariance for every non-culled splat (N6).
                 // Colour is only ever read by RenderGaussians through the sorted list, so for a splat
@@ -281,8 +350,8 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
                     rec1 = make_float4(cov[2], res[0], res[1], res[2]);
                     rec2 = make_float4(scene.opacity[g], 0.0f, 0.0f, 0.0f);
                     sc.depth_key[g] = depth_key;
-                    sc.extents[g] = make_uint2((uint32_t)min_x | ((uint32_t)y0 << 16),
-                                               (uint32_t)max_x | ((uint32_t)y1 << 16));
+                    sc.extents[g] = make_uint2((uint32_t)min_x | ((uint32_t)k0 << 16),
+                                               (uint32_t)max_x | ((uint32_t)k1 << 16));
                 }
                 }   // !band_skip
             }
@@ -301,7 +370,6 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
         // into the band -- RenderGaussians reaches records only through the sorted list -- so a wave whose 64
         // splats all emit nothing skips its 3 KB of the block (most waves of a narrow band; the arrays are in
         // Morton order).  With the full grid every record is written as the reference does (N6).
-        const bool band = fp.row_begin != 0u || fp.row_end != fp.grid_h;
         s_wave_emits[wave_id()] = (!band || wsum != 0u) ? 1u : 0u;
     }
     __syncthreads();
@@ -393,6 +461,9 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
     // every global read of the workgroup is issued up front (one memory latency instead of a chain);
     // extents/depth of splats that emit nothing are stale or uninitialised and never used
     const uint32_t total = sc.block_sums[blockIdx.x];
+    // a context with a subset of the tile rows has mostly empty workgroups (some never wrote their per-splat
+    // arrays, see k_project): look at the total first there
+    if (!owns_every_row(fp) && total == 0) return;
     const uint32_t base = sc.block_offsets[blockIdx.x];
     const uint32_t cnt = g < n ? sc.tiles_touched[g] : 0u;
     const uint2 my_ext = g < n ? sc.extents[g] : make_uint2(0u, 0u);
@@ -458,10 +529,11 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
                 int32_t rx = (int32_t)(id_local - ry * wdt);
                 if (rx < 0) { --ry; rx += (int32_t)wdt; }
                 else if ((uint32_t)rx >= wdt) { ++ry; rx -= (int32_t)wdt; }
-                const uint32_t tile_key = (y0 + ry) * fp.grid_w + (min_x + (uint32_t)rx);  // :137
+                // :137 with y = the y0-th + ry owned row: compact tile id (FrameParams), the global one on one GPU
+                const uint32_t tile_key = (y0 + ry) * fp.grid_w + (min_x + (uint32_t)rx);
                 const uint64_t out = (uint64_t)base + j;
                 if (out < fp.capacity) {                                  // :143
-                    if (fp.hi16) reinterpret_cast<uint16_t*>(out_hi)[out] = (uint16_t)(tile_key - fp.tile_bias);
+                    if (fp.hi16) reinterpret_cast<uint16_t*>(out_hi)[out] = (uint16_t)tile_key;
                     else out_hi[out] = tile_key;
                     out_lo[out] = s_depth[s];
                     out_id[out] = g0 + s;

@@ -21,11 +21,19 @@
 
 namespace gs {
 
+// The sort list holds compact tile ids (FrameParams); ranges[] is indexed by the GLOBAL tile id.
+struct TileMap { uint32_t grid_w, first_row, row_stride; };
+__device__ __forceinline__ uint32_t global_tile(const TileMap& m, uint32_t c) {
+    if (m.row_stride == 1u) return c + m.first_row * m.grid_w;
+    const uint32_t k = c / m.grid_w;
+    return (m.first_row + k * m.row_stride) * m.grid_w + (c - k * m.grid_w);
+}
+
 __global__ __launch_bounds__(256) void k_find_ranges(const uint32_t* __restrict__ tile,
                                                       const SortParams* __restrict__ params,
-                                                      uint32_t* __restrict__ ranges, uint32_t hi16, uint32_t tile_bias) {
+                                                      uint32_t* __restrict__ ranges, uint32_t hi16, TileMap map) {
     const uint32_t e = params->num_elems;
-    // hi16: 16-bit tile ids relative to tile_bias (see k_scatter) -- eight elements per 16-byte load, else four
+    // hi16: 16-bit tile ids (see k_scatter) -- eight elements per 16-byte load, else four
     const uint16_t* tile16 = reinterpret_cast<const uint16_t*>(tile);
     const uint32_t per = hi16 ? 8u : 4u;
     const uint32_t chunks = (e + per - 1u) / per;
@@ -37,7 +45,7 @@ __global__ __launch_bounds__(256) void k_find_ranges(const uint32_t* __restrict_
                 const uint4 v = *reinterpret_cast<const uint4*>(tile16 + i0);
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int k = 0; k < 8; ++k) t[k] = ((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) + tile_bias;
+                for (int k = 0; k < 8; ++k) t[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
             } else {
                 const uint4 v = *reinterpret_cast<const uint4*>(tile + i0);
                 t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
@@ -45,20 +53,20 @@ __global__ __launch_bounds__(256) void k_find_ranges(const uint32_t* __restrict_
         } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                t[k] = (uint32_t)k < per && i0 + k < e ? (hi16 ? (uint32_t)tile16[i0 + k] + tile_bias : tile[i0 + k]) : 0u;
+                t[k] = (uint32_t)k < per && i0 + k < e ? (hi16 ? (uint32_t)tile16[i0 + k] : tile[i0 + k]) : 0u;
         }
-        uint32_t prev = i0 > 0 ? (hi16 ? (uint32_t)tile16[i0 - 1] + tile_bias : tile[i0 - 1]) : 0u;
+        uint32_t prev = i0 > 0 ? (hi16 ? (uint32_t)tile16[i0 - 1] : tile[i0 - 1]) : 0u;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t i = i0 + k;
             if ((uint32_t)k < per && i < e) {
                 if (i == 0) {
-                    ranges[t[k] * 2 + 0] = 0;               // FindRanges.comp:59-64
-                } else if (prev != t[k]) {                  // :48-58
-                    ranges[prev * 2 + 1] = i;
-                    ranges[t[k] * 2 + 0] = i;
+                    ranges[global_tile(map, t[k]) * 2 + 0] = 0;               // FindRanges.comp:59-64
+                } else if (prev != t[k]) {                                    // :48-58
+                    ranges[global_tile(map, prev) * 2 + 1] = i;
+                    ranges[global_tile(map, t[k]) * 2 + 0] = i;
                 }
-                if (i == e - 1) ranges[t[k] * 2 + 1] = e;   // end of the last tile = E
+                if (i == e - 1) ranges[global_tile(map, t[k]) * 2 + 1] = e;   // end of the last tile = E
                 prev = t[k];
             }
         }
@@ -213,7 +221,8 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
     const int lane = threadIdx.x;
     const uint32_t tile_in_band = blockIdx.x / WPT;
     const uint32_t sub = blockIdx.x % WPT;
-    const uint32_t ty = fp.row_begin + tile_in_band / fp.grid_w;
+    const uint32_t krow = tile_in_band / fp.grid_w;                    // index among this context's tile rows
+    const uint32_t ty = fp.first_row + krow * fp.row_stride;
     const uint32_t tx = tile_in_band % fp.grid_w;
     const uint32_t tile_index = ty * fp.grid_w + tx;                   // :74-76
     const uint32_t start = ranges[tile_index * 2 + 0];                 // :77
@@ -377,7 +386,8 @@ finish:
         packed[k] = v;
     }
     if (py < fp.height) {
-        uint32_t* row = rgba + (size_t)py * fp.width;
+        const uint32_t out_y = fp.compact_out ? krow * kTile + sub * ROWS + (uint32_t)(lane / LPR) : py;
+        uint32_t* row = rgba + (size_t)out_y * fp.width;
         const bool vec_ok = (fp.width % PX) == 0u && px0 + (PX - 1) < fp.width;
         if (PX == 4 && vec_ok) {
             *reinterpret_cast<uint4*>(row + px0) = make_uint4(packed[0], packed[PX > 1 ? 1 : 0], packed[PX > 2 ? 2 : 0], packed[PX > 3 ? 3 : 0]);
@@ -410,7 +420,8 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
     __shared__ uint32_t s_done;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t ty = fp.row_begin + blockIdx.x / fp.grid_w;
+    const uint32_t krow = blockIdx.x / fp.grid_w;                      // index among this context's tile rows
+    const uint32_t ty = fp.first_row + krow * fp.row_stride;
     const uint32_t tx = blockIdx.x % fp.grid_w;
     const uint32_t tile_index = ty * fp.grid_w + tx;                   // :74-76
     const uint32_t start = ranges[tile_index * 2 + 0];                 // :77
@@ -503,7 +514,8 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
         v |= (uint32_t)(clampf(col0, 0.0f, 1.0f) * 255.0f + 0.5f);
         v |= (uint32_t)(clampf(col1, 0.0f, 1.0f) * 255.0f + 0.5f) << 8;
         v |= (uint32_t)(clampf(col2, 0.0f, 1.0f) * 255.0f + 0.5f) << 16;
-        rgba[(size_t)py * fp.width + px] = v;
+        const uint32_t out_y = fp.compact_out ? krow * kTile + (uint32_t)wave * 4u + (uint32_t)(lane >> 4) : py;
+        rgba[(size_t)out_y * fp.width + px] = v;
     }
 }
 
@@ -520,18 +532,18 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
 // Few tiles cannot fill 1024 SIMDs with one wave each, so they get four independent waves; in the middle the
 // workgroup kernel wins because a tile is staged once and its longest dependent chain is a quarter as long; with
 // very many tiles every shape is throughput-bound and the ones that do the least per-splat work lead.
-void launch_find_ranges(const uint32_t* sorted_tile, const SortParams* params, uint32_t capacity,
-                        uint32_t* ranges, hipStream_t stream, uint32_t hi16, uint32_t tile_bias) {
-    uint32_t blocks = (capacity / 4u + 255u) / 256u;
+void launch_find_ranges(const FrameParams& fp, const uint32_t* sorted_tile, const SortParams* params,
+                        uint32_t* ranges, hipStream_t stream) {
+    uint32_t blocks = (fp.capacity / 4u + 255u) / 256u;
     if (blocks > 2048u) blocks = 2048u;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(k_find_ranges, dim3(blocks), dim3(256), 0, stream, sorted_tile, params, ranges, hi16, tile_bias);
+    const TileMap map{fp.grid_w, fp.first_row, fp.row_stride};
+    hipLaunchKernelGGL(k_find_ranges, dim3(blocks), dim3(256), 0, stream, sorted_tile, params, ranges, fp.hi16, map);
 }
 
 void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
                          const uint32_t* ranges, uint8_t* rgba, uint4* stats, hipStream_t stream) {
-    const uint32_t rows = fp.row_end > fp.row_begin ? fp.row_end - fp.row_begin : 0u;
-    const uint32_t tiles = rows * fp.grid_w;
+    const uint32_t tiles = fp.rows_owned * fp.grid_w;
     if (tiles == 0) return;
     hipLaunchKernelGGL((k_render<true, 4, true>), dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
                        ranges, reinterpret_cast<uint32_t*>(rgba), stats);
@@ -540,8 +552,7 @@ void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const
 void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
                    const uint32_t* ranges, uint8_t* rgba, uint32_t render_mode, uint32_t render_kernel,
                    hipStream_t stream) {
-    const uint32_t rows = fp.row_end > fp.row_begin ? fp.row_end - fp.row_begin : 0u;
-    const uint32_t tiles = rows * fp.grid_w;
+    const uint32_t tiles = fp.rows_owned * fp.grid_w;
     if (tiles == 0) return;
     uint32_t* out = reinterpret_cast<uint32_t*>(rgba);
     const uint32_t px = render_kernel != 0u ? render_kernel : tiles < 1500u ? 1u : tiles < 20000u ? 16u : 2u;

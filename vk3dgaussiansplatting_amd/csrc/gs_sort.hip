@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
                                                          const uint32_t* __restrict__ word,
                                                          uint32_t* __restrict__ table,
                                                          uint32_t* __restrict__ seg_sum,
-                                                         uint32_t sh, uint32_t bias) {
+                                                         uint32_t sh) {
     __shared__ uint32_t s_pack[2][kSortWaves][8];   // per-wave packed totals (two 16-bit counters per word)
     const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const uint32_t key = (k[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
-                    const uint32_t d = digit_of(key - bias, sh);
+                    const uint32_t d = digit_of(key, sh);
                     const bool ok = full || tile_base + (uint32_t)(r * kSortThreads + tid) * 8u + (uint32_t)q < e;
                     c += (uint64_t)(ok ? 1u : 0u) << (d * 4u);
                 }
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
             const uint32_t k[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t d = digit_of(k[q] - bias, sh);
+                const uint32_t d = digit_of(k[q], sh);
                 const bool ok = full || tile_base + (uint32_t)(r * kSortThreads + tid) * 4u + q < e;
                 c += (uint64_t)(ok ? 1u : 0u) << (d * 4u);
             }
@@ -281,8 +281,7 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
     const SortParams* __restrict__ params, const uint32_t* __restrict__ in_lo,
     const uint32_t* __restrict__ in_hi, const uint32_t* __restrict__ in_id,
     uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_hi, uint32_t* __restrict__ out_id,
-    const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base, uint32_t shift,
-    uint32_t hi_bias) {
+    const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base, uint32_t shift) {
     __shared__ uint32_t s_lo[kSortTile];
     __shared__ uint32_t s_hi[kSortTile];
     __shared__ uint32_t s_id[kSortTile];
@@ -337,7 +336,7 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
         for (int r = 0; r < kSortKeysPerThread; ++r) {
             const uint32_t idx = base + r * 64;
             const bool ok = idx < e;
-            const uint32_t dg = digit_of(use_hi ? k.hi[r] - hi_bias : k.lo[r], sh);
+            const uint32_t dg = digit_of(use_hi ? k.hi[r] : k.lo[r], sh);
             uint64_t mask = __ballot(ok);
 #pragma unroll
             for (int b = 0; b < kRadixBits; ++b) {
@@ -388,7 +387,7 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
         for (int r = 0; r < kSortKeysPerThread; ++r) {
             const uint32_t idx = base + r * 64;
             if (idx < e) {
-                const uint32_t dg = digit_of(use_hi ? k.hi[r] - hi_bias : k.lo[r], sh);
+                const uint32_t dg = digit_of(use_hi ? k.hi[r] : k.lo[r], sh);
 #if GS_SCATTER_ABLATE & 4
                 const uint32_t p = rank[r];
 #else
@@ -409,7 +408,7 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
             const uint32_t p = (uint32_t)r * kSortThreads + tid;
             if (p < valid) {
                 const uint32_t l = LO_IN != 0 ? s_lo[p] : 0u, h = s_hi[p];
-                const uint32_t d = digit_of(use_hi ? h - hi_bias : l, sh);
+                const uint32_t d = digit_of(use_hi ? h : l, sh);
 #if GS_SCATTER_ABLATE & 8
                 const uint32_t o = tile_base + p + 13u + (d & 0u) < e ? tile_base + p + 13u : p;   // contiguous but misaligned
 #elif GS_SCATTER_ABLATE & 5
@@ -433,10 +432,9 @@ __global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
 }
 
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
-                      hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit, uint32_t tile_bias,
+                      hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit,
                       bool drop_depth_payload, bool hi16) {
     const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
-    if (hi16) tile_bias = 0;   // 16-bit tile words are stored relative to the band already
     int src = 0;
     uint32_t pass = 0;
     for (uint32_t shift = first_bit; shift < num_sort_bits; shift += kRadixBits, ++pass) { // RadixSort.cpp:309
@@ -452,11 +450,11 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
         if constexpr (kHi16Supported) {
             if (word16)
                 hipLaunchKernelGGL((k_count<0, true>), dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
-                                   word, sb.table, sb.seg_sum, lo16 ? shift - 16u : shift & 31u, 0u);
+                                   word, sb.table, sb.seg_sum, lo16 ? shift - 16u : shift & 31u);
         }
         if (!word16)
             hipLaunchKernelGGL((k_count<0, false>), dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
-                               word, sb.table, sb.seg_sum, shift & 31u, tile_pass ? tile_bias : 0u);
+                               word, sb.table, sb.seg_sum, shift & 31u);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, sb.seg_sum);
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass], stream);
         // bytes of the depth word read / written by this pass (see k_scatter)
@@ -466,7 +464,7 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
 #define GS_LAUNCH_SCATTER(LO_IN, LO_OUT, HI16)                                                                       \
         hipLaunchKernelGGL((k_scatter<LO_IN, LO_OUT, HI16>), dim3(pgrid), dim3(kSortThreads), 0, stream, sb.params, \
                            sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],                  \
-                           sb.table, sb.seg_sum, shift, tile_bias)
+                           sb.table, sb.seg_sum, shift)
 #define GS_LAUNCH_SCATTER_H(LO_IN, LO_OUT) \
         do { if (hi16) GS_LAUNCH_SCATTER(LO_IN, LO_OUT, true); else GS_LAUNCH_SCATTER(LO_IN, LO_OUT, false); } while (0)
         if (lo_in == 4 && lo_out == 4) GS_LAUNCH_SCATTER_H(4, 4);
@@ -523,9 +521,9 @@ __global__ void k_check_sorted(const uint32_t* lo, const uint32_t* hi, uint32_t 
 void launch_count_ablate(int ablate, const SortBuffers& sb, uint32_t capacity, uint32_t grid, hipStream_t stream) {
     (void)capacity; (void)grid;
     switch (ablate) {
-        case 0: hipLaunchKernelGGL(k_count<0>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u, 0u); break;
-        case 3: hipLaunchKernelGGL(k_count<2>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u, 0u); break;
-        default: hipLaunchKernelGGL(k_count<6>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u, 0u); break;
+        case 0: hipLaunchKernelGGL(k_count<0>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u); break;
+        case 3: hipLaunchKernelGGL(k_count<2>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u); break;
+        default: hipLaunchKernelGGL(k_count<6>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u); break;
     }
 }
 

@@ -269,14 +269,21 @@ __device__ __forceinline__ bool wg_radix_pass_single8(const uint32_t* src_key, c
 
 // LDS-resident sort of one tile's run of NMIN < n <= NMAX elements.  ROUNDS > 0: single-chunk passes
 // (NMAX == THREADS * ROUNDS); ROUNDS == 0: chunked passes (any NMAX that fits LDS).
+// workgroup b -> global tile id of the b-th owned tile (FrameParams: rows first_row + k * row_stride)
+struct TsTiles { uint32_t grid_w, first_row, row_stride; };
+__device__ __forceinline__ uint32_t ts_tile(const TsTiles& m, uint32_t b) {
+    const uint32_t k = b / m.grid_w;
+    return (m.first_row + k * m.row_stride) * m.grid_w + (b - k * m.grid_w);
+}
+
 template <int THREADS, int ROUNDS, uint32_t NMIN, uint32_t NMAX>
 __global__ __launch_bounds__(THREADS) void k_tile_sort_lds(const uint32_t* __restrict__ ranges,
                                                             uint32_t* __restrict__ lo,
                                                             uint32_t* __restrict__ id,
-                                                            uint32_t tile0) {
+                                                            TsTiles tiles) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     static_assert(ROUNDS == 0 || NMAX == (uint32_t)(THREADS * ROUNDS), "single-chunk capacity");
-    const uint32_t tile = tile0 + blockIdx.x;
+    const uint32_t tile = ts_tile(tiles, blockIdx.x);
     const uint32_t start = ranges[tile * 2 + 0], end = ranges[tile * 2 + 1];
     const uint32_t n = end > start ? end - start : 0u;
     if (n <= NMIN || n > NMAX) return;
@@ -318,9 +325,9 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort_lds(const uint32_t* __res
 // Oversized runs: the same passes directly on the global ping-pong halves (one workgroup per tile).
 __global__ __launch_bounds__(1024) void k_tile_sort_global(const uint32_t* __restrict__ ranges,
                                                            uint32_t* lo, uint32_t* id, uint32_t* lo_alt,
-                                                           uint32_t* id_alt, uint32_t tile0) {
+                                                           uint32_t* id_alt, TsTiles tiles) {
     __shared__ uint32_t scratch[kTsScratchWords];
-    const uint32_t tile = tile0 + blockIdx.x;
+    const uint32_t tile = ts_tile(tiles, blockIdx.x);
     const uint32_t start = ranges[tile * 2 + 0], end = ranges[tile * 2 + 1];
     const uint32_t n = end > start ? end - start : 0u;
     if (n <= kTsBigMax) return;
@@ -365,10 +372,12 @@ int init_tile_sort() {
 // The size classes touch disjoint tiles, so the rare big ones (few workgroups, whole-CU LDS) run on a
 // helper stream beside the two small classes that hold most of the work: fork after FindRanges, join
 // before RenderGaussians.
-void launch_tile_sort(const uint32_t* ranges, uint32_t tile0, uint32_t num_tiles, uint32_t* lo, uint32_t* id,
+void launch_tile_sort(const FrameParams& fp, const uint32_t* ranges, uint32_t* lo, uint32_t* id,
                       uint32_t* lo_alt, uint32_t* id_alt, hipStream_t stream, hipStream_t helper,
                       hipEvent_t fork, hipEvent_t join) {
+    const uint32_t num_tiles = fp.rows_owned * fp.grid_w;
     if (num_tiles == 0) return;
+    const TsTiles tile0{fp.grid_w, fp.first_row, fp.row_stride};
     const bool split = helper != nullptr && fork != nullptr && join != nullptr;
     hipStream_t big = split ? helper : stream;
     if (split) {

@@ -46,6 +46,64 @@ __global__ __launch_bounds__(256) void k_aos_to_soa(const float* __restrict__ ch
     }
 }
 
+// Per project workgroup (kProjThreads consecutive splats -- neighbours in space, the arrays are in Morton order): the
+// box around the positions and the largest sig2.  A context that renders a subset of the tile rows rejects whole
+// workgroups with it (k_project).  min/max are exact selections, so the box contains every position whatever the order.
+__global__ __launch_bounds__(kProjThreads) void k_block_bounds(uint32_t n, SceneBuffers s) {
+    __shared__ float s_red[kProjThreads / 64][7];
+    const uint32_t g = blockIdx.x * kProjThreads + threadIdx.x;
+    const bool ok = g < n;
+    float v[7];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float p = ok ? s.pos[(size_t)a * n + g] : 0.0f;
+        v[a] = ok ? p : 3.0e38f;        // min
+        v[3 + a] = ok ? p : -3.0e38f;   // max
+    }
+    v[6] = ok ? s.sig2[g] : 0.0f;
+    // a NaN position or bound must not be lost by fminf/fmaxf: it poisons the record instead (k_project then keeps
+    // the workgroup, every comparison with a NaN being false)
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) bad = bad || (ok && !(v[k] == v[k]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = fminf(v[k], __shfl_xor(v[k], off, 64));
+#pragma unroll
+        for (int k = 3; k < 7; ++k) v[k] = fmaxf(v[k], __shfl_xor(v[k], off, 64));
+    }
+    const bool wave_bad = __ballot(bad) != 0ull;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s_red[threadIdx.x >> 6][k] = wave_bad ? __builtin_nanf("") : v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r[8];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            float acc = s_red[0][k];
+            bool nan = !(acc == acc);
+            for (int w = 1; w < kProjThreads / 64; ++w) {
+                const float t = s_red[w][k];
+                nan = nan || !(t == t);
+                acc = k < 3 ? fminf(acc, t) : fmaxf(acc, t);
+            }
+            r[k] = nan ? __builtin_nanf("") : acc;
+        }
+        r[7] = 0.0f;
+        float4* out = reinterpret_cast<float4*>(s.block_bounds) + (size_t)blockIdx.x * 2;
+        out[0] = make_float4(r[0], r[1], r[2], r[3]);
+        out[1] = make_float4(r[4], r[5], r[6], r[7]);
+    }
+}
+
+void launch_block_bounds(uint32_t n, const SceneBuffers& s, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_block_bounds, dim3((n + kProjThreads - 1) / kProjThreads), dim3(kProjThreads), 0, stream, n, s);
+}
+
 void launch_aos_to_soa(const float* chunk, uint32_t first, uint32_t count, uint32_t n,
                        const SceneBuffers& s, hipStream_t stream) {
     if (count == 0) return;
@@ -79,6 +137,39 @@ __global__ __launch_bounds__(256) void k_stream_read(const T* __restrict__ src, 
     if (acc == 0x9E3779B9u) sink[0] = acc;   // keeps the loads alive, practically never taken
 }
 
+// Copy with four 16-byte loads in flight per lane before the first store (the plain grid-stride copy above keeps one):
+// what MI355X_MICROARCH.md's 6.3 TB/s "float4 copy" needs -- more bytes in flight per CU.  NT = 1: non-temporal
+// stores (the destination is not re-read); NT = 2: non-temporal loads too.
+template <int NT>
+__global__ __launch_bounds__(256) void k_stream_copy4(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (NT == 2) {
+                const unsigned __attribute__((ext_vector_type(4)))* p =
+                    reinterpret_cast<const unsigned __attribute__((ext_vector_type(4)))*>(src + i + k * stride);
+                const unsigned __attribute__((ext_vector_type(4))) t = __builtin_nontemporal_load(p);
+                v[k] = make_uint4(t.x, t.y, t.z, t.w);
+            } else {
+                v[k] = src[i + k * stride];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (NT >= 1) {
+                unsigned __attribute__((ext_vector_type(4))) t = {v[k].x, v[k].y, v[k].z, v[k].w};
+                __builtin_nontemporal_store(t, reinterpret_cast<unsigned __attribute__((ext_vector_type(4)))*>(dst + i + k * stride));
+            } else {
+                dst[i + k * stride] = v[k];
+            }
+        }
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
 // Radix-scatter write pattern without the sorting: the buffer is treated as three arrays of n dwords;
 // persistent workgroups read tiles of TILE consecutive dwords from each array and write every tile as
 // 16 runs of TILE/16 dwords into 16 destination regions (what a 4-bit pass with uniform digits does).
@@ -110,6 +201,9 @@ void launch_stream_probe(int kind, const void* src, void* dst, size_t bytes, uin
         case 7: hipLaunchKernelGGL(k_scatter_pattern<49152>, dim3(blocks), dim3(256), 0, stream, (const uint32_t*)src, (uint32_t*)dst, bytes / 4); return;
         case 8: hipLaunchKernelGGL((k_scatter_pattern<3072, 37>), dim3(blocks), dim3(256), 0, stream, (const uint32_t*)src, (uint32_t*)dst, bytes / 4); return;
         case 9: hipLaunchKernelGGL((k_scatter_pattern<3072, 5>), dim3(blocks), dim3(256), 0, stream, (const uint32_t*)src, (uint32_t*)dst, bytes / 4); return;
+        case 10: hipLaunchKernelGGL(k_stream_copy4<0>, dim3(blocks), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, bytes / 16); return;
+        case 11: hipLaunchKernelGGL(k_stream_copy4<1>, dim3(blocks), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, bytes / 16); return;
+        case 12: hipLaunchKernelGGL(k_stream_copy4<2>, dim3(blocks), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, bytes / 16); return;
         default: break;
     }
     switch (kind) {

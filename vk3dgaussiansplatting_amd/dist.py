@@ -31,6 +31,11 @@ def strip_rows(tiles_y: int, world_size: int, tile: int = 16) -> int:
     return ((tiles_y + world_size - 1) // world_size) * tile
 
 
+def interleaved_rows(tiles_y: int, rank: int, world_size: int) -> List[int]:
+    """Tile rows of `rank` when rows are dealt round-robin (gs_set_tile_rows_interleaved(rank, world_size))."""
+    return list(range(rank, tiles_y, world_size))
+
+
 class ShardedFrame:
     """Band render + gather.  n_strips strips (round-robin) so that the gather of frame f can run beside the
     compute of the following frames: `gather_async(k)` starts the collective on strip k, `wait(k)` orders the
@@ -42,12 +47,15 @@ class ShardedFrame:
     the CPU test (an injected checker)."""
 
     def __init__(self, width: int, height: int, rank: int, world_size: int, device="cpu", group=None,
-                 host_gather: bool = False, n_strips: int = 2):
+                 host_gather: bool = False, n_strips: int = 2, interleaved: bool = False):
         import torch
         self.torch = torch
         self.width, self.height = width, height
         self.rank, self.world = rank, world_size
         self.tiles_y = (height + 15) // 16
+        # interleaved: rank r owns tile rows r, r + world, ...; its strip holds them packed (owned row k at strip
+        # rows [16 k, 16 k + 16)), which is what a context set up with gs_set_tile_rows_interleaved(r, world, 1) writes
+        self.interleaved = interleaved
         self.bands = tile_row_partition(self.tiles_y, world_size)
         self.rows = strip_rows(self.tiles_y, world_size)
         self.group = group
@@ -100,6 +108,12 @@ class ShardedFrame:
     def assemble(self, strips) -> "np.ndarray":
         """Rank 0: strips -> [H, W, 4] image (crops the padding of the last band)."""
         img = self.torch.zeros((self.height, self.width, 4), dtype=self.torch.uint8, device=strips[0].device)
+        if self.interleaved:
+            for r in range(self.world):
+                for k, row in enumerate(interleaved_rows(self.tiles_y, r, self.world)):
+                    y0, y1 = row * 16, min(row * 16 + 16, self.height)
+                    img[y0:y1] = strips[r][k * 16: k * 16 + (y1 - y0)]
+            return img
         for r, (b, e) in enumerate(self.bands):
             y0, y1 = b * 16, min(e * 16, self.height)
             if y1 > y0:
@@ -107,7 +121,9 @@ class ShardedFrame:
         return img
 
     def frame(self, render_band: Callable, k: int = 0) -> "np.ndarray | None":
-        b, e = self.band
+        """contiguous: render_band(row_begin, row_end, strip); interleaved: render_band(rows, None, strip) with the
+        list of owned tile rows, to be written packed."""
+        b, e = (interleaved_rows(self.tiles_y, self.rank, self.world), None) if self.interleaved else self.band
         self.wait(k)
         render_band(b, e, self.strips[k])
         strips = self.gather(k)

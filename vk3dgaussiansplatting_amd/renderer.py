@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import GsConfig, GsSceneInfo, GsTimings
+from ._lib import GsConfig, GsHostTimings, GsSceneInfo, GsTimings
 
 FLOATS_PER_GAUSSIAN = 84
 GAUSSIAN_DTYPE = np.dtype([
@@ -395,7 +395,7 @@ class Renderer:
     def initForScene(self, scene: Scene | None = None, share_with: "Renderer | None" = None):
         """share_with: another Renderer whose uploaded gaussians this one renders too (gs_share_scene) -- the way
         to keep several frames in flight (GfxSettings::FRAMES_IN_FLIGHT, GfxSettings.h:15) without uploading the
-        scene once per frame slot.  The sharing renderer must be cleaned up before the one it borrows from."""
+        scene once per frame slot.  The arrays are reference-counted: clean the renderers up in any order."""
         assert self._ctx is not None, "Renderer.init() first"
         L = _lib.lib()
         if share_with is not None:
@@ -421,6 +421,11 @@ class Renderer:
     def setTileRows(self, row_begin: int, row_end: int):
         self._ctx.check(_lib.lib().gs_set_tile_rows(self._ctx.handle, row_begin, row_end))
 
+    def setTileRowsInterleaved(self, phase: int, stride: int, compact_output: bool = True):
+        """Rank `phase` of `stride`: tile rows phase, phase + stride, ...; with compact_output drawDevice writes the
+        rank's strip (owned rows packed) instead of addressing the whole frame."""
+        self._ctx.check(_lib.lib().gs_set_tile_rows_interleaved(self._ctx.handle, phase, stride, int(compact_output)))
+
     # -- Renderer.cpp:297-515
     def draw(self, scene: Scene, out: np.ndarray | None = None) -> np.ndarray:
         cam = scene.getCamera()
@@ -434,8 +439,9 @@ class Renderer:
         self._accumulate()
         return out
 
-    def drawDevice(self, scene: Scene, device_ptr: int | None = None, sync: bool = True):
-        """Same frame with the image left in HBM (device_ptr = e.g. torch tensor .data_ptr())."""
+    def drawDevice(self, scene: Scene, device_ptr: int | None = None, sync: bool = True, compact_rows: bool = False):
+        """Same frame with the image left in HBM (device_ptr = e.g. torch tensor .data_ptr()).  compact_rows only
+        documents the call site: whether rows are packed is a property of the context (setTileRowsInterleaved)."""
         cam = scene.getCamera()
         view = np.ascontiguousarray(cam.getViewMatrix(), dtype=np.float32)
         proj = np.ascontiguousarray(cam.getProjectionMatrix(), dtype=np.float32)
@@ -456,6 +462,13 @@ class Renderer:
         t = GsTimings()
         self._ctx.check(_lib.lib().gs_get_timings(self._ctx.handle, C.byref(t)))
         return t
+
+    def hostTimings(self) -> dict:
+        """RECORD_CPU_TIMES of the last draw (Renderer.cpp:399-456): waitForFence, recordCommandBuffer, present, CPU frame."""
+        t = GsHostTimings()
+        self._ctx.check(_lib.lib().gs_get_host_timings(self._ctx.handle, C.byref(t)))
+        return {"wait_for_gpu": round(t.wait_ms, 4), "record_commands": round(t.record_ms, 4),
+                "present": round(t.present_ms, 4), "cpu_frame": round(t.cpu_frame_ms, 4)}
 
     def _accumulate(self):  # Renderer.cpp:477-488
         t = self.timings()
