@@ -3,6 +3,9 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401 -- first, so that the process has ONE HIP runtime: torch's bundled libamdhip64 and the /opt/rocm one
+              # the library links share a SONAME, and torch.cuda fails to initialise ("No HIP GPUs are available") when
+              # the library has brought the other copy up before torch is imported (seen with a test subset on the GPU box)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

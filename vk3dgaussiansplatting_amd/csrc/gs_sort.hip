@@ -27,6 +27,8 @@
 #include "gs_device_utils.h"
 #include "gs_internal.h"
 
+#include <type_traits>
+
 namespace gs {
 
 __device__ __forceinline__ uint32_t digit_of(uint32_t word, uint32_t sh) { return (word >> sh) & 15u; }
@@ -36,11 +38,6 @@ constexpr int kSortWaves = kSortThreads / 64;
 // ---------------------------------------------------------------------------------------------
 // Count + Reduce
 // ---------------------------------------------------------------------------------------------
-#ifndef GS_SCATTER_GRID
-#define GS_SCATTER_GRID 1048576 // cap on k_scatter's grid: above it workgroups walk several groups.  One workgroup per
-                                // group (no cap in practice) measured faster than 1024 persistent ones once the
-                                // payload shrank: 39.8 / 45.4 / 52.3 us against 45.3 / 50.9 / 58.7 for the 12 / 16 / 20-byte passes
-#endif
 
 // Count + Reduce.  Persistent workgroups walk the groups (tiles) with a stride of gridDim and
 // prefetch the next group's keys while counting the current one, so HBM never idles between the
@@ -208,227 +205,231 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ seg_sum) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Scan + ScanAdd (prologue) + Scatter.  Persistent workgroups, next group's keys prefetched into
-// registers while the current group is ranked, staged and stored.
+// ScanAdd (prologue) + Scatter: one workgroup per group of kSortTile keys, two barriers.
+//
+//   loads      the group's keys and payload, striped (key r of lane l of wave w is element w*512 + r*64 + l of the
+//              group: every load instruction of a wave covers 64 consecutive elements), all issued up front
+//              together with the ScanAdd inputs
+//   ScanAdd    every wave, redundantly, in registers: lane d + 16 q sums the table entries l = q, q+4, ... of digit
+//              d for the earlier groups of the segment; two cross-row adds and the scanned segment base give the
+//              global index of the group's first key of digit d in lanes d, d+16, d+32, d+48
+//   rank       per round of 64 keys: 4 ballots give every lane the mask of lanes holding the same digit (stable
+//              rank inside the round = v_mbcnt of it); lane d keeps the wave's running count of digit d
+//   barrier 1  the four waves' digit counts meet in LDS; every wave derives, again redundantly in lanes 0..15 (DPP
+//              scan inside the 16-lane row), the local start of each digit, its own base and the global offset
+//   stage      keys + payload to their sorted local position in LDS, one 8-byte slot per element (plus a third word
+//              when 12 or more bytes travel)
+//   barrier 2
+//   store      position p = r*256 + tid read back linearly; consecutive local positions of one digit are
+//              consecutive global indices (RadixSortScatter.comp:153-168): run-wise coalesced stores
+// The group count (not the list capacity) bounds the work: surplus workgroups leave at once.
 // ---------------------------------------------------------------------------------------------
-struct ScatterKeys {
-    uint32_t lo[kSortKeysPerThread], hi[kSortKeysPerThread], id[kSortKeysPerThread];
-};
-
-template <int LO_IN, bool HI16>
-__device__ __forceinline__ void scatter_load(const uint32_t* __restrict__ in_lo,
-                                             const uint32_t* __restrict__ in_hi,
-                                             const uint32_t* __restrict__ in_id, uint32_t base,
-                                             uint32_t e, ScatterKeys& k) {
-#pragma unroll
-    for (int r = 0; r < kSortKeysPerThread; ++r) {   // coalesced: 256 contiguous bytes per wave-instruction
-        const uint32_t idx = base + r * 64;
-        const bool ok = idx < e;
-        if constexpr (LO_IN == 4) k.lo[r] = ok ? in_lo[idx] : 0xFFFFFFFFu;
-        else if constexpr (LO_IN == 2) k.lo[r] = ok ? (uint32_t)reinterpret_cast<const uint16_t*>(in_lo)[idx] : 0xFFFFu;
-        else k.lo[r] = 0u;
-        if constexpr (HI16) k.hi[r] = ok ? (uint32_t)reinterpret_cast<const uint16_t*>(in_hi)[idx] : 0xFFFFu;
-        else k.hi[r] = ok ? in_hi[idx] : 0xFFFFFFFFu;
-        k.id[r] = ok ? in_id[idx] : 0u;
-    }
-}
-
-// ScanAdd inputs of one group for this wave's four digits: the lane's share of the per-group counts of the earlier
-// groups of the segment, and the scanned segment base.
-struct ScanAddRegs {
-    uint32_t pre[kBins / kSortWaves], base[kBins / kSortWaves];
-};
-
-__device__ __forceinline__ void scan_add_load(const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base,
-                                              uint32_t grp, uint32_t G, uint32_t K, int wave, int lane, ScanAddRegs& sa) {
-    const uint32_t seg = grp / K, j = grp - seg * K;   // j < K (K <= 64 up to 134 M elements)
-#pragma unroll
-    for (int q = 0; q < kBins / kSortWaves; ++q) {
-        const int d = wave * (kBins / kSortWaves) + q;
-        uint32_t pre = 0;
-        for (uint32_t l0 = 0; l0 < j; l0 += 64)
-            pre += l0 + (uint32_t)lane < j ? table[d * G + seg * K + l0 + lane] : 0u;
-        sa.pre[q] = pre;
-        sa.base[q] = seg_base[d * kSegments + seg];
-    }
-}
-
-// GS_SCATTER_ABLATE: timing-only builds (tools/build_variants.sh), never shipped.  bit 0: stores go to
-// the tile's own range (no scatter pattern); bit 1: no global stores; bit 2: no ranking.
-// Measured at E = 13.1 M (MI355X): full 71.7 us; identity stores 55.4; no stores 44.5; no ranking +
-// identity stores 48.7; neither 18.3.  An XCD-contiguous walk of the groups (so that neighbouring
-// runs meet in one L2) measured 74.5 us -- slower, not kept.
 #ifndef GS_SCATTER_ABLATE
-#define GS_SCATTER_ABLATE 0
+#define GS_SCATTER_ABLATE 0     // timing-only builds (tools/build_variants.sh), never shipped.  bit 0: stores go to the
+                                // group's own range (no scatter pattern); bit 1: no global stores; bit 2: no ranking
 #endif
-#ifndef GS_SCATTER_PREFETCH
-#define GS_SCATTER_PREFETCH 0   // 1: keep the next group's keys in registers while working on the current one (only
-                                // useful with a persistent grid, see GS_SCATTER_GRID)
+#ifndef GS_RANK_XNOR
+#define GS_RANK_XNOR 1
 #endif
-#ifndef GS_SCATTER_MINWAVES
-#define GS_SCATTER_MINWAVES 5
+#ifndef GS_SCATTER_MINWAVES_KEY
+#define GS_SCATTER_MINWAVES_KEY 5    // resident workgroups per CU asked of the compiler: passes that carry 12 or more bytes
 #endif
+#ifndef GS_SCATTER_MINWAVES_SMALL
+#define GS_SCATTER_MINWAVES_SMALL 5  // ... passes whose element fits one 8-byte LDS slot
+#endif
+
+// inclusive prefix sum inside each row of 16 lanes (DPP row_shr 1/2/4/8; lanes shifted in from outside the row add 0)
+__device__ __forceinline__ uint32_t row16_inclusive_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);   // row_shr:8
+    return v;
+}
+
 // LO_IN / LO_OUT = bytes of the depth word read / written per element (4, 2 or 0).  The stand-alone sorter
 // (gs_sort_host) and GS_SORT_TILE_BUCKET use <4, 4>: everything moves.  In a frame the depth word is needed only as a
 // sort key -- FindRanges reads the tile words, RenderGaussians the ids, gs_debug_read rebuilds the sorted depth
 // words from the ids -- so bits a pass has consumed are dead weight: passes 0-2 run <4, 4>, pass 3 writes only the
 // upper half <4, 2>, passes 4-6 sort on that half <2, 2>, pass 7 (last depth digit) does not write it <2, 0>, and the
 // tile-word passes run <0, 0>.
-// HI16: the tile words are stored as 16-bit ids relative to the band's first tile (any grid of at most 65535 tiles):
-// 2 bytes less read and 2 less written per element in every pass.
-template <int LO_IN, int LO_OUT, bool HI16>
-__global__ __launch_bounds__(kSortThreads, GS_SCATTER_MINWAVES) void k_scatter(
-    const SortParams* __restrict__ params, const uint32_t* __restrict__ in_lo,
+// HI16: the tile words are 16-bit compact tile ids (at most 65535 owned tiles): 2 bytes less read and 2 less written
+// per element in every pass.
+// FULL: the group holds kSortTile valid keys (every group but the last): no per-element bounds logic.
+template <int LO_IN, int LO_OUT, bool HI16, bool FULL>
+__device__ __forceinline__ void scatter_group(
+    uint32_t e, uint32_t G, uint32_t K, uint32_t grp, const uint32_t* __restrict__ in_lo,
     const uint32_t* __restrict__ in_hi, const uint32_t* __restrict__ in_id,
     uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_hi, uint32_t* __restrict__ out_id,
-    const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base, uint32_t shift) {
-    __shared__ uint32_t s_lo[kSortTile];
-    __shared__ uint32_t s_hi[kSortTile];
-    __shared__ uint32_t s_id[kSortTile];
-    __shared__ uint32_t s_wcnt[kSortWaves][kBins];
-    __shared__ uint32_t s_wbase[kSortWaves][kBins];
-    __shared__ uint32_t s_gpre[kBins];   // ScanAdd: global index of the first key of digit d of this group
-    __shared__ int32_t s_gbase[kBins];
-
-    const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
-    uint32_t grp = blockIdx.x;
-    if (grp >= G) return;
+    const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base, uint32_t shift,
+    uint2* s_slot, typename std::conditional<HI16, uint16_t, uint32_t>::type* s_third, uint32_t* s_wcnt) {
+    constexpr int R = kSortKeysPerThread;
+    // what travels beside the 8-byte slot {id, word}: nothing when the element is id + one 32-bit word (tile-word
+    // passes; depth passes whose depth and tile words are both 16 bits wide), else the tile word (s_third)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool use_hi = shift >= 32u;
     const uint32_t sh = use_hi ? shift - 32u : (LO_IN == 2 ? shift - 16u : shift);   // bit offset inside the stored word
-    const uint32_t wave_off = (uint32_t)wave * (kSortKeysPerThread * 64) + lane;
+    const uint32_t tile_base = grp * kSortTile;
+    const uint32_t base = tile_base + (uint32_t)wave * (R * 64) + lane;
+    const uint32_t valid = FULL ? (uint32_t)kSortTile : e - tile_base;
 
-#if GS_SCATTER_PREFETCH
-    ScatterKeys nxt;
-    scatter_load<LO_IN, HI16>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, nxt);
-#endif
-    ScanAddRegs sa_nxt;
-    scan_add_load(table, seg_base, grp, G, K, wave, lane, sa_nxt);
+    // ---- ScanAdd inputs (L2-resident table of the Count launch) and the group's elements: every load up front
+    const uint32_t seg = grp / K, j = grp - seg * K;
+    const int sd = lane & 15, sq = lane >> 4;
+    uint32_t pre = 0;
+    for (uint32_t l = (uint32_t)sq; l < j; l += 4u) pre += table[sd * G + seg * K + l];
+    const uint32_t segb = seg_base[sd * kSegments + seg];
 
-    for (; grp < G; grp += gridDim.x) {
-#if GS_SCATTER_PREFETCH
-        ScatterKeys k = nxt;
-        if (grp + gridDim.x < G)
-            scatter_load<LO_IN, HI16>(in_lo, in_hi, in_id, (grp + gridDim.x) * kSortTile + wave_off, e, nxt); // prefetch
-#else
-        ScatterKeys k;
-        scatter_load<LO_IN, HI16>(in_lo, in_hi, in_id, grp * kSortTile + wave_off, e, k);
-#endif
-        const ScanAddRegs sa = sa_nxt;
-        if (grp + gridDim.x < G) scan_add_load(table, seg_base, grp + gridDim.x, G, K, wave, lane, sa_nxt);
-        const uint32_t tile_base = grp * kSortTile;
-        const uint32_t base = tile_base + wave_off;
-
-        // ---- ScanAdd: keys of digit d in all groups before this one = scanned segment base +
-        //      counts of the earlier groups of the same segment (wave w: digits 4w..4w+3).  The table
-        //      reads were issued one group ahead (scan_add_load), only the wave sums happen here.
+    uint32_t lo[R], hi[R], id[R];
+    {
+        const uint16_t* lo16 = reinterpret_cast<const uint16_t*>(in_lo) + base;
+        const uint16_t* hi16 = reinterpret_cast<const uint16_t*>(in_hi) + base;
+        const uint32_t *lo32 = in_lo + base, *hi32 = in_hi + base, *id32 = in_id + base;
 #pragma unroll
-        for (int q = 0; q < kBins / kSortWaves; ++q) {
-            const int d = wave * (kBins / kSortWaves) + q;
-            const uint32_t pre = wave_sum_to_lane63(sa.pre[q]);
-            if (lane == 63) s_gpre[d] = pre + sa.base[q];
+        for (int r = 0; r < R; ++r) {   // coalesced: 64 consecutive elements per wave-instruction
+            const bool ok = FULL || base + r * 64 < e;
+            if constexpr (HI16) hi[r] = ok ? (uint32_t)hi16[r * 64] : 0xFFFFu;
+            else hi[r] = ok ? hi32[r * 64] : 0xFFFFFFFFu;
+            if constexpr (LO_IN == 4) lo[r] = ok ? lo32[r * 64] : 0xFFFFFFFFu;
+            else if constexpr (LO_IN == 2) lo[r] = ok ? (uint32_t)lo16[r * 64] : 0xFFFFu;
+            else lo[r] = 0u;
         }
-        // ---- stable rank inside the wave.  Per round: 4 ballots give every lane the mask of lanes
-        //      holding the same digit; lane d (d < 16) keeps the wave's running count of digit d.
-        uint32_t rank[kSortKeysPerThread];
-        uint32_t cntreg = 0;
 #pragma unroll
-        for (int r = 0; r < kSortKeysPerThread; ++r) {
-            const uint32_t idx = base + r * 64;
-            const bool ok = idx < e;
-            const uint32_t dg = digit_of(use_hi ? k.hi[r] : k.lo[r], sh);
-            uint64_t mask = __ballot(ok);
-#pragma unroll
-            for (int b = 0; b < kRadixBits; ++b) {
-                const bool bit = (dg >> b) & 1u;
-                const uint64_t bal = __ballot(bit);
-                mask &= bit ? bal : ~bal;
-            }
-            mask = ok ? mask : 0ull;
-            const uint32_t in_round = mbcnt(mask);
-            const uint32_t n_round = (uint32_t)__popcll(mask);
-            const uint32_t before = (uint32_t)__shfl((int)cntreg, (int)dg, 64);
-            rank[r] = before + in_round;
-            // the first lane of every digit group sends the group's size to counter lane `dg`;
-            // everybody else sends to lane 63, which holds no counter
-            const bool leader = ok && in_round == 0u;
-            const int dest = leader ? (int)dg : 63;
-            const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)n_round);
-            cntreg += lane < kBins ? recv : 0u;
-#if GS_SCATTER_ABLATE & 4
-            rank[r] = (uint32_t)(wave * kSortKeysPerThread + r) * 64u + lane;   // linear position
-#endif
-        }
-        if (lane < kBins) s_wcnt[wave][lane] = cntreg;
-        __syncthreads();
-
-        // ---- local digit starts, per-wave bases, global base (threads 0..15, one per digit)
-        if (tid < kBins) {
-            uint32_t c[kSortWaves];
-            uint32_t tot = 0;
-#pragma unroll
-            for (int w = 0; w < kSortWaves; ++w) { c[w] = s_wcnt[w][tid]; tot += c[w]; }
-            uint32_t inc = tot;
-#pragma unroll
-            for (int off = 1; off < kBins; off <<= 1) {
-                const uint32_t t = __shfl_up(inc, off, 64);
-                if (tid >= off) inc += t;
-            }
-            const uint32_t dstart = inc - tot;       // first local position of digit d
-            uint32_t run = dstart;
-#pragma unroll
-            for (int w = 0; w < kSortWaves; ++w) { s_wbase[w][tid] = run; run += c[w]; }
-            s_gbase[tid] = (int32_t)(s_gpre[tid] - dstart); // global = s_gbase[d] + local pos
-        }
-        __syncthreads();
-
-        // ---- local sort into LDS
-#pragma unroll
-        for (int r = 0; r < kSortKeysPerThread; ++r) {
-            const uint32_t idx = base + r * 64;
-            if (idx < e) {
-                const uint32_t dg = digit_of(use_hi ? k.hi[r] : k.lo[r], sh);
-#if GS_SCATTER_ABLATE & 4
-                const uint32_t p = rank[r];
-#else
-                const uint32_t p = s_wbase[wave][dg] + rank[r];
-#endif
-                if constexpr (LO_IN != 0) s_lo[p] = k.lo[r];
-                s_hi[p] = k.hi[r];
-                s_id[p] = k.id[r];
-            }
-        }
-        __syncthreads();
-
-        // ---- run-wise coalesced stores: consecutive local positions of one digit are consecutive
-        //      global indices (RadixSortScatter.comp:153-168)
-        const uint32_t valid = (e - tile_base) < (uint32_t)kSortTile ? (e - tile_base) : (uint32_t)kSortTile;
-#pragma unroll
-        for (int r = 0; r < kSortKeysPerThread; ++r) {
-            const uint32_t p = (uint32_t)r * kSortThreads + tid;
-            if (p < valid) {
-                const uint32_t l = LO_IN != 0 ? s_lo[p] : 0u, h = s_hi[p];
-                const uint32_t d = digit_of(use_hi ? h : l, sh);
-#if GS_SCATTER_ABLATE & 8
-                const uint32_t o = tile_base + p + 13u + (d & 0u) < e ? tile_base + p + 13u : p;   // contiguous but misaligned
-#elif GS_SCATTER_ABLATE & 5
-                const uint32_t o = tile_base + p + (d & 0u);
-#else
-                const uint32_t o = (uint32_t)(s_gbase[d] + (int32_t)p);
-#endif
-#if GS_SCATTER_ABLATE & 2
-                if (l == 0x12345678u && h == 0x9abcdef0u) out_lo[o] = l;   // keeps the pipeline alive, ~never taken
-#else
-                if constexpr (LO_OUT == 4) out_lo[o] = l;
-                else if constexpr (LO_OUT == 2) reinterpret_cast<uint16_t*>(out_lo)[o] = (uint16_t)(LO_IN == 4 ? l >> 16 : l);
-                if constexpr (HI16) reinterpret_cast<uint16_t*>(out_hi)[o] = (uint16_t)h;
-                else out_hi[o] = h;
-                out_id[o] = s_id[p];
-#endif
-            }
-        }
-        __syncthreads();   // LDS is reused by the next group
+        for (int r = 0; r < R; ++r) id[r] = (FULL || base + r * 64 < e) ? id32[r * 64] : 0u;
     }
+
+    // ---- ScanAdd: global index of the group's first key of digit sd (lanes sd, sd + 16, sd + 32, sd + 48)
+    pre += (uint32_t)__shfl_xor((int)pre, 16, 64);
+    pre += (uint32_t)__shfl_xor((int)pre, 32, 64);
+    const uint32_t gpre = pre + segb;
+
+    // ---- stable rank inside the wave.  Per round: 4 ballots give every lane the mask of lanes holding the same
+    //      digit; lane d (d < 16) keeps the wave's running count of digit d.
+    uint32_t rank[R];
+    uint32_t cntreg = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool ok = FULL || base + r * 64 < e;
+        const uint32_t kw = use_hi ? hi[r] : lo[r];
+        const uint32_t dg = digit_of(kw, sh);
+#if GS_RANK_XNOR
+        // per digit bit b: S = all ones where the lane's bit is set (one signed bit-field extract), the ballot of the
+        // bit, and XNOR(ballot, S) = the lanes that agree with this lane on bit b; AND over the four bits
+        uint32_t m_lo = 0xFFFFFFFFu, m_hi = 0xFFFFFFFFu;
+        if (!FULL) { const uint64_t v = __ballot(ok); m_lo = (uint32_t)v; m_hi = (uint32_t)(v >> 32); }
+#pragma unroll
+        for (int b = 0; b < kRadixBits; ++b) {
+            const int32_t sbit = __builtin_amdgcn_sbfe((int32_t)kw, sh + (uint32_t)b, 1u);
+            const uint64_t bal = __ballot(sbit != 0);
+            m_lo &= ~((uint32_t)bal ^ (uint32_t)sbit);
+            m_hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)sbit);
+        }
+        uint64_t mask = ((uint64_t)m_hi << 32) | m_lo;
+#else
+        uint64_t mask = FULL ? ~0ull : __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; ++b) {
+            const bool bit = (dg >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            mask &= bit ? bal : ~bal;
+        }
+#endif
+        if (!FULL) mask = ok ? mask : 0ull;
+        const uint32_t in_round = mbcnt(mask);
+        const uint32_t n_round = (uint32_t)__popcll(mask);
+        const uint32_t before = (uint32_t)__shfl((int)cntreg, (int)dg, 64);
+        rank[r] = before + in_round;
+        // the first lane of every digit group sends the group's size to counter lane `dg`;
+        // everybody else sends to lane 63, which holds no counter
+        const bool leader = ok && in_round == 0u;
+        const int dest = leader ? (int)dg : 63;
+        const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)n_round);
+        cntreg += lane < kBins ? recv : 0u;
+#if GS_SCATTER_ABLATE & 4
+        rank[r] = (uint32_t)(wave * R + r) * 64u + lane;   // linear position
+#endif
+    }
+    if (lane < kBins) s_wcnt[lane * kSortWaves + wave] = cntreg;
+    __syncthreads();
+
+    // ---- local digit starts, this wave's bases, global offset: lane d of every row of 16 (all four rows alike)
+    uint32_t wbase, gofs;
+    {
+        static_assert(kSortWaves == 4, "one 16-byte LDS read per digit");
+        const uint4 c = *reinterpret_cast<const uint4*>(&s_wcnt[sd * kSortWaves]);
+        const uint32_t tot = c.x + c.y + c.z + c.w;
+        const uint32_t dstart = row16_inclusive_scan(tot) - tot;        // first local position of digit sd
+        wbase = dstart + (wave > 0 ? c.x : 0u) + (wave > 1 ? c.y : 0u) + (wave > 2 ? c.z : 0u);
+        gofs = gpre - dstart;                                            // global = gofs(digit) + local position
+    }
+
+    // ---- local sort into LDS.  The cross-lane reads run with every lane active (a lane past the end of a ragged
+    //      group must still SERVE its wbase to the others: ds_bpermute returns 0 for a masked-off source lane)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t dg = digit_of(use_hi ? hi[r] : lo[r], sh);
+#if GS_SCATTER_ABLATE & 4
+        const uint32_t p = rank[r];
+#else
+        const uint32_t p = (uint32_t)__shfl((int)wbase, (int)dg, 64) + rank[r];
+#endif
+        if (FULL || base + r * 64 < e) {
+            if constexpr (LO_IN == 0) s_slot[p] = make_uint2(id[r], hi[r]);
+            else if constexpr (LO_IN == 2 && HI16) s_slot[p] = make_uint2(id[r], lo[r] | (hi[r] << 16));
+            else { s_slot[p] = make_uint2(id[r], lo[r]); s_third[p] = (typename std::conditional<HI16, uint16_t, uint32_t>::type)hi[r]; }
+        }
+    }
+    __syncthreads();
+
+    // ---- run-wise coalesced stores (positions past `valid` read stale LDS: their digit only feeds a cross-lane
+    //      read that must run unmasked, nothing of theirs is stored)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t p = (uint32_t)r * kSortThreads + tid;
+        const uint2 sl = s_slot[p];
+        uint32_t l, h;
+        if constexpr (LO_IN == 0) { l = 0u; h = sl.y; }
+        else if constexpr (LO_IN == 2 && HI16) { l = sl.y & 0xFFFFu; h = sl.y >> 16; }
+        else { l = sl.y; h = s_third[p]; }
+        const uint32_t d = digit_of(use_hi ? h : l, sh);
+#if GS_SCATTER_ABLATE & 5
+        const uint32_t o = tile_base + p + (d & 0u);
+#else
+        const uint32_t o = (uint32_t)__shfl((int)gofs, (int)d, 64) + p;
+#endif
+        if (FULL || p < valid) {
+#if GS_SCATTER_ABLATE & 2
+            if (l == 0x12345678u && h == 0x9abcdef0u) out_lo[o] = l;   // keeps the pipeline alive, ~never taken
+#else
+            if constexpr (LO_OUT == 4) out_lo[o] = l;
+            else if constexpr (LO_OUT == 2) reinterpret_cast<uint16_t*>(out_lo)[o] = (uint16_t)(LO_IN == 4 ? l >> 16 : l);
+            if constexpr (HI16) reinterpret_cast<uint16_t*>(out_hi)[o] = (uint16_t)h;
+            else out_hi[o] = h;
+            out_id[o] = sl.x;
+#endif
+        }
+    }
+}
+
+template <int LO_IN, int LO_OUT, bool HI16>
+__global__ __launch_bounds__(kSortThreads, (LO_IN == 4 || (LO_IN == 2 && !HI16)) ? GS_SCATTER_MINWAVES_KEY : GS_SCATTER_MINWAVES_SMALL)
+void k_scatter(const SortParams* __restrict__ params, const uint32_t* __restrict__ in_lo,
+               const uint32_t* __restrict__ in_hi, const uint32_t* __restrict__ in_id,
+               uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_hi, uint32_t* __restrict__ out_id,
+               const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base, uint32_t shift) {
+    constexpr bool kThird = LO_IN == 4 || (LO_IN == 2 && !HI16);
+    __shared__ uint2 s_slot[kSortTile];
+    __shared__ typename std::conditional<HI16, uint16_t, uint32_t>::type s_third[kThird ? kSortTile : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t s_wcnt[kBins * kSortWaves];
+    const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
+    const uint32_t grp = blockIdx.x;
+    if (grp >= G) return;
+    if (grp * kSortTile + kSortTile <= e)
+        scatter_group<LO_IN, LO_OUT, HI16, true>(e, G, K, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table,
+                                                 seg_base, shift, s_slot, s_third, s_wcnt);
+    else
+        scatter_group<LO_IN, LO_OUT, HI16, false>(e, G, K, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table,
+                                                  seg_base, shift, s_slot, s_third, s_wcnt);
 }
 
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
@@ -460,7 +461,7 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
         // bytes of the depth word read / written by this pass (see k_scatter)
         int lo_in, lo_out;
         scatter_depth_bytes(shift, first_bit, drop_depth_payload, &lo_in, &lo_out);
-        const uint32_t pgrid = max_groups < (uint32_t)GS_SCATTER_GRID ? max_groups : (uint32_t)GS_SCATTER_GRID;
+        const uint32_t pgrid = max_groups;
 #define GS_LAUNCH_SCATTER(LO_IN, LO_OUT, HI16)                                                                       \
         hipLaunchKernelGGL((k_scatter<LO_IN, LO_OUT, HI16>), dim3(pgrid), dim3(kSortThreads), 0, stream, sb.params, \
                            sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],                  \
