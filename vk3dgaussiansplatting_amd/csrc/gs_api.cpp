@@ -116,7 +116,7 @@ void free_scene(gs_ctx* c) {
 
 void free_sort(SortBuffers& s) {
     for (int k = 0; k < 2; ++k) { free_dev(s.lo[k]); free_dev(s.hi[k]); free_dev(s.id[k]); }
-    free_dev(s.table); free_dev(s.seg_sum); free_dev(s.params);
+    free_dev(s.table); free_dev(s.seg_sum); free_dev(s.params); free_dev(s.coarse);
 }
 
 void drop_sort_graph(gs_ctx* c) {
@@ -154,6 +154,7 @@ int alloc_sort(gs_ctx* ctx, SortBuffers& s, uint32_t capacity) {
     HIP_TRY(ctx, hipMalloc((void**)&s.seg_sum, (size_t)kBins * kSegments * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc((void**)&s.params, sizeof(SortParams)));
     HIP_TRY(ctx, hipMemset(s.params, 0, sizeof(SortParams)));
+    HIP_TRY(ctx, hipMalloc((void**)&s.coarse, (size_t)kMaxSortPasses * kBins * kCoarse * sizeof(uint32_t)));
     return GS_OK;
 }
 
@@ -904,33 +905,6 @@ int gs_debug_render_stats(gs_ctx* c, const float* view, const float* proj, const
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_debug_render_stats: ") + hipGetErrorString(e));
-    return GS_OK;
-}
-
-// Tuning only (not declared in gsplat.h): times k_count alone with parts of it switched off.
-int gs_debug_count_bench(gs_ctx* c, uint32_t n, int ablate, uint32_t grid, uint32_t iters, float* us) {
-    if (!c || !us || n == 0 || iters == 0) return GS_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
-    SortBuffers sb{};
-    int rc = alloc_sort(c, sb, n);
-    if (rc != GS_OK) { free_sort(sb); return rc; }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipError_t e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    launch_fill_random_keys(sb.lo[0], sb.hi[0], sb.id[0], n, 8160, 1, c->stream);
-    launch_set_sort_params(sb.params, n, c->stream);
-    for (int w = 0; w < 3; ++w) launch_count_ablate(ablate, sb, n, grid, c->stream);
-    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
-    for (uint32_t i = 0; i < iters; ++i) launch_count_ablate(ablate, sb, n, grid, c->stream);
-    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    float ms = 0;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    free_sort(sb);
-    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_debug_count_bench: ") + hipGetErrorString(e));
-    *us = ms * 1e3f / (float)iters;
     return GS_OK;
 }
 

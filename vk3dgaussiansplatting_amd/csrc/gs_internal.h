@@ -33,6 +33,8 @@ constexpr int kSortTile = kSortThreads * kSortKeysPerThread; // 2048 keys
 #define GS_SEGMENTS 1024
 #endif
 constexpr int kSegments = GS_SEGMENTS;        // reduce segments = persistent Count workgroups; each owns a contiguous run of groups
+constexpr int kCoarse = 64;                   // coarse reduce segments (kSegments / kCoarse segments each): second Reduce level
+constexpr int kMaxSortPasses = 16;            // 64 key bits / 4
 
 // ---- InitSortList tiling -----------------------------------------------------------------
 constexpr int kProjThreads = 256;      // splats per workgroup in project + emit
@@ -113,7 +115,8 @@ struct SplatScratch {
 struct SortBuffers {
     uint32_t *lo[2], *hi[2], *id[2]; // ping-pong: depth word, tile word, gaussian index; [capacity]
     uint32_t* table;                 // [16][G_max]  per-group digit counts (sumTable)
-    uint32_t* seg_sum;               // [16][kSegments]  per-segment digit counts, then their exclusive scan (reduce buffer)
+    uint32_t* seg_sum;               // [16][kSegments]  per-segment digit counts (reduce buffer)
+    uint32_t* coarse;                // [kMaxSortPasses][16][kCoarse]  per-pass digit counts of the coarse segments
     SortParams* params;
 };
 
@@ -159,7 +162,6 @@ void launch_aos_to_soa(const float* chunk, uint32_t first, uint32_t count, uint3
                        const SceneBuffers& s, hipStream_t stream);
 void launch_block_bounds(uint32_t n, const SceneBuffers& s, hipStream_t stream);
 void launch_stream_probe(int kind, const void* src, void* dst, size_t bytes, uint32_t blocks, hipStream_t stream);
-void launch_count_ablate(int ablate, const SortBuffers& sb, uint32_t capacity, uint32_t grid, hipStream_t stream);
 void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
                          const uint32_t* ranges, uint8_t* rgba, uint4* stats, hipStream_t stream);
 // helpers for the stand-alone sorter entry points

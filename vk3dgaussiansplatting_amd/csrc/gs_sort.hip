@@ -10,7 +10,7 @@
 //                       reduce segment) and stores the run's 16 digit totals to seg_sum[bin][segment]
 //                       with plain stores (RadixSortReduce.comp:34-72; device atomics here cost
 //                       ~15 us per pass on MI355X, measured).
-//   k_scan     Scan   : one workgroup, exclusive scan of the 16 x 1024 segment totals in bin-major
+//   (k_scan)   Scan   : no launch of its own any more -- see k_scatter; was: one workgroup, exclusive scan of the 16 x 1024 segment totals in bin-major
 //                       order, in place (RadixSortScan.comp:29-71).
 //   k_scatter  ScanAdd: prologue -- exclusive prefix of the group's counts inside its segment,
 //                       read from the L2-resident table, plus the segment base
@@ -36,172 +36,142 @@ __device__ __forceinline__ uint32_t digit_of(uint32_t word, uint32_t sh) { retur
 constexpr int kSortWaves = kSortThreads / 64;
 
 // ---------------------------------------------------------------------------------------------
-// Count + Reduce
+// Count + Reduce.  Workgroup s owns reduce segment s = the contiguous groups [s K, s K + K); its four waves take
+// the groups round-robin, ONE WAVE PER GROUP: a lane reads 32 keys of the group with 16-byte loads (order inside a
+// group is irrelevant for a histogram), the next group's loads are in flight while the current one is counted, and
+// nothing crosses waves until the segment totals at the very end (one barrier per workgroup instead of one per
+// group).  Per-lane counters: sixteen 4-bit fields of one 64-bit register per 8 keys (a key = one shift + one add),
+// widened into 16-bit fields and summed over the wave with DPP adds; no LDS atomics.
+// W16: the word the digit lives in is stored as 16 bits (tile ids of a frame; the upper depth half in passes 4-7).
 // ---------------------------------------------------------------------------------------------
+constexpr int kCountKeysPerLane = kSortTile / 64;   // 32
+static_assert(kCountKeysPerLane % 8 == 0, "k_count consumes the group in chunks of 8 keys per lane");
 
-// Count + Reduce.  Persistent workgroups walk the groups (tiles) with a stride of gridDim and
-// prefetch the next group's keys while counting the current one, so HBM never idles between the
-// load / count / store phases of a group.  16-byte coalesced loads (order inside the tile is
-// irrelevant for a histogram); per-thread counters packed 8 x 8 bit in two 64-bit registers,
-// widened to 16-bit fields and summed across the wave with six DPP adds per word; no LDS atomics.
-static_assert(kSortKeysPerThread % 4 == 0 && kSortKeysPerThread <= 252, "packed 8-bit counters");
-constexpr int kCountVec = kSortKeysPerThread / 4;
+template <bool W16>
+struct CountRegs { uint4 v[kCountKeysPerLane / (W16 ? 8 : 4)]; };
 
-// HI16: `word` is an array of 16-bit tile ids (a group of kSortTile keys is kSortTile * 2 bytes: with 8 keys per
-// thread exactly one 16-byte load, kept in v[0]).
-template <bool HI16>
-__device__ __forceinline__ void count_load(const uint32_t* __restrict__ word, uint32_t grp, uint32_t e,
-                                           int tid, uint4 (&v)[kCountVec]) {
+template <bool W16>
+__device__ __forceinline__ void count_load(const uint32_t* __restrict__ word, uint32_t grp, uint32_t e, int lane,
+                                           CountRegs<W16>& k) {
+    constexpr int V = kCountKeysPerLane / (W16 ? 8 : 4);
+    constexpr uint32_t PER = W16 ? 8u : 4u;          // keys per 16-byte load
     const uint32_t tile_base = grp * kSortTile;
-    if constexpr (HI16) {
-        static_assert(kSortKeysPerThread % 8 == 0, "16-bit count path: 8 keys per 16-byte load");
-        constexpr int V16 = kSortKeysPerThread / 8;   // 16-byte loads per thread, kept in v[0..V16)
-        const uint16_t* h = reinterpret_cast<const uint16_t*>(word);
-        if (tile_base + kSortTile <= e) {
-            const uint4* w4 = reinterpret_cast<const uint4*>(h + tile_base);
-#pragma unroll
-            for (int r = 0; r < V16; ++r) v[r] = w4[r * kSortThreads + tid];
-        } else {
-#pragma unroll
-            for (int r = 0; r < V16; ++r) {
-                uint32_t w[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t i0 = tile_base + (uint32_t)(r * kSortThreads + tid) * 8u + (uint32_t)q * 2u;
-                    const uint32_t a = i0 < e ? h[i0] : 0u, b = i0 + 1 < e ? h[i0 + 1] : 0u;
-                    w[q] = a | (b << 16);
-                }
-                v[r] = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-        }
-        return;
-    }
     if (tile_base + kSortTile <= e) {
-        const uint4* w4 = reinterpret_cast<const uint4*>(word + tile_base);
+        const uint4* w4 = W16 ? reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(word) + tile_base)
+                              : reinterpret_cast<const uint4*>(word + tile_base);
 #pragma unroll
-        for (int r = 0; r < kCountVec; ++r) v[r] = w4[r * kSortThreads + tid];
-    } else {   // ragged last tile: element-wise, missing keys marked with an impossible pattern below
+        for (int r = 0; r < V; ++r) k.v[r] = w4[r * 64 + lane];
+    } else {   // ragged last group: element-wise; keys past the end are skipped by the bounds test of the count
 #pragma unroll
-        for (int r = 0; r < kCountVec; ++r) {
-            const uint32_t i0 = tile_base + (uint32_t)(r * kSortThreads + tid) * 4u;
-            v[r].x = i0 + 0 < e ? word[i0 + 0] : 0u;
-            v[r].y = i0 + 1 < e ? word[i0 + 1] : 0u;
-            v[r].z = i0 + 2 < e ? word[i0 + 2] : 0u;
-            v[r].w = i0 + 3 < e ? word[i0 + 3] : 0u;
+        for (int r = 0; r < V; ++r) {
+            const uint32_t i0 = tile_base + (uint32_t)(r * 64 + lane) * PER;
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (W16) {
+                    const uint16_t* h = reinterpret_cast<const uint16_t*>(word);
+                    const uint32_t i = i0 + 2u * (uint32_t)q;
+                    w[q] = (i < e ? (uint32_t)h[i] : 0u) | ((i + 1u < e ? (uint32_t)h[i + 1u] : 0u) << 16);
+                } else {
+                    w[q] = i0 + (uint32_t)q < e ? word[i0 + q] : 0u;
+                }
+            }
+            k.v[r] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
 }
 
-// ABLATE is a tuning-only switch (gs_debug_count_bench): bit 1 drops the table store, bit 2 the
-// counting itself.  The product always launches ABLATE = 0.
-template <int ABLATE, bool HI16 = false>
+// Digit histogram of the wave's group into four 64-bit registers of 16-bit fields: a[j] holds digits j, j+4, j+8, j+12.
+template <bool W16, bool FULL>
+__device__ __forceinline__ void count_keys(const CountRegs<W16>& k, uint32_t grp, uint32_t e, int lane, uint32_t sh,
+                                           uint64_t (&a)[4]) {
+    constexpr int V = kCountKeysPerLane / (W16 ? 8 : 4);
+    constexpr uint32_t PER = W16 ? 8u : 4u;
+    constexpr int CH = W16 ? 1 : 2;                 // 16-byte loads per chunk of 8 keys
+    const uint64_t m = 0x000F000F000F000Full;
+    const uint32_t tile_base = grp * kSortTile;
+#pragma unroll
+    for (int ch = 0; ch < V / CH; ++ch) {
+        uint64_t c = 0;                             // sixteen 4-bit counters, at most 8 keys each
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int r = ch * CH + u;
+            const uint32_t w[4] = {k.v[r].x, k.v[r].y, k.v[r].z, k.v[r].w};
+            const uint32_t i0 = tile_base + (uint32_t)(r * 64 + lane) * PER;
+#pragma unroll
+            for (uint32_t q = 0; q < PER; ++q) {
+                const uint32_t key = W16 ? (w[q >> 1] >> (16u * (q & 1u))) & 0xFFFFu : w[q];
+                const uint32_t d = digit_of(key, sh);
+                const bool ok = FULL || i0 + q < e;
+                c += (uint64_t)(ok ? 1u : 0u) << (d * 4u);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] += (c >> (4 * j)) & m;
+    }
+}
+
+template <bool W16>
 __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __restrict__ params,
                                                          const uint32_t* __restrict__ word,
                                                          uint32_t* __restrict__ table,
                                                          uint32_t* __restrict__ seg_sum,
+                                                         uint32_t* __restrict__ coarse,
                                                          uint32_t sh) {
-    __shared__ uint32_t s_pack[2][kSortWaves][8];   // per-wave packed totals (two 16-bit counters per word)
+    __shared__ uint32_t s_pack[kSortWaves][8];      // wave-private: packed totals of the group the wave just counted
+    __shared__ uint32_t s_tot[kSortWaves][kBins];   // per-wave share of the segment totals
     const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // segment = blockIdx.x owns groups [seg*K, min(seg*K + K, G))
-    uint32_t grp = blockIdx.x * K;
-    const uint32_t grp_end = (grp + K < G) ? grp + K : G;
-    uint32_t seg_total = 0;     // threads 0..15: this segment's total of digit tid
-    uint4 nxt[kCountVec];
-    if (grp < grp_end) count_load<HI16>(word, grp, e, tid, nxt);
-    for (int it = 0; grp < grp_end; ++grp, it ^= 1) {
-        uint4 v[kCountVec];
-#pragma unroll
-        for (int r = 0; r < kCountVec; ++r) v[r] = nxt[r];
-        if (grp + 1 < grp_end) count_load<HI16>(word, grp + 1, e, tid, nxt);   // prefetch
-        const uint32_t tile_base = grp * kSortTile;
-        const bool full = tile_base + kSortTile <= e;
-        // per-lane counters: one 4-bit field per digit in a single 64-bit register (a lane sees at most
-        // kSortKeysPerThread <= 15 keys of a group), so a key costs one shift and one 64-bit add
-        static_assert(kSortKeysPerThread <= 15, "4-bit per-lane digit counters");
-        uint64_t c = 0;
-        if (ABLATE & 4) {
-#pragma unroll
-            for (int r = 0; r < kCountVec; ++r) c += v[r].x ^ v[r].y ^ v[r].z ^ v[r].w;
-        } else if constexpr (HI16) {
-#pragma unroll
-            for (int r = 0; r < kSortKeysPerThread / 8; ++r) {
-                const uint32_t k[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const uint32_t key = (k[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
-                    const uint32_t d = digit_of(key, sh);
-                    const bool ok = full || tile_base + (uint32_t)(r * kSortThreads + tid) * 8u + (uint32_t)q < e;
-                    c += (uint64_t)(ok ? 1u : 0u) << (d * 4u);
-                }
-            }
-        } else
-#pragma unroll
-        for (int r = 0; r < kCountVec; ++r) {
-            const uint32_t k[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t d = digit_of(k[q], sh);
-                const bool ok = full || tile_base + (uint32_t)(r * kSortThreads + tid) * 4u + q < e;
-                c += (uint64_t)(ok ? 1u : 0u) << (d * 4u);
-            }
-        }
-        // widen to 16-bit fields (a wave total is at most 64 * kSortKeysPerThread < 65536): a[j] holds digits
-        // j, j+4, j+8, j+12 in its four 16-bit fields
-        const uint64_t m = 0x000F000F000F000Full;
-        const uint64_t a[4] = {c & m, (c >> 4) & m, (c >> 8) & m, (c >> 12) & m};
+    // segment = blockIdx.x owns groups [seg*K, min(seg*K + K, G)); wave w takes groups seg*K + w, + 4, ...
+    const uint32_t grp_end = (blockIdx.x * K + K < G) ? blockIdx.x * K + K : G;
+    uint32_t grp = blockIdx.x * K + (uint32_t)wave;
+    uint32_t seg_total = 0;     // lanes 0..15: the wave's share of the segment's total of digit `lane`
+    CountRegs<W16> cur;
+    if (grp < grp_end) count_load<W16>(word, grp, e, lane, cur);
+    while (grp < grp_end) {
+        const uint32_t nxt_grp = grp + kSortWaves;
+        CountRegs<W16> nxt;
+        if (nxt_grp < grp_end) count_load<W16>(word, nxt_grp, e, lane, nxt);   // in flight while this group is counted
+        uint64_t a[4] = {0, 0, 0, 0};
+        if (grp * kSortTile + kSortTile <= e) count_keys<W16, true>(cur, grp, e, lane, sh, a);
+        else count_keys<W16, false>(cur, grp, e, lane, sh, a);
         uint32_t w[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 4; ++q) {                // a wave total is at most 2048: fits the 16-bit fields
             w[2 * q] = wave_sum_to_lane63((uint32_t)a[q]);
             w[2 * q + 1] = wave_sum_to_lane63((uint32_t)(a[q] >> 32));
         }
+        // lane 63 holds the totals; lanes 0..15 pick theirs up through the wave's own LDS words (one wave writes and
+        // reads them, DS operations of a wave execute in order: no barrier)
         if (lane == 63) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s_pack[it][wave][q] = w[q];
+            for (int q = 0; q < 8; ++q) s_pack[wave][q] = w[q];
         }
-        __syncthreads();   // s_pack is double-buffered, so one barrier per group is enough
-        if (tid < kBins) {
+        if (lane < kBins) {
             // digit d sits in u64 a[d & 3], 16-bit field d >> 2
-            const int word = (tid & 3) * 2 + (tid >> 3);
-            const int half = (tid >> 2) & 1;
-            uint32_t t = 0;
-#pragma unroll
-            for (int k = 0; k < kSortWaves; ++k) t += (s_pack[it][k][word] >> (16 * half)) & 0xFFFFu;
-            if (!(ABLATE & 2) || t == 0xFFFFFFFFu) table[tid * G + grp] = t; // RadixSortCount.comp:89, bin-major
+            const int widx = (lane & 3) * 2 + (lane >> 3);
+            const int half = (lane >> 2) & 1;
+            const uint32_t t = (s_pack[wave][widx] >> (16 * half)) & 0xFFFFu;
+            table[lane * G + grp] = t;               // RadixSortCount.comp:89, bin-major
             seg_total += t;
         }
+        if (nxt_grp < grp_end) cur = nxt;
+        grp = nxt_grp;
     }
-    if (tid < kBins) seg_sum[tid * kSegments + blockIdx.x] = seg_total;   // Reduce (zero for empty segments)
-}
-
-// ---------------------------------------------------------------------------------------------
-// Scan: exclusive scan of seg_sum[16][kSegments] in bin-major order, in place; one workgroup of 1024
-// threads, thread t owns 16*kSegments/1024 consecutive entries (16-byte loads).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ seg_sum) {
-    constexpr int PER = kBins * kSegments / 1024;      // consecutive entries per thread
-    static_assert(PER % 4 == 0 && PER >= 4, "k_scan: 16-byte loads");
-    __shared__ uint32_t s_wave_tot[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint4* p = reinterpret_cast<uint4*>(seg_sum) + tid * (PER / 4);
-    uint4 v[PER / 4];
-#pragma unroll
-    for (int q = 0; q < PER / 4; ++q) v[q] = p[q];
-    uint32_t x[PER];
-#pragma unroll
-    for (int q = 0; q < PER / 4; ++q) { x[4 * q] = v[q].x; x[4 * q + 1] = v[q].y; x[4 * q + 2] = v[q].z; x[4 * q + 3] = v[q].w; }
-    uint32_t run = 0;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) { const uint32_t t = x[q]; x[q] = run; run += t; }
-    const uint32_t inc = wave_inclusive_scan(run);
-    if (lane == 63) s_wave_tot[wave] = inc;
+    if (lane < kBins) s_tot[wave][lane] = seg_total;
     __syncthreads();
-    uint32_t base = inc - run;
-    for (int w = 0; w < wave; ++w) base += s_wave_tot[w];
+    if (tid < kBins) {
+        uint32_t t = 0;
 #pragma unroll
-    for (int q = 0; q < PER / 4; ++q)
-        p[q] = make_uint4(x[4 * q] + base, x[4 * q + 1] + base, x[4 * q + 2] + base, x[4 * q + 3] + base);
+        for (int k = 0; k < kSortWaves; ++k) t += s_tot[k][tid];
+        seg_sum[tid * kSegments + blockIdx.x] = t;   // Reduce (RadixSortReduce.comp:34-72); zero for empty segments
+        // Reduce, second level: kCoarse coarse segments of kSegments / kCoarse segments each, summed with one
+        // agent-scope atomic add per digit and workgroup (no return value, nothing waits for it; the launch boundary
+        // publishes it).  Scatter's prologue scans these 16 x kCoarse totals itself -- there is no Scan launch.
+        if (t != 0u)
+            (void)__hip_atomic_fetch_add(&coarse[tid * kCoarse + blockIdx.x / (kSegments / kCoarse)], t,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -261,8 +231,9 @@ __device__ __forceinline__ void scatter_group(
     uint32_t e, uint32_t G, uint32_t K, uint32_t grp, const uint32_t* __restrict__ in_lo,
     const uint32_t* __restrict__ in_hi, const uint32_t* __restrict__ in_id,
     uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_hi, uint32_t* __restrict__ out_id,
-    const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base, uint32_t shift,
-    uint2* s_slot, typename std::conditional<HI16, uint16_t, uint32_t>::type* s_third, uint32_t* s_wcnt) {
+    const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_sum, const uint32_t* __restrict__ coarse,
+    uint32_t shift, uint2* s_slot, typename std::conditional<HI16, uint16_t, uint32_t>::type* s_third,
+    uint32_t* s_wcnt, uint32_t* s_pre) {
     constexpr int R = kSortKeysPerThread;
     // what travels beside the 8-byte slot {id, word}: nothing when the element is id + one 32-bit word (tile-word
     // passes; depth passes whose depth and tile words are both 16 bits wide), else the tile word (s_third)
@@ -273,12 +244,20 @@ __device__ __forceinline__ void scatter_group(
     const uint32_t base = tile_base + (uint32_t)wave * (R * 64) + lane;
     const uint32_t valid = FULL ? (uint32_t)kSortTile : e - tile_base;
 
-    // ---- ScanAdd inputs (L2-resident table of the Count launch) and the group's elements: every load up front
-    const uint32_t seg = grp / K, j = grp - seg * K;
+    // ---- Scan + ScanAdd inputs (L2-resident outputs of the Count launch) and the group's elements: every load up
+    //      front.  Keys of digit d ahead of this group = all keys of smaller digits (totals over the coarse segments)
+    //      + digit d in earlier coarse segments + in earlier segments of this coarse segment + in earlier groups of
+    //      this segment (RadixSortScan.comp:29-71 and RadixSortScanAdd.comp:34-66, evaluated where they are used).
+    constexpr uint32_t kFinePerCoarse = kSegments / kCoarse;
+    const uint32_t seg = grp / K, j = grp - seg * K;                  // j < K (K <= 64 up to 134 M elements)
+    const uint32_t cseg = seg / kFinePerCoarse, jf = seg - cseg * kFinePerCoarse;
     const int sd = lane & 15, sq = lane >> 4;
+    // thread t: digit t >> 4, coarse segments 4 (t & 15) .. + 3
+    static_assert(kCoarse == 64 && kSortThreads == 256, "one 16-byte load per thread covers the coarse totals");
+    const uint4 cv = reinterpret_cast<const uint4*>(coarse)[tid];
     uint32_t pre = 0;
     for (uint32_t l = (uint32_t)sq; l < j; l += 4u) pre += table[sd * G + seg * K + l];
-    const uint32_t segb = seg_base[sd * kSegments + seg];
+    for (uint32_t l = (uint32_t)sq; l < jf; l += 4u) pre += seg_sum[sd * kSegments + cseg * kFinePerCoarse + l];
 
     uint32_t lo[R], hi[R], id[R];
     {
@@ -298,10 +277,19 @@ __device__ __forceinline__ void scatter_group(
         for (int r = 0; r < R; ++r) id[r] = (FULL || base + r * 64 < e) ? id32[r * 64] : 0u;
     }
 
-    // ---- ScanAdd: global index of the group's first key of digit sd (lanes sd, sd + 16, sd + 32, sd + 48)
+    // ---- per digit: total over all coarse segments, and over those before this group's (row of 16 lanes = one
+    //      digit; DPP scan inside the row, lane 15 of the row holds the sums) -> LDS, read after barrier 1
+    {
+        const uint32_t c0 = 4u * (uint32_t)(tid & 15);
+        const uint32_t all = cv.x + cv.y + cv.z + cv.w;
+        const uint32_t before = (c0 < cseg ? cv.x : 0u) + (c0 + 1u < cseg ? cv.y : 0u) + (c0 + 2u < cseg ? cv.z : 0u) +
+                                (c0 + 3u < cseg ? cv.w : 0u);
+        const uint32_t all_s = row16_inclusive_scan(all), before_s = row16_inclusive_scan(before);
+        if ((tid & 15) == 15) { s_pre[tid >> 4] = all_s; s_pre[kBins + (tid >> 4)] = before_s; }
+    }
+    // fine segments and groups ahead inside this coarse segment (every wave alike, lanes sd + 16 q)
     pre += (uint32_t)__shfl_xor((int)pre, 16, 64);
     pre += (uint32_t)__shfl_xor((int)pre, 32, 64);
-    const uint32_t gpre = pre + segb;
 
     // ---- stable rank inside the wave.  Per round: 4 ballots give every lane the mask of lanes holding the same
     //      digit; lane d (d < 16) keeps the wave's running count of digit d.
@@ -360,6 +348,9 @@ __device__ __forceinline__ void scatter_group(
         const uint32_t tot = c.x + c.y + c.z + c.w;
         const uint32_t dstart = row16_inclusive_scan(tot) - tot;        // first local position of digit sd
         wbase = dstart + (wave > 0 ? c.x : 0u) + (wave > 1 ? c.y : 0u) + (wave > 2 ? c.z : 0u);
+        // Scan: keys of smaller digits anywhere = exclusive scan of the digit totals
+        const uint32_t dtot = s_pre[sd];
+        const uint32_t gpre = (row16_inclusive_scan(dtot) - dtot) + s_pre[kBins + sd] + pre;
         gofs = gpre - dstart;                                            // global = gofs(digit) + local position
     }
 
@@ -416,26 +407,30 @@ __global__ __launch_bounds__(kSortThreads, (LO_IN == 4 || (LO_IN == 2 && !HI16))
 void k_scatter(const SortParams* __restrict__ params, const uint32_t* __restrict__ in_lo,
                const uint32_t* __restrict__ in_hi, const uint32_t* __restrict__ in_id,
                uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_hi, uint32_t* __restrict__ out_id,
-               const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base, uint32_t shift) {
+               const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_sum,
+               const uint32_t* __restrict__ coarse, uint32_t shift) {
     constexpr bool kThird = LO_IN == 4 || (LO_IN == 2 && !HI16);
     __shared__ uint2 s_slot[kSortTile];
     __shared__ typename std::conditional<HI16, uint16_t, uint32_t>::type s_third[kThird ? kSortTile : 1];
     __shared__ __attribute__((aligned(16))) uint32_t s_wcnt[kBins * kSortWaves];
+    __shared__ uint32_t s_pre[2 * kBins];
     const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
     const uint32_t grp = blockIdx.x;
     if (grp >= G) return;
     if (grp * kSortTile + kSortTile <= e)
         scatter_group<LO_IN, LO_OUT, HI16, true>(e, G, K, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table,
-                                                 seg_base, shift, s_slot, s_third, s_wcnt);
+                                                 seg_sum, coarse, shift, s_slot, s_third, s_wcnt, s_pre);
     else
         scatter_group<LO_IN, LO_OUT, HI16, false>(e, G, K, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table,
-                                                  seg_base, shift, s_slot, s_third, s_wcnt);
+                                                  seg_sum, coarse, shift, s_slot, s_third, s_wcnt, s_pre);
 }
 
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit,
                       bool drop_depth_payload, bool hi16) {
     const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
+    // the coarse digit totals of every pass (Count adds into them with atomics): cleared once per sort
+    (void)hipMemsetAsync(sb.coarse, 0, (size_t)kMaxSortPasses * kBins * kCoarse * sizeof(uint32_t), stream);
     int src = 0;
     uint32_t pass = 0;
     for (uint32_t shift = first_bit; shift < num_sort_bits; shift += kRadixBits, ++pass) { // RadixSort.cpp:309
@@ -448,15 +443,15 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
         scatter_depth_bytes(shift, first_bit, drop_depth_payload, &cin, &cout);
         const bool lo16 = !tile_pass && cin == 2;
         const bool word16 = kHi16Supported && ((tile_pass && hi16) || lo16);
+        uint32_t* coarse = sb.coarse + (size_t)pass * kBins * kCoarse;   // zeroed above; this pass's Count adds into it
         if constexpr (kHi16Supported) {
             if (word16)
-                hipLaunchKernelGGL((k_count<0, true>), dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
-                                   word, sb.table, sb.seg_sum, lo16 ? shift - 16u : shift & 31u);
+                hipLaunchKernelGGL((k_count<true>), dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
+                                   word, sb.table, sb.seg_sum, coarse, lo16 ? shift - 16u : shift & 31u);
         }
         if (!word16)
-            hipLaunchKernelGGL((k_count<0, false>), dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
-                               word, sb.table, sb.seg_sum, shift & 31u);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, sb.seg_sum);
+            hipLaunchKernelGGL((k_count<false>), dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
+                               word, sb.table, sb.seg_sum, coarse, shift & 31u);
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass], stream);
         // bytes of the depth word read / written by this pass (see k_scatter)
         int lo_in, lo_out;
@@ -465,7 +460,7 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
 #define GS_LAUNCH_SCATTER(LO_IN, LO_OUT, HI16)                                                                       \
         hipLaunchKernelGGL((k_scatter<LO_IN, LO_OUT, HI16>), dim3(pgrid), dim3(kSortThreads), 0, stream, sb.params, \
                            sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],                  \
-                           sb.table, sb.seg_sum, shift)
+                           sb.table, sb.seg_sum, coarse, shift)
 #define GS_LAUNCH_SCATTER_H(LO_IN, LO_OUT) \
         do { if (hi16) GS_LAUNCH_SCATTER(LO_IN, LO_OUT, true); else GS_LAUNCH_SCATTER(LO_IN, LO_OUT, false); } while (0)
         if (lo_in == 4 && lo_out == 4) GS_LAUNCH_SCATTER_H(4, 4);
@@ -517,15 +512,6 @@ __global__ void k_check_sorted(const uint32_t* lo, const uint32_t* hi, uint32_t 
         local += a > b ? 1u : 0u;
     }
     if (local) atomicAdd(bad, local);
-}
-
-void launch_count_ablate(int ablate, const SortBuffers& sb, uint32_t capacity, uint32_t grid, hipStream_t stream) {
-    (void)capacity; (void)grid;
-    switch (ablate) {
-        case 0: hipLaunchKernelGGL(k_count<0>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u); break;
-        case 3: hipLaunchKernelGGL(k_count<2>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u); break;
-        default: hipLaunchKernelGGL(k_count<6>, dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params, sb.lo[0], sb.table, sb.seg_sum, 0u); break;
-    }
 }
 
 void launch_set_sort_params(SortParams* params, uint32_t n, hipStream_t stream) {
