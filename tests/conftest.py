@@ -60,13 +60,13 @@ def _cached_synth_clouds():
     cache = {}
 
     @functools.wraps(orig)
-    def cached(n, width, height, mu, seed, morton=True, chunk=400_000):
-        key = (n, round(width / height, 9), mu, seed, morton)
+    def cached(n, width, height, mu, seed, morton=True, chunk=400_000, kind="uniform"):
+        key = (n, round(width / height, 9), mu, seed, morton, kind)
         if n < 1_000_000 or n > 10_000_000:
-            return orig(n, width, height, mu, seed, morton, chunk)
+            return orig(n, width, height, mu, seed, morton, chunk, kind)
         if key not in cache:
             cache.clear()                          # at most one big cloud alive
-            cache[key] = orig(n, width, height, mu, seed, morton, chunk)
+            cache[key] = orig(n, width, height, mu, seed, morton, chunk, kind)
         return cache[key].copy()
 
     synth.generate = cached

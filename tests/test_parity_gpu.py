@@ -348,6 +348,14 @@ def test_config_c_full_frame(oracle_mod):
     full_size_parity(oracle_mod, "C", (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET), 2**24, 48, e_readme=13_098_506)
 
 
+def test_config_c_hard_full_frame(oracle_mod):
+    """The Garden-30k shape once more on a cloud that is not fog (synth.CONFIGS["Chard"]: clusters, a ground plane,
+    needle / disc splats, a few dozen screen-filling ones, opacities near 1; tile lists from 29 to 24,063 entries):
+    keys, ranges and all 1920x1080 pixels bit-exact, both sort back-ends -- long and short per-tile runs, early
+    saturation, splats that cover every tile."""
+    full_size_parity(oracle_mod, "Chard", (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET), 2**24, 48, e_readme=13_098_506)
+
+
 def test_config_d_4k_full_frame(oracle_mod):
     """BASELINE config D shape (Garden-30k @ 3840x2160, 32,400 tiles, E = 33 M): keys, ranges and all 3840x2160
     pixels bit-exact, both sort back-ends."""

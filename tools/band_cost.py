@@ -1,36 +1,51 @@
-"""Per-rank cost of a tile-row band on ONE GPU: what a rank of an R-way sharded frame (dist.py) spends,
-without the gather.  For each R the heaviest band (the middle one) and the lightest (the first) are timed."""
+"""Per-rank cost of a tile-row share on ONE GPU: what a rank of an R-way sharded frame (dist.py) spends, without the
+gather.  For each R: the middle and the first contiguous band, and the interleaved share of rank R // 2.
+    python tools/band_cost.py [C|D|Chard]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import vk3dgaussiansplatting_amd as gs
 from vk3dgaussiansplatting_amd import synth, dist
 name = sys.argv[1] if len(sys.argv) > 1 else "C"
-kernel = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # gs_config.render_kernel
-aos, cfg = synth.generate_config(name)
+cfg = synth.CONFIGS[name]
+cache = f"/dev/shm/gs_cloud_{cfg['n']}_{cfg['mu']}_{cfg['seed']}_{cfg.get('kind', 'uniform')}.npy"
+if os.path.exists(cache):
+    aos = np.load(cache)
+else:
+    aos = synth.generate_config(name)[0]
+    np.save(cache, aos)
 w, h = cfg["width"], cfg["height"]
 rm = gs.ResourceManager(); rm.setGaussians(aos)
 sc = gs.Scene(rm, aspect_ratio=w / h); cam = sc.getCamera(); cam.setPosition((0, 0, 0)); cam.setRotation(0, 0); cam.recalculate()
 ty = (h + 15) // 16
+owner = gs.Renderer(w, h, record_timings=0, warmup_frames=0); owner.init(rm); owner.initForScene(sc)
 for R in (1, 2, 4, 8):
     bands = dist.tile_row_partition(ty, R)
-    for label, k in (("mid", R // 2), ("first", 0)):
-        if R == 1 and label == "first": continue
-        b, e = bands[k]
-        for rec in (0, 2):
-            r = gs.Renderer(w, h, record_timings=rec, warmup_frames=0, render_kernel=kernel); r.init(rm); r.initForScene(sc)
-            r.setTileRows(b, e)
+    shares = [("band mid", lambda r, k=R // 2: r.setTileRows(*bands[k]))]
+    if R > 1:
+        shares += [("band first", lambda r: r.setTileRows(*bands[0])),
+                   ("interleaved", lambda r, k=R // 2: r.setTileRowsInterleaved(k, R, False))]
+    for label, setup in shares:
+        res = {}
+        for rec in (0, 1):
+            r = gs.Renderer(w, h, record_timings=rec, warmup_frames=0); r.init(rm); r.initForScene(sc, share_with=owner)
+            setup(r)
             for _ in range(20): r.drawDevice(sc, None, sync=False)
             r.synchronize()
-            n = 100
-            t0 = time.perf_counter()
-            for _ in range(n): r.drawDevice(sc, None, sync=(rec != 0))
-            r.synchronize()
-            ms = 1e3 * (time.perf_counter() - t0) / n
+            n = 200
             if rec == 0:
-                wall = ms
+                t0 = time.perf_counter()
+                for _ in range(n): r.drawDevice(sc, None, sync=False)
+                r.synchronize()
+                res["wall"] = 1e3 * (time.perf_counter() - t0) / n
             else:
-                t = r.timings()
-                print(f"config {name} R={R} band {label} rows [{b},{e}): wall {wall:.4f} ms; buckets init {t.init_sort_list_ms:.4f} sort {t.radix_sort_ms:.4f} "
-                      f"ranges {t.find_ranges_ms:.4f} render {t.render_ms:.4f}; E={t.num_sort_elements}", flush=True)
+                acc = np.zeros(5)
+                for _ in range(n):
+                    r.drawDevice(sc, None, sync=True)
+                    t = r.timings()
+                    acc += [t.init_sort_list_ms, t.radix_sort_ms, t.find_ranges_ms, t.render_ms, t.total_ms]
+                acc /= n
+                print(f"config {name} R={R} {label:12s}: frames back to back {res['wall']:.4f} ms; buckets init {acc[0]:.4f} sort {acc[1]:.4f} "
+                      f"ranges {acc[2]:.4f} render {acc[3]:.4f} total {acc[4]:.4f}; E={t.num_sort_elements} passes={r.sceneInfo().rows_owned}rows", flush=True)
             r.cleanup()
+owner.cleanup()

@@ -4,7 +4,13 @@ import numpy as np
 import vk3dgaussiansplatting_amd as gs
 from vk3dgaussiansplatting_amd import synth, _lib
 name = sys.argv[1] if len(sys.argv) > 1 else "C"
-aos, cfg = synth.generate_config(name)
+cfg = synth.CONFIGS[name]
+cache = f"/dev/shm/gs_cloud_{cfg['n']}_{cfg['mu']}_{cfg['seed']}_{cfg.get('kind', 'uniform')}.npy"
+if os.path.exists(cache):
+    aos = np.load(cache)
+else:
+    aos = synth.generate_config(name)[0]
+    np.save(cache, aos)
 w, h = cfg["width"], cfg["height"]
 rm = gs.ResourceManager(); rm.setGaussians(aos)
 sc = gs.Scene(rm, aspect_ratio=w / h); cam = sc.getCamera(); cam.setPosition((0, 0, 0)); cam.setRotation(0, 0); cam.recalculate()

@@ -15,7 +15,7 @@ ap.add_argument("--sort", default="radix4")
 ap.add_argument("--rows", default=None, help="rb:re tile-row band")
 a = ap.parse_args()
 cfg = synth.CONFIGS[a.config]
-cache = f"/dev/shm/gs_cloud_{a.config}.npy"
+cache = f"/dev/shm/gs_cloud_{cfg['n']}_{cfg['mu']}_{cfg['seed']}_{cfg.get('kind', 'uniform')}.npy"
 if os.path.exists(cache):
     aos = np.load(cache)
 else:

@@ -500,7 +500,7 @@ int gs_upload_gaussians(gs_ctx* c, const void* aos336, uint32_t n) {
         if (e == hipSuccess) e = hipMalloc((void**)&b.sh, 48 * N * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&b.opacity, N * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&b.sig2, N * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&b.block_bounds, (size_t)((n + kProjThreads - 1) / kProjThreads) * 8 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&b.block_bounds, ((size_t)(n + 63u) / 64u + 4u) * 8 * sizeof(float));
         if (e != hipSuccess) {
             free_scene(c);
             return fail(c, GS_ERR_HIP, std::string("gs_upload_gaussians: ") + hipGetErrorString(e));

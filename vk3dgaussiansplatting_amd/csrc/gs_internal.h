@@ -98,8 +98,8 @@ struct SceneBuffers {
     float* opacity;  // [N]   shCoeffs[0].w
     float* sig2;     // [N]   upper bound of the largest eigenvalue of the 3-D covariance: |R|_F^2 * max(scale)^2,
                      //       computed at upload; lets a tile-row band skip far-away splats early (k_project)
-    float* block_bounds; // [ceil(N / kProjThreads)][8]  per project workgroup: min xyz, max xyz of its splats' positions,
-                     //       max sig2, pad -- a band context drops a whole workgroup with one record (k_project)
+    float* block_bounds; // [ceil(N / 64)][8]  per wave of 64 consecutive splats: min xyz, max xyz of their positions,
+                     //       max sig2, pad -- a context with a subset of the tile rows drops a whole wave with one record
 };
 
 // Per-splat scratch of one frame.

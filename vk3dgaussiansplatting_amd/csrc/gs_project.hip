@@ -182,11 +182,14 @@ __device__ __forceinline__ float radius_bound(const FrameParams& fp, float tx, f
     return 3.0f * sqrtf(lam) + 2.0f;
 }
 
-// True when no owned tile row can intersect the pixel rows [ylo, yhi] (widened by two tile rows on either side); a NaN
-// anywhere gives false, i.e. the caller takes the normal path.
+// True when no owned tile row intersects the pixel rows [ylo, yhi] (the callers have already widened the range by
+// more than any rounding difference to the reference's own extents); a NaN anywhere gives false, i.e. the caller
+// takes the normal path.
 __device__ __forceinline__ bool misses_owned_rows(const FrameParams& fp, float ylo, float yhi) {
     if (!(ylo == ylo) || !(yhi == yhi) || !(ylo <= yhi)) return false;
-    const float lo_row = floorf(ylo * (1.0f / 16.0f)) - 2.0f, hi_row = floorf(yhi * (1.0f / 16.0f)) + 3.0f;   // [lo, hi)
+    // rows as the reference cuts them (InitSortList.comp:61-64): int() truncates TOWARDS ZERO, so a splat whose lower
+    // edge lies up to 16 px above the frame still lands in row 0
+    const float lo_row = truncf(ylo * (1.0f / 16.0f)), hi_row = truncf(yhi * (1.0f / 16.0f)) + 1.0f;   // [lo, hi)
     const int y0 = lo_row < (float)fp.row_begin ? (int)fp.row_begin : (lo_row > 1e6f ? 1000000 : (int)lo_row);
     const int y1 = hi_row > (float)fp.row_end ? (int)fp.row_end : (hi_row < -1e6f ? -1000000 : (int)hi_row);
     if (y1 <= y0) return true;
@@ -208,42 +211,45 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
     float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0;   // culled splats: zero record
     const bool band = !owns_every_row(fp);
 
-    // A context that owns a subset of the tile rows first tests the workgroup as a whole: the box around its 256 splat
-    // positions (Morton order keeps it small) and their largest sig2, from the upload.  If all eight corners are beyond
-    // the near plane, every splat's screen y lies between the corners' extremes and its radius is below the bound taken
-    // at the nearest corner depth; when that range misses every owned row the workgroup emits nothing: one 32-byte read
-    // instead of 256 positions (and everything after).  Nothing is written for the splats but the workgroup's zero
-    // count -- k_emit never looks at the per-splat arrays of an empty workgroup, RenderGaussians never at its records.
+    // A context that owns a subset of the tile rows first tests each wave as a whole: the box around its 64 splat
+    // positions (the arrays are in Morton order, so it is small) and their largest sig2, from the upload.  Lanes 0..7
+    // project one corner each.  If all eight corners are beyond the near plane, every splat's screen y lies between
+    // the corners' extremes and its radius is below the bound taken at the nearest corner depth; when that range
+    // misses every owned row the wave emits nothing: one 32-byte read instead of 64 positions (and everything after).
+    // Only zero tile counts are written for its splats (k_emit reads the counts of a workgroup that emits anything);
+    // RenderGaussians never sees their records.
+    bool wave_skip = false;
     if (band) {
-        const float4 b0 = reinterpret_cast<const float4*>(scene.block_bounds)[blockIdx.x * 2 + 0];
-        const float4 b1 = reinterpret_cast<const float4*>(scene.block_bounds)[blockIdx.x * 2 + 1];
-        const float lo[3] = {b0.x, b0.y, b0.z}, hi[3] = {b0.w, b1.x, b1.y};
+        const uint32_t wrec = blockIdx.x * (kProjThreads / 64) + (uint32_t)wave_id();
+        const int c = lane_id() & 7;
+        const float4 b0 = reinterpret_cast<const float4*>(scene.block_bounds)[wrec * 2 + 0];
+        const float4 b1 = reinterpret_cast<const float4*>(scene.block_bounds)[wrec * 2 + 1];
         const float hgt = (float)fp.height;
         const float tfx = fp.tan_fov_y * (float)fp.width / hgt;
-        float ymin = 3.0e38f, ymax = -3.0e38f, zmin = 3.0e38f;
-        bool in_front = true;
+        float vp[4], q[4];
+        mat4_mul_vec4(fp.view, (c & 1) ? b0.w : b0.x, (c & 2) ? b1.x : b0.y, (c & 4) ? b1.y : b0.z, 1.0f, vp);
+        mat4_mul_vec4(fp.proj, vp[0], vp[1], vp[2], vp[3], q);
+        const float depth = -vp[2];
+        const float sy = (1.0f - q[1] / q[3]) * 0.5f * hgt;
+        // a NaN / infinite corner, or one at or behind the near plane, keeps the wave
+        const bool corner_ok = depth > fp.near_plane && q[3] > 0.0f && (sy - sy == 0.0f);
+        float ymin = sy, ymax = sy, zmin = depth;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float vp[4], q[4];
-            mat4_mul_vec4(fp.view, (c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2], 1.0f, vp);
-            mat4_mul_vec4(fp.proj, vp[0], vp[1], vp[2], vp[3], q);
-            const float depth = -vp[2];
-            in_front = in_front && depth > fp.near_plane && q[3] > 0.0f;
-            const float sy = (1.0f - q[1] / q[3]) * 0.5f * hgt;
-            in_front = in_front && (sy - sy == 0.0f);               // finite (a NaN / infinite corner keeps the workgroup)
-            ymin = fminf(ymin, sy); ymax = fmaxf(ymax, sy); zmin = fminf(zmin, depth);
+        for (int off = 1; off < 8; off <<= 1) {
+            ymin = fminf(ymin, __shfl_xor(ymin, off, 64));
+            ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+            zmin = fminf(zmin, __shfl_xor(zmin, off, 64));
         }
+        const bool in_front = (__ballot(corner_ok) & 0xFFull) == 0xFFull;
         if (in_front) {
             const float rmax = radius_bound(fp, tfx * fp.in_view_limit, fp.tan_fov_y * fp.in_view_limit, zmin, b1.z);
             // 1 px of slack for the rounding of the corner projections against the per-splat ones
-            if (misses_owned_rows(fp, ymin - rmax - 1.0f, ymax + rmax + 1.0f)) {
-                if (threadIdx.x == 0) sc.block_sums[blockIdx.x] = 0u;
-                return;
-            }
+            wave_skip = misses_owned_rows(fp, ymin - rmax - 1.0f, ymax + rmax + 1.0f);
         }
+        wave_skip = __builtin_amdgcn_readfirstlane((int)wave_skip) != 0;   // lanes 0..7 agree; make it wave-uniform
     }
 
-    if (g < n) {
+    if (g < n && !wave_skip) {
         const float px = scene.pos[g], py = scene.pos[(size_t)n + g], pz = scene.pos[2 * (size_t)n + g];
         float vp[4];
         mat4_mul_vec4(fp.view, px, py, pz, 1.0f, vp);                 // InitSortList.comp:93
@@ -357,6 +363,8 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
             }
         }
         sc.tiles_touched[g] = count;
+    } else if (g < n) {
+        sc.tiles_touched[g] = 0u;     // skipped wave: k_emit reads the counts of every splat of a workgroup that emits
     }
 
     s_raster[threadIdx.x * 3 + 0] = rec0;

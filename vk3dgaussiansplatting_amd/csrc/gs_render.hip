@@ -141,12 +141,14 @@ __device__ __forceinline__ bool rect_unreachable(float sx, float sy, float ix, f
     const float v0 = y0 - sy, v1 = y0 + rows_m1 - sy;                               // v range
     bool reject = false;
     if (ix > 0.0f && iz > 0.0f && !(u0 <= 0.0f && u1 >= 0.0f && v0 <= 0.0f && v1 >= 0.0f)) {
+        // hardware reciprocals (1 ulp): q is stationary at the minimiser, so its error enters q squared -- far below tol
+        const float r_iz = __builtin_amdgcn_rcpf(iz), r_ix = __builtin_amdgcn_rcpf(ix);
         auto edge_u = [&](float ue) {   // min over v in [v0,v1] of q(ue, v)
-            const float vs = fminf(fmaxf(-iy * ue / iz, v0), v1);
+            const float vs = fminf(fmaxf(-iy * ue * r_iz, v0), v1);
             return ix * ue * ue + 2.0f * iy * ue * vs + iz * vs * vs;
         };
         auto edge_v = [&](float ve) {   // min over u in [u0,u1] of q(u, ve)
-            const float us = fminf(fmaxf(-iy * ve / ix, u0), u1);
+            const float us = fminf(fmaxf(-iy * ve * r_ix, u0), u1);
             return ix * us * us + 2.0f * iy * us * ve + iz * ve * ve;
         };
         const float qmin = fminf(fminf(edge_u(u0), edge_u(u1)), fminf(edge_v(v0), edge_v(v1)));
@@ -401,14 +403,32 @@ finish:
     }
 }
 
+// Rows of the tile (0..15, relative to tile_y0) that the splat can reach at all: where the exponent can come up to
+// the skip threshold, f >= fthr - tol, i.e. q(u, v) <= Q' = 2 (tol - fthr).  For the conic M = [[ix, iy], [iy, iz]]
+// the ellipse q <= Q' spans |v| <= sqrt(Q' ix / det M).  Returned as a 4-bit mask of the 4-row strips the four waves
+// of k_render_wg blend (bit w = rows 4 w .. 4 w + 3).  Conservative (0.01 % + 0.05 px wider); anything odd -> all.
+__device__ __forceinline__ uint32_t strip_mask(float sy, float ix, float iy, float iz, float fthr, float tol, float tile_y0) {
+    const float detm = ix * iz - iy * iy;
+    const float qq = 2.0f * (tol - fthr);
+    if (!(detm > 0.0f) || !(ix > 0.0f) || !(qq == qq)) return 0xFu;
+    if (qq < 0.0f) return 0u;                                     // the threshold is out of reach everywhere
+    const float vmax = __builtin_amdgcn_sqrtf(qq * ix * __builtin_amdgcn_rcpf(detm)) * 1.0001f + 0.05f;   // 1-ulp ops, inside the margin
+    if (!(vmax == vmax) || vmax > 1.0e6f) return 0xFu;
+    const float lo = sy - vmax - tile_y0, hi = sy + vmax - tile_y0;   // rows relative to the tile, as reals
+    uint32_t m = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) m |= (hi >= (float)(4 * w) && lo <= (float)(4 * w + 3)) ? (1u << w) : 0u;
+    return m;
+}
+
 // One 256-thread workgroup per tile, one pixel per lane -- the reference's own shape (RenderGaussians.comp:
-// local_size 16x16, 256-splat shared batch) with the wave-level tricks of k_render kept: the four waves stage a
-// batch of 256 list entries together (each entry is fetched, set up and rectangle-tested ONCE per tile, then
-// compacted in list order across the waves), and each wave blends its own four pixel rows over the compacted
-// batch, skipping entries none of its pixels can see by wave vote.  A wave whose 64 pixels are all done stops
-// blending but keeps staging; the workgroup leaves the list when all four are done.  Against one wave per tile
-// with 4 px/lane the longest dependent chain of a tile is about a quarter as long, and 4T workgroups are handed
-// out dynamically instead of all T waves being resident from the start.
+// local_size 16x16, 256-splat shared batch) with wave-level scheduling on top.  Per batch of 256 list entries: thread
+// t fetches entry t (prefetched one batch ahead), sets it up ONCE for the tile (RenderGaussians.comp:86-108) and
+// stores it at slot t together with the mask of 4-row strips it can reach (0 = dropped: it provably touches no pixel
+// of the tile).  After ONE barrier each wave turns the masks into four 64-bit scalar bit sets -- ballot of "entry
+// reaches my strip" -- and walks only the set bits, in list order: a splat three pixels across costs the one wave it
+// lies in a visit, not all four.  A wave whose 64 pixels are all done stops blending but keeps staging; the workgroup
+// leaves the list when all four are done.
 template <bool EXACT>
 __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
                                                     const SplatRaster* __restrict__ raster,
@@ -416,7 +436,7 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
                                                     const uint32_t* __restrict__ ranges,
                                                     uint32_t* __restrict__ rgba) {
     __shared__ float4 s_batch[256][3];
-    __shared__ uint32_t s_wcnt[4];
+    __shared__ uint32_t s_mask[256];
     __shared__ uint32_t s_done;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -441,68 +461,71 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
     Fetched nxt = fetch_splat(raster, sorted_id, start + tid, end);
     for (uint32_t i = start; i < end; i += 256) {                      // :81
         float4 r0, r1, r2;
-        const bool keep = stage_splat(nxt, tile_x0, tile_y0, 15.0f, r0, r1, r2);
-        const uint64_t kmask = __ballot(keep);
-        if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(kmask);
-        __syncthreads();                                               // counts of this batch; s_done settled
+        uint32_t mask = 0u;
+        if (stage_splat(nxt, tile_x0, tile_y0, 15.0f, r0, r1, r2)) {
+            // the bound on the rounding of the per-pixel exponent that stage_splat's rectangle test uses, over the tile
+            const float far_x = fmaxf(fabsf(r0.x - tile_x0), fabsf(r0.x - (tile_x0 + 15.0f)));
+            const float far_y = fmaxf(fabsf(r0.y - tile_y0), fabsf(r0.y - (tile_y0 + 15.0f)));
+            const float mag = fabsf(r0.z) * far_x * far_x + fabsf(r1.x) * far_y * far_y + 2.0f * fabsf(r0.w) * far_x * far_y;
+            mask = strip_mask(r0.y, r0.z, r0.w, r1.x, r2.y, 0.01f + 8e-6f * mag, tile_y0);
+        }
+        if (mask) {
+            s_batch[tid][0] = r0;
+            s_batch[tid][1] = r1;
+            s_batch[tid][2] = r2;
+        }
+        s_mask[tid] = mask;
+        __syncthreads();                                               // :109; s_done of the previous batch settled
         if (s_done == 4u) break;                                       // every pixel of the tile is finished
-        uint32_t off = 0, n = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t c = s_wcnt[w];
-            off += w < wave ? c : 0u;
-            n += c;
-        }
-        if (keep) {
-            const uint32_t slot = off + mbcnt(kmask);                  // list order preserved across the waves
-            s_batch[slot][0] = r0;
-            s_batch[slot][1] = r1;
-            s_batch[slot][2] = r2;
-        }
-        __syncthreads();                                               // :109
         nxt = fetch_splat(raster, sorted_id, i + 256 + tid, end);      // prefetch next batch
 
         if (!wave_done) {
-            for (uint32_t j = 0; j < n; ++j) {                         // :112
-                const float4 g0 = s_batch[j][0];
-                const float4 g1 = s_batch[j][1];
-                const float2 g2 = *reinterpret_cast<const float2*>(&s_batch[j][2]);
-                const float ga = g2.x, fthr = g2.y;
-                float ey = g0.y - fpy;                                 // :119
-                ey = -ey;                                              // :120
-                const float ex = g0.x - fpx;
-                float f;
-                if constexpr (EXACT) {
-                    f = -0.5f * (g0.z * ex * ex + g1.x * ey * ey) - g0.w * ex * ey;   // :123
-                } else {
-                    const float q = __builtin_fmaf(g0.z * ex, ex, g1.x * ey * ey);
-                    f = __builtin_fmaf(-0.5f, q, -(g0.w * ey * ex));
-                }
-                const bool need = !done && !(f > 0.0f) && !(f < fthr);
-                if (!__any(need)) continue;                            // nobody in these rows can pass :127
-                float alpha;
-                if constexpr (EXACT) alpha = ga * exp_pinned(f);       // :124
-                else alpha = ga * __builtin_amdgcn_exp2f(f * 0x1.715476p+0f);
-                const bool act = need && !(alpha < 1.0f / 255.0f);     // :127
-                const float wgt = T * alpha;                           // :131
-                if constexpr (EXACT) {
-                    col0 = act ? col0 + wgt * g1.y : col0;
-                    col1 = act ? col1 + wgt * g1.z : col1;
-                    col2 = act ? col2 + wgt * g1.w : col2;
-                } else {
-                    const float w0 = act ? wgt : 0.0f;
-                    col0 = __builtin_fmaf(w0, g1.y, col0);
-                    col1 = __builtin_fmaf(w0, g1.z, col1);
-                    col2 = __builtin_fmaf(w0, g1.w, col2);
-                }
-                const float next_t = T * (1.0f - alpha);               // :133
-                const bool fin = act && next_t < 0.0001f;              // :136-140, colour already added
-                done = done || fin;
-                T = (act && !fin) ? next_t : T;                        // :142
-                if (__all(done)) {                                     // this wave's rows are finished
-                    wave_done = true;
-                    if (lane == 0) atomicAdd(&s_done, 1u);
-                    break;
+#pragma unroll 1
+            for (int k = 0; k < 4 && !wave_done; ++k) {
+                uint64_t m = __ballot((s_mask[k * 64 + lane] >> wave) & 1u);   // entries of this chunk that reach my rows
+                while (m) {                                            // :112, list order
+                    const int j = k * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float4 g0 = s_batch[j][0];
+                    const float4 g1 = s_batch[j][1];
+                    const float2 g2 = *reinterpret_cast<const float2*>(&s_batch[j][2]);
+                    const float ga = g2.x, fthr = g2.y;
+                    float ey = g0.y - fpy;                             // :119
+                    ey = -ey;                                          // :120
+                    const float ex = g0.x - fpx;
+                    float f;
+                    if constexpr (EXACT) {
+                        f = -0.5f * (g0.z * ex * ex + g1.x * ey * ey) - g0.w * ex * ey;   // :123
+                    } else {
+                        const float q = __builtin_fmaf(g0.z * ex, ex, g1.x * ey * ey);
+                        f = __builtin_fmaf(-0.5f, q, -(g0.w * ey * ex));
+                    }
+                    const bool need = !done && !(f > 0.0f) && !(f < fthr);
+                    if (!__any(need)) continue;                        // nobody in these rows can pass :127
+                    float alpha;
+                    if constexpr (EXACT) alpha = ga * exp_pinned(f);   // :124
+                    else alpha = ga * __builtin_amdgcn_exp2f(f * 0x1.715476p+0f);
+                    const bool act = need && !(alpha < 1.0f / 255.0f); // :127
+                    const float wgt = T * alpha;                       // :131
+                    if constexpr (EXACT) {
+                        col0 = act ? col0 + wgt * g1.y : col0;
+                        col1 = act ? col1 + wgt * g1.z : col1;
+                        col2 = act ? col2 + wgt * g1.w : col2;
+                    } else {
+                        const float w0 = act ? wgt : 0.0f;
+                        col0 = __builtin_fmaf(w0, g1.y, col0);
+                        col1 = __builtin_fmaf(w0, g1.z, col1);
+                        col2 = __builtin_fmaf(w0, g1.w, col2);
+                    }
+                    const float next_t = T * (1.0f - alpha);           // :133
+                    const bool fin = act && next_t < 0.0001f;          // :136-140, colour already added
+                    done = done || fin;
+                    T = (act && !fin) ? next_t : T;                    // :142
+                    if (__all(done)) {                                 // this wave's rows are finished
+                        wave_done = true;
+                        if (lane == 0) atomicAdd(&s_done, 1u);
+                        break;
+                    }
                 }
             }
         }

@@ -46,12 +46,11 @@ __global__ __launch_bounds__(256) void k_aos_to_soa(const float* __restrict__ ch
     }
 }
 
-// Per project workgroup (kProjThreads consecutive splats -- neighbours in space, the arrays are in Morton order): the
-// box around the positions and the largest sig2.  A context that renders a subset of the tile rows rejects whole
-// workgroups with it (k_project).  min/max are exact selections, so the box contains every position whatever the order.
-__global__ __launch_bounds__(kProjThreads) void k_block_bounds(uint32_t n, SceneBuffers s) {
-    __shared__ float s_red[kProjThreads / 64][7];
-    const uint32_t g = blockIdx.x * kProjThreads + threadIdx.x;
+// Per wave of the project kernel (64 consecutive splats -- neighbours in space, the arrays are in Morton order): the box
+// around the positions and the largest sig2.  A context that renders a subset of the tile rows rejects whole waves
+// with it (k_project).  min/max are exact selections, so the box contains every position whatever the order.
+__global__ __launch_bounds__(256) void k_block_bounds(uint32_t n, SceneBuffers s) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const bool ok = g < n;
     float v[7];
 #pragma unroll
@@ -62,7 +61,7 @@ __global__ __launch_bounds__(kProjThreads) void k_block_bounds(uint32_t n, Scene
     }
     v[6] = ok ? s.sig2[g] : 0.0f;
     // a NaN position or bound must not be lost by fminf/fmaxf: it poisons the record instead (k_project then keeps
-    // the workgroup, every comparison with a NaN being false)
+    // the wave, every comparison with a NaN being false)
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < 7; ++k) bad = bad || (ok && !(v[k] == v[k]));
@@ -74,34 +73,17 @@ __global__ __launch_bounds__(kProjThreads) void k_block_bounds(uint32_t n, Scene
         for (int k = 3; k < 7; ++k) v[k] = fmaxf(v[k], __shfl_xor(v[k], off, 64));
     }
     const bool wave_bad = __ballot(bad) != 0ull;
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) s_red[threadIdx.x >> 6][k] = wave_bad ? __builtin_nanf("") : v[k];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float r[8];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            float acc = s_red[0][k];
-            bool nan = !(acc == acc);
-            for (int w = 1; w < kProjThreads / 64; ++w) {
-                const float t = s_red[w][k];
-                nan = nan || !(t == t);
-                acc = k < 3 ? fminf(acc, t) : fmaxf(acc, t);
-            }
-            r[k] = nan ? __builtin_nanf("") : acc;
-        }
-        r[7] = 0.0f;
-        float4* out = reinterpret_cast<float4*>(s.block_bounds) + (size_t)blockIdx.x * 2;
-        out[0] = make_float4(r[0], r[1], r[2], r[3]);
-        out[1] = make_float4(r[4], r[5], r[6], r[7]);
+    if ((threadIdx.x & 63) == 0 && blockIdx.x * 256u + (threadIdx.x & ~63u) < n) {
+        const float nanv = __builtin_nanf("");
+        float4* out = reinterpret_cast<float4*>(s.block_bounds) + (size_t)(g >> 6) * 2;
+        out[0] = wave_bad ? make_float4(nanv, nanv, nanv, nanv) : make_float4(v[0], v[1], v[2], v[3]);
+        out[1] = wave_bad ? make_float4(nanv, nanv, nanv, nanv) : make_float4(v[4], v[5], v[6], 0.0f);
     }
 }
 
 void launch_block_bounds(uint32_t n, const SceneBuffers& s, hipStream_t stream) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_block_bounds, dim3((n + kProjThreads - 1) / kProjThreads), dim3(kProjThreads), 0, stream, n, s);
+    hipLaunchKernelGGL(k_block_bounds, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, s);
 }
 
 void launch_aos_to_soa(const float* chunk, uint32_t first, uint32_t count, uint32_t n,

@@ -22,6 +22,11 @@ CONFIGS = {
     "C": dict(n=5_834_784, width=1920, height=1080, mu=-4.65381, seed=20240807 + 2),
     "D": dict(n=5_834_784, width=3840, height=2160, mu=-4.65381, seed=20240807 + 2),
     "E": dict(n=50_000_000, width=1920, height=1080, mu=-5.55, seed=20240807 + 4),
+    # Garden-30k shape again (same N, E calibrated to README.md:61), but a cloud that behaves like a captured scene
+    # rather than like fog: clustered objects and a ground plane (tile lists from a few hundred to tens of thousands
+    # of entries), needle / disc shaped splats, a few dozen screen-filling ones, opacities skewed towards 1 (pixels
+    # saturate after tens of splats and the early-outs matter).  kind="hard" in generate().
+    "Chard": dict(n=5_834_784, width=1920, height=1080, mu=-6.65332, seed=20240807 + 5, kind="hard"),   # E = 13,084,731; tile lists 29 .. 24,063 (median 1,047)
 }
 
 
@@ -67,10 +72,58 @@ def morton_codes(pos: np.ndarray) -> np.ndarray:
     return (part(q[:, 2]) << np.uint32(2)) + (part(q[:, 1]) << np.uint32(1)) + part(q[:, 0])
 
 
+_HARD_CLUSTERS = 96
+
+
+def _hard_cluster_table(seed: int, aspect: float) -> np.ndarray:
+    """[clusters, 4] = centre xyz + radius, from a stream of its own."""
+    base = np.arange(_HARD_CLUSTERS, dtype=np.uint64) * np.uint64(8)
+    s2 = seed ^ 0x5EED5
+    d = 1.0 + 13.0 * _uniform(s2, base, 0) ** 1.5               # more clusters near the camera
+    x = d * aspect * (-1.05 + 2.1 * _uniform(s2, base, 1))
+    y = d * (-1.0 + 2.0 * _uniform(s2, base, 2))
+    r = d * (0.02 + 0.10 * _uniform(s2, base, 3))
+    return np.stack([x, y, d, r], axis=1)
+
+
+def _make_hard(rec, seed, base, mu, aspect):
+    """kind="hard": overrides positions, scales and opacity of the uniform records in place (draws 111..123)."""
+    sel = _uniform(seed, base, 111)
+    tab = _hard_cluster_table(seed, aspect)
+    cid = np.minimum((_uniform(seed, base, 112) * _HARD_CLUSTERS).astype(np.int64), _HARD_CLUSTERS - 1)
+    c = tab[cid]
+    in_cluster, on_ground = sel < 0.68, (sel >= 0.68) & (sel < 0.95)
+    off = np.stack([_normal(seed, base, 113), _normal(seed, base, 115), _normal(seed, base, 117)], axis=1)
+    cpos = c[:, :3] + c[:, 3:4] * off
+    cpos[:, 2] = np.maximum(cpos[:, 2], 0.3)
+    # a ground plane below the camera, denser towards the viewer (what a table / lawn does to the lower tile rows)
+    gz = 0.6 + 19.4 * _uniform(seed, base, 113) ** 2
+    gx = gz * aspect * (-1.3 + 2.6 * _uniform(seed, base, 115))
+    gy = -1.1 + 0.03 * _normal(seed, base, 117)
+    gpos = np.stack([gx, gy, gz], axis=1)
+    pos = rec[:, 0:3].astype(np.float64)
+    pos[in_cluster] = cpos[in_cluster]
+    pos[on_ground] = gpos[on_ground]
+    rec[:, 0:3] = pos
+    # needles and discs: one axis 2x .. 10x longer; ground splats flat
+    axis = np.minimum((_uniform(seed, base, 119) * 3).astype(np.int64), 2)
+    factor = np.exp(0.7 + 1.6 * _uniform(seed, base, 120))
+    sc = rec[:, 4:7].astype(np.float64)
+    sc[np.arange(sc.shape[0]), axis] *= factor
+    sc[on_ground, 1] *= 0.2
+    # a few dozen screen-filling splats
+    huge = _uniform(seed, base, 121) < 48.0 / 5_834_784
+    sc[huge] *= (30.0 + 70.0 * _uniform(seed, base, 122))[huge, None]
+    rec[:, 4:7] = sc
+    logit = 0.0 + 6.0 * _uniform(seed, base, 123)               # opacity 0.5 .. 0.9975
+    rec[:, 15] = 1.0 / (1.0 + np.exp(-logit))
+
+
 def generate(n: int, width: int, height: int, mu: float, seed: int, morton: bool = True,
-             chunk: int = 400_000) -> np.ndarray:
+             chunk: int = 400_000, kind: str = "uniform") -> np.ndarray:
     """Returns float32 [n, 84] records in the reference's AoS layout (already in 'loaded' space:
-    scale exp'd, rotation normalised, opacity sigmoid'd into shCoeffs[0].w)."""
+    scale exp'd, rotation normalised, opacity sigmoid'd into shCoeffs[0].w).  kind: "uniform" (fog filling the
+    frustum) or "hard" (see CONFIGS["Chard"])."""
     aspect = float(width) / float(height)
     out = np.zeros((n, FLOATS_PER_GAUSSIAN), dtype=np.float32)
     for lo in range(0, n, chunk):
@@ -93,6 +146,8 @@ def generate(n: int, width: int, height: int, mu: float, seed: int, morton: bool
         for k in range(15):
             for c in range(3):
                 rec[:, 16 + 4 * k + c] = 0.1 * _normal(seed, base, 21 + 2 * (3 * k + c))
+        if kind == "hard":
+            _make_hard(rec, seed, base, mu, aspect)
     if morton:
         order = np.argsort(morton_codes(out[:, 0:3]), kind="stable")
         out = out[order]
@@ -103,7 +158,7 @@ def generate_config(name: str, n: int | None = None) -> tuple[np.ndarray, dict]:
     cfg = dict(CONFIGS[name])
     if n is not None:
         cfg["n"] = int(n)
-    aos = generate(cfg["n"], cfg["width"], cfg["height"], cfg["mu"], cfg["seed"])
+    aos = generate(cfg["n"], cfg["width"], cfg["height"], cfg["mu"], cfg["seed"], kind=cfg.get("kind", "uniform"))
     return aos, cfg
 
 
