@@ -752,6 +752,28 @@ def test_band_block_cull_keeps_every_emitting_splat(oracle_mod):
         r.cleanup()
 
 
+def test_band_exceeding_the_launch_estimate(oracle_mod):
+    """A context that owns a share of the tile rows launches Scatter over twice that share of the list capacity; a
+    band that holds more (every splat is huge and covers the whole row) makes the workgroups walk on over the
+    remaining groups.  Same list as the oracle's band run, both sorters."""
+    w, h = 640, 360                                            # 40 x 23 tiles, capacity 2^20 = 512 groups
+    aos = synth.generate(24000, w, h, 0.5, seed=77)
+    sc = make_scene(aos, w, h)
+    _, band = oracle_run(oracle_mod, sc, w, h, row_begin=11, row_end=12)
+    e = band["e"]
+    assert e > (512 * 2 // 23 + 64) * 2048, "the band does not exceed the launch estimate"
+    for sort in (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET):
+        r = make_renderer(sc, w, h, sort=sort)
+        r.setTileRows(11, 12)
+        img = r.draw(sc)
+        assert r.timings().num_sort_elements == e
+        assert np.array_equal(r.debugRead(gs.BUF_SORTED_TILE), band["tile"][:e])
+        assert np.array_equal(r.debugRead(gs.BUF_SORTED_DEPTH), band["depth"][:e])
+        assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), band["id"][:e])
+        assert np.array_equal(img[176:192], band["image"][176:192])
+        r.cleanup()
+
+
 def test_host_timers(small_cloud):
     """RECORD_CPU_TIMES figures (Renderer.cpp:399-456) through gs_get_host_timings."""
     w, h = 320, 180

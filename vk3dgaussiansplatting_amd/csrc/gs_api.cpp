@@ -214,13 +214,14 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     // gpuSort->computeSort (RadixSort.cpp:207-653)
     const bool bucket = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET;
     const bool per_pass_events = c->cfg.record_timings >= 2;
+    const float tile_share = c->grid_h ? (float)c->rows_owned / (float)c->grid_h : 1.0f;
     if (!per_pass_events && !c->sort_graph && !c->sort_graph_failed) {
         // capture the passes once (nothing executes during capture)
         hipGraph_t graph = nullptr;
         bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
             c->sort_graph_result = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, nullptr,
-                                                     bucket ? 32u : 0u, !bucket, c->hi16);
+                                                     bucket ? 32u : 0u, !bucket, c->hi16, tile_share);
             ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph != nullptr;
         }
         if (ok) ok = hipGraphInstantiate(&c->sort_graph, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -233,7 +234,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     } else {
         c->sorted_index = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st,
                                             per_pass_events ? c->scatter_ev : nullptr,
-                                            bucket ? 32u : 0u, !bucket, c->hi16);
+                                            bucket ? 32u : 0u, !bucket, c->hi16, tile_share);
     }
     c->depth_dropped = !bucket;
     if (int r = check_launch(c, "RadixSort")) return r;

@@ -147,7 +147,7 @@ void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffer
 // hi16: the hi arrays hold 16-bit tile ids (frame path, at most 65535 owned tiles).
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events = nullptr, uint32_t first_bit = 0,
-                      bool drop_depth_payload = false, bool hi16 = false);
+                      bool drop_depth_payload = false, bool hi16 = false, float share = 1.0f);
 // GS_SORT_TILE_BUCKET: per-tile depth sort of the owned tiles (gs_tilesort.hip)
 int init_tile_sort();
 void launch_tile_sort(const FrameParams& fp, const uint32_t* ranges, uint32_t* lo, uint32_t* id,

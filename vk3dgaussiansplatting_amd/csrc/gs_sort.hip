@@ -415,20 +415,29 @@ void k_scatter(const SortParams* __restrict__ params, const uint32_t* __restrict
     __shared__ __attribute__((aligned(16))) uint32_t s_wcnt[kBins * kSortWaves];
     __shared__ uint32_t s_pre[2 * kBins];
     const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
-    const uint32_t grp = blockIdx.x;
-    if (grp >= G) return;
-    if (grp * kSortTile + kSortTile <= e)
-        scatter_group<LO_IN, LO_OUT, HI16, true>(e, G, K, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table,
-                                                 seg_sum, coarse, shift, s_slot, s_third, s_wcnt, s_pre);
-    else
-        scatter_group<LO_IN, LO_OUT, HI16, false>(e, G, K, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table,
-                                                  seg_sum, coarse, shift, s_slot, s_third, s_wcnt, s_pre);
+    // one group per workgroup as a rule: the grid is sized from an upper estimate of the element count (the list
+    // capacity scaled to the context's share of the tiles) and walks on only if a frame exceeds it
+    for (uint32_t grp = blockIdx.x; grp < G; grp += gridDim.x) {
+        if (grp != blockIdx.x) __syncthreads();   // LDS is reused
+        if (grp * kSortTile + kSortTile <= e)
+            scatter_group<LO_IN, LO_OUT, HI16, true>(e, G, K, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table,
+                                                     seg_sum, coarse, shift, s_slot, s_third, s_wcnt, s_pre);
+        else
+            scatter_group<LO_IN, LO_OUT, HI16, false>(e, G, K, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table,
+                                                      seg_sum, coarse, shift, s_slot, s_third, s_wcnt, s_pre);
+    }
 }
 
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit,
-                      bool drop_depth_payload, bool hi16) {
-    const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
+                      bool drop_depth_payload, bool hi16, float share) {
+    uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
+    // a context that owns a share of the tiles (tile-row band of a multi-GPU frame) launches Scatter over twice
+    // that share of the capacity's groups; k_scatter walks on if a frame should hold more
+    if (share < 0.5f) {
+        const uint32_t g = (uint32_t)((float)max_groups * 2.0f * share) + 64u;
+        max_groups = g < max_groups ? g : max_groups;
+    }
     // the coarse digit totals of every pass (Count adds into them with atomics): cleared once per sort
     (void)hipMemsetAsync(sb.coarse, 0, (size_t)kMaxSortPasses * kBins * kCoarse * sizeof(uint32_t), stream);
     int src = 0;
