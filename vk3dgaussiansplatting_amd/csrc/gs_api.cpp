@@ -559,7 +559,7 @@ int gs_set_resolution(gs_ctx* c, uint32_t width, uint32_t height) {
     c->capacity = ceil_pow2((uint32_t)want);
     c->num_sort_bits = num_sort_bits_for(gw * gh);
     c->band_sort_bits = c->num_sort_bits;
-    c->hi16 = kHi16Supported && (uint64_t)gw * gh <= 65535u;
+    c->hi16 = (uint64_t)gw * gh <= 65535u;
     int rc = alloc_sort(c, c->sort, c->capacity);
     if (rc != GS_OK) { free_resolution(c); return rc; }
     // any failure from here on leaves the context without a resolution (capacity 0), never half set up
@@ -582,7 +582,7 @@ static int apply_tile_rows(gs_ctx* c, uint32_t row_begin, uint32_t row_end, uint
     c->compact_out = compact_out;
     const uint32_t owned_tiles = c->rows_owned * c->grid_w;
     c->band_sort_bits = num_sort_bits_for(owned_tiles ? owned_tiles : 1u);
-    c->hi16 = kHi16Supported && owned_tiles <= 65535u;
+    c->hi16 = owned_tiles <= 65535u;
     if (c->sort_graph) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));   // the graph may still be executing
         drop_sort_graph(c);

@@ -14,25 +14,14 @@ constexpr int kBins = 1 << kRadixBits; // RS_BIN_COUNT
 
 // ---- radix-sort tiling -------------------------------------------------------------------
 // One workgroup (256 threads = 4 waves) owns kSortTile consecutive keys of the current pass.
-// The reference uses 64 keys per group (RS_WORK_GROUP_SIZE, RadixSort.h:38); a 2048-key tile
+// The reference uses 64 keys per group (RS_WORK_GROUP_SIZE, RadixSort.h:38); a 2048-key group
 // shrinks the histogram table 32x and makes every global access of a pass a >= 256-byte run.
-// 8 keys per thread (24.6 KB LDS, 88-95 VGPRs, five Scatter workgroups per CU) is the measured optimum on MI355X:
-// 12 keys per thread was within 3 % while every pass still moved 24 bytes per element and loses the 16-bit word
-// paths (they load 8 keys per 16-byte access); 16 keys per thread is 10-20 % slower.
-#ifndef GS_SORT_THREADS
-#define GS_SORT_THREADS 256
-#endif
-constexpr int kSortThreads = GS_SORT_THREADS;
-#ifndef GS_SORT_KPT
-#define GS_SORT_KPT 8
-#endif
-constexpr int kSortKeysPerThread = GS_SORT_KPT;
-constexpr bool kHi16Supported = GS_SORT_KPT % 8 == 0;   // the 16-bit Count path loads 8 keys per 16-byte access
+// 8 keys per thread is the measured optimum on MI355X (12 and 16 keys per thread
+// were 3-20 % slower) and what the 16-bit word paths are written for (8 keys per 16-byte load).
+constexpr int kSortThreads = 256;
+constexpr int kSortKeysPerThread = 8;
 constexpr int kSortTile = kSortThreads * kSortKeysPerThread; // 2048 keys
-#ifndef GS_SEGMENTS
-#define GS_SEGMENTS 1024
-#endif
-constexpr int kSegments = GS_SEGMENTS;        // reduce segments = persistent Count workgroups; each owns a contiguous run of groups
+constexpr int kSegments = 1024;               // reduce segments = Count workgroups; each owns a contiguous run of groups
 constexpr int kCoarse = 64;                   // coarse reduce segments (kSegments / kCoarse segments each): second Reduce level
 constexpr int kMaxSortPasses = 16;            // 64 key bits / 4
 
@@ -126,7 +115,7 @@ inline void scatter_depth_bytes(uint32_t shift, uint32_t first_bit, bool drop_de
     *lo_in = 4; *lo_out = 4;
     if (!drop_depth_payload) return;
     if (shift >= 32u) { *lo_in = 0; *lo_out = 0; return; }
-    if (first_bit == 0u && kHi16Supported) {
+    if (first_bit == 0u) {
         *lo_in = shift >= 16u ? 2 : 4;
         *lo_out = shift >= 28u ? 0 : (shift >= 12u ? 2 : 4);
     }

@@ -451,14 +451,12 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
         int cin, cout;
         scatter_depth_bytes(shift, first_bit, drop_depth_payload, &cin, &cout);
         const bool lo16 = !tile_pass && cin == 2;
-        const bool word16 = kHi16Supported && ((tile_pass && hi16) || lo16);
+        const bool word16 = (tile_pass && hi16) || lo16;
         uint32_t* coarse = sb.coarse + (size_t)pass * kBins * kCoarse;   // zeroed above; this pass's Count adds into it
-        if constexpr (kHi16Supported) {
-            if (word16)
-                hipLaunchKernelGGL((k_count<true>), dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
-                                   word, sb.table, sb.seg_sum, coarse, lo16 ? shift - 16u : shift & 31u);
-        }
-        if (!word16)
+        if (word16)
+            hipLaunchKernelGGL((k_count<true>), dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
+                               word, sb.table, sb.seg_sum, coarse, lo16 ? shift - 16u : shift & 31u);
+        else
             hipLaunchKernelGGL((k_count<false>), dim3(kSegments), dim3(kSortThreads), 0, stream, sb.params,
                                word, sb.table, sb.seg_sum, coarse, shift & 31u);
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass], stream);
