@@ -205,9 +205,9 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     // computeInitSortList (Subrenderer.cpp:37-170): per-frame resets, then the dispatch.  Only the
     // ranges need clearing here: the 0xFF sentinel fill of both lists (Subrenderer.cpp:42-46,
     // RadixSort.cpp:676-692) is unobservable once every later stage runs over E instead of C.
-    HIP_TRY(c, hipMemsetAsync(c->ranges, 0, (size_t)c->grid_w * c->grid_h * 2 * sizeof(uint32_t), st));
+    // (the ranges and the sort's coarse totals are cleared inside k_scan_blocks: no fill launches in a frame)
     launch_project(fp, c->scene, c->scratch, st);
-    launch_scan_blocks(fp, c->scratch, c->sort.params, st);
+    launch_scan_blocks(fp, c->scratch, c->sort.params, c->ranges, c->sort.coarse, st);
     launch_emit(fp, c->scratch, c->sort, st);
     if (int r = check_launch(c, "InitSortList")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[2], st));
@@ -563,7 +563,7 @@ int gs_set_resolution(gs_ctx* c, uint32_t width, uint32_t height) {
     int rc = alloc_sort(c, c->sort, c->capacity);
     if (rc != GS_OK) { free_resolution(c); return rc; }
     // any failure from here on leaves the context without a resolution (capacity 0), never half set up
-    hipError_t e = hipMalloc((void**)&c->ranges, (size_t)gw * gh * 2 * sizeof(uint32_t));
+    hipError_t e = hipMalloc((void**)&c->ranges, ((size_t)gw * gh * 2 * sizeof(uint32_t) + 15) & ~(size_t)15);   // cleared 16 bytes at a time
     if (e == hipSuccess) e = hipMalloc((void**)&c->framebuffer, (size_t)width * height * 4);
     if (e == hipSuccess) e = hipMemset(c->ranges, 0, (size_t)gw * gh * 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(c->framebuffer, 0, (size_t)width * height * 4);
@@ -659,7 +659,7 @@ int gs_debug_init_sort_list(gs_ctx* c, const float view[16], const float proj[16
     HIP_TRY(c, hipSetDevice(c->device));
     const FrameParams fp = make_frame_params(c, view, proj, cam_pos, sh_mode);
     launch_project(fp, c->scene, c->scratch, c->stream);
-    launch_scan_blocks(fp, c->scratch, c->sort.params, c->stream);
+    launch_scan_blocks(fp, c->scratch, c->sort.params, c->ranges, c->sort.coarse, c->stream);
     launch_emit(fp, c->scratch, c->sort, c->stream);
     if (int r = check_launch(c, "InitSortList")) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -834,7 +834,7 @@ int gs_sort_host(gs_ctx* c, uint32_t* tile, uint32_t* depth, uint32_t* id, uint3
     if (e == hipSuccess) e = hipMemcpyAsync(sb.id[0], id, bytes, hipMemcpyHostToDevice, c->stream);
     int si = 0;
     if (e == hipSuccess) {
-        launch_set_sort_params(sb.params, n, c->stream);
+        launch_set_sort_params(sb.params, sb.coarse, n, c->stream);
         si = launch_radix_sort(sb, n, num_sort_bits, c->stream);
         e = hipGetLastError();
     }
@@ -864,7 +864,7 @@ int gs_sort_bench(gs_ctx* c, uint32_t n, uint32_t num_tiles, uint32_t iters, uin
     int si = 0;
     for (uint32_t it = 0; it < iters + 1 && e == hipSuccess; ++it) {   // iteration 0 = warm-up
         launch_fill_random_keys(sb.lo[0], sb.hi[0], sb.id[0], n, num_tiles, seed + it, c->stream);
-        launch_set_sort_params(sb.params, n, c->stream);
+        launch_set_sort_params(sb.params, sb.coarse, n, c->stream);
         e = hipEventRecord(e0, c->stream);
         if (e != hipSuccess) break;
         si = launch_radix_sort(sb, n, bits, c->stream);

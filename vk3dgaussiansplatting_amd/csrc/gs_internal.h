@@ -125,7 +125,7 @@ inline void scatter_depth_bytes(uint32_t shift, uint32_t first_bit, bool drop_de
 void launch_project(const FrameParams& fp, const SceneBuffers& scene, const SplatScratch& sc,
                     hipStream_t stream);
 void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParams* params,
-                        hipStream_t stream);
+                        uint32_t* ranges, uint32_t* coarse, hipStream_t stream);
 void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb,
                  hipStream_t stream);
 // Sorts buffers [0] -> result index returned (0 or 1) after num_sort_bits/4 passes.
@@ -154,7 +154,7 @@ void launch_stream_probe(int kind, const void* src, void* dst, size_t bytes, uin
 void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
                          const uint32_t* ranges, uint8_t* rgba, uint4* stats, hipStream_t stream);
 // helpers for the stand-alone sorter entry points
-void launch_set_sort_params(SortParams* params, uint32_t n, hipStream_t stream);
+void launch_set_sort_params(SortParams* params, uint32_t* coarse, uint32_t n, hipStream_t stream);
 void launch_fill_random_keys(uint32_t* lo, uint32_t* hi, uint32_t* id, uint32_t n,
                              uint32_t num_tiles, uint64_t seed, hipStream_t stream);
 void launch_check_sorted(const uint32_t* lo, const uint32_t* hi, uint32_t n, uint32_t* bad_count,

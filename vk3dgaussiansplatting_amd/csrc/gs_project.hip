@@ -403,10 +403,15 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
 // scene is still counted correctly), then the IndirectSetup record.  Thread t owns the `per`
 // consecutive entries [t*per, t*per+per) (16-byte loads; the arrays are zero-padded to 1024*per
 // entries at upload): one pass to sum, one block scan, one pass to write -- no row-by-row carry chain.
+// It also does the frame's clears (computeInitSortList's fills, Subrenderer.cpp:42-60): the tile ranges and the
+// per-pass coarse digit totals of the sort -- two fill launches less per frame.
 __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict__ block_sums,
                                                        uint32_t* __restrict__ block_offsets,
                                                        uint32_t num_blocks, uint32_t capacity,
-                                                       SortParams* params) {
+                                                       SortParams* params, uint4* __restrict__ zero_a, uint32_t n16_a,
+                                                       uint4* __restrict__ zero_b, uint32_t n16_b) {
+    for (uint32_t i = threadIdx.x; i < n16_a; i += 1024u) zero_a[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t i = threadIdx.x; i < n16_b; i += 1024u) zero_b[i] = make_uint4(0u, 0u, 0u, 0u);
     __shared__ uint64_t s_wave_tot[16];
     __shared__ uint64_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -560,10 +565,14 @@ void launch_project(const FrameParams& fp, const SceneBuffers& scene, const Spla
 }
 
 void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParams* params,
-                        hipStream_t stream) {
+                        uint32_t* ranges, uint32_t* coarse, hipStream_t stream) {
     const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
+    // ranges: [grid_w * grid_h][2] uint32 (hipMalloc'd, so 16-byte aligned; padded to a multiple of 16 bytes by the caller)
+    const uint32_t n16_ranges = (fp.grid_w * fp.grid_h * 2u + 3u) / 4u;
+    const uint32_t n16_coarse = (uint32_t)(kMaxSortPasses * kBins * kCoarse) / 4u;
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, sc.block_sums,
-                       sc.block_offsets, blocks, fp.capacity, params);
+                       sc.block_offsets, blocks, fp.capacity, params, reinterpret_cast<uint4*>(ranges), n16_ranges,
+                       reinterpret_cast<uint4*>(coarse), n16_coarse);
 }
 
 void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb,

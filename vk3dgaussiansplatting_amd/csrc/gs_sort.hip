@@ -438,8 +438,8 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
         const uint32_t g = (uint32_t)((float)max_groups * 2.0f * share) + 64u;
         max_groups = g < max_groups ? g : max_groups;
     }
-    // the coarse digit totals of every pass (Count adds into them with atomics): cleared once per sort
-    (void)hipMemsetAsync(sb.coarse, 0, (size_t)kMaxSortPasses * kBins * kCoarse * sizeof(uint32_t), stream);
+    // sb.coarse (the coarse digit totals of every pass; Count adds into them with atomics) must be zero on entry:
+    // k_scan_blocks clears it in a frame, k_set_sort_params for the stand-alone sorter
     int src = 0;
     uint32_t pass = 0;
     for (uint32_t shift = first_bit; shift < num_sort_bits; shift += kRadixBits, ++pass) { // RadixSort.cpp:309
@@ -486,7 +486,9 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
 // ---------------------------------------------------------------------------------------------
 // helpers for the stand-alone sorter entry points (gs_sort_host / gs_sort_bench)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_set_sort_params(SortParams* params, uint32_t n) {
+__global__ __launch_bounds__(1024) void k_set_sort_params(SortParams* params, uint32_t* coarse, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(kMaxSortPasses * kBins * kCoarse); i += 1024u) coarse[i] = 0u;
+    if (threadIdx.x != 0) return;
     params->counter = n;
     params->num_elems = n;
     params->num_groups = (n + kSortTile - 1) / kSortTile;
@@ -521,8 +523,8 @@ __global__ void k_check_sorted(const uint32_t* lo, const uint32_t* hi, uint32_t 
     if (local) atomicAdd(bad, local);
 }
 
-void launch_set_sort_params(SortParams* params, uint32_t n, hipStream_t stream) {
-    hipLaunchKernelGGL(k_set_sort_params, dim3(1), dim3(1), 0, stream, params, n);
+void launch_set_sort_params(SortParams* params, uint32_t* coarse, uint32_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_set_sort_params, dim3(1), dim3(1024), 0, stream, params, coarse, n);
 }
 void launch_fill_random_keys(uint32_t* lo, uint32_t* hi, uint32_t* id, uint32_t n,
                              uint32_t num_tiles, uint64_t seed, hipStream_t stream) {
