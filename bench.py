@@ -241,7 +241,10 @@ def main():
 
         def __init__(self, F, sort=None, owner=None):
             self.F, self.n = F, 0
-            self.sf = gsdist.ShardedFrame(w, h, rank, world, device=device, host_gather=args.rehearse, n_strips=F,
+            # N > 1: at least two strips, so that the gather of frame f runs beside the rendering of frame f + 1 (the
+            # rasterization itself stays in F slots; only the collective is double-buffered)
+            self.S = max(F, 2) if world > 1 else F
+            self.sf = gsdist.ShardedFrame(w, h, rank, world, device=device, host_gather=args.rehearse, n_strips=self.S,
                                           interleaved=interleaved)
             rb = 0 if interleaved else self.sf.band[0]
             # the library addresses the FULL frame; hand it the strips shifted up by the band's first row
@@ -258,13 +261,13 @@ def main():
             self.gather_s = 0.0
 
         def step(self):
-            k = self.n % self.F
+            k, st = self.n % self.F, self.n % self.S
             self.n += 1
             with torch.cuda.stream(self.streams[k]):
-                self.sf.wait(k)                  # the previous gather of strip k must have read it
-                self.rs[k].drawDevice(scene, self.ptrs[k], sync=False, compact_rows=interleaved)
+                self.sf.wait(st)                 # the previous gather of this strip must have read it
+                self.rs[k].drawDevice(scene, self.ptrs[st], sync=False, compact_rows=interleaved)
                 if world > 1:
-                    self.sf.gather_async(k)
+                    self.sf.gather_async(st)
 
         def barrier(self):
             self.sf.wait_all()
@@ -276,7 +279,7 @@ def main():
         def timed(self, steps, warmup):
             # one untimed frame per slot first: the hipGraph of the radix passes is captured on a slot's first frame
             # and kernels are loaded lazily, so the W warm-up and K timed steps are steady-state frames
-            for _ in range(self.F):
+            for _ in range(max(self.F, self.S)):
                 self.step()
             self.barrier()
             self.n = 0
@@ -331,7 +334,7 @@ def main():
 
     ms_per_step = ring.timed(args.steps, args.warmup)
     # every slot rendered the same camera: their strips must be identical
-    slots_ok = all(bool(torch.equal(ring.sf.strips[0], ring.sf.strips[k])) for k in range(1, F))
+    slots_ok = all(bool(torch.equal(ring.sf.strips[0], ring.sf.strips[k])) for k in range(1, ring.S))
     sf_main = ring.sf
     ring.close(keep_owner=True)
 
@@ -490,7 +493,7 @@ def main():
                 "num_gaussians": n, "width": w, "height": h, "sort_elements": e_total,
                 "capacity": int(info.capacity), "radix_passes": passes_full + passes_tile, "render_mode": args.mode,
                 "render_kernel": args.render_kernel,
-                "sort_algorithm": args.sort, "frames_in_flight": F,
+                "sort_algorithm": args.sort, "frames_in_flight": F, "gather_strips": ring.S if world > 1 else None,
                 "parallelism": (f"tile-row shard x{world} ({args.rows} rows), RGBA8 strips gathered to rank 0 over "
                                 f"{'gloo (rehearsal on one GPU)' if args.rehearse else 'RCCL'}") if world > 1 else "single GPU",
                 "baseline_note": "vs_baseline = the reference README's total GPU frame time on an RTX 3080 Ti for the real "

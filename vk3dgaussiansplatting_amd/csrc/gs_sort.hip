@@ -147,6 +147,7 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
 #pragma unroll
             for (int q = 0; q < 8; ++q) s_pack[wave][q] = w[q];
         }
+        __builtin_amdgcn_wave_barrier();   // no code: keeps the compiler from moving the reads below above the writes
         if (lane < kBins) {
             // digit d sits in u64 a[d & 3], 16-bit field d >> 2
             const int widx = (lane & 3) * 2 + (lane >> 3);
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
             table[lane * G + grp] = t;               // RadixSortCount.comp:89, bin-major
             seg_total += t;
         }
+        __builtin_amdgcn_wave_barrier();   // ... nor the next group's writes above these reads
         if (nxt_grp < grp_end) cur = nxt;
         grp = nxt_grp;
     }
