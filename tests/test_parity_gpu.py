@@ -774,6 +774,61 @@ def test_band_exceeding_the_launch_estimate(oracle_mod):
         r.cleanup()
 
 
+def test_randomized_frames(oracle_mod):
+    """Sixty seeded random set-ups -- cloud size (1 .. 6000), footprint scale, resolution (ragged tiles included),
+    camera pose, SH mode, sorter, render launch shape, whole frame / contiguous band / interleaved rows -- each
+    compared with the oracle in full (counter, keys, payload order, ranges, pixels).  Element counts land on both
+    sides of every group / wave / batch boundary of the kernels."""
+    from vk3dgaussiansplatting_amd import dist as gsdist
+    rng = np.random.default_rng(20240807)
+    kernels = [gs.GS_RENDER_KERNEL_AUTO, gs.GS_RENDER_KERNEL_WAVE_1PX, gs.GS_RENDER_KERNEL_WAVE_2PX,
+               gs.GS_RENDER_KERNEL_WAVE_4PX, gs.GS_RENDER_KERNEL_WORKGROUP]
+    for case in range(60):
+        n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 2047, 2048, 2049, 4000, 6000]))
+        w, h = int(rng.integers(1, 500)), int(rng.integers(1, 300))
+        mu = float(rng.uniform(-4.0, -1.0))
+        aos = synth.generate(n, max(w, 16), max(h, 16), mu, seed=1000 + case)
+        pos = tuple(float(x) for x in rng.uniform(-1.0, 1.0, 3) * np.array([1.0, 0.5, 2.0]))
+        yaw, pitch = float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.3, 0.3))
+        sh_mode = int(rng.integers(0, 3))
+        sort = gs.GS_SORT_RADIX4 if rng.random() < 0.7 else gs.GS_SORT_TILE_BUCKET
+        kernel = kernels[int(rng.integers(0, len(kernels)))]
+        sc = make_scene(aos, w, h, pos=pos, yaw=yaw, pitch=pitch, sh_mode=sh_mode)
+        r = make_renderer(sc, w, h, sort=sort, kernel=kernel)
+        gh = r.sceneInfo().tiles_y
+        share = rng.random()
+        what = f"case {case}: n={n} {w}x{h} mu={mu:.2f} sh={sh_mode} sort={sort} kernel={kernel}"
+        if share < 0.5 or gh < 2:
+            img = r.draw(sc)
+            _, ref = oracle_run(oracle_mod, sc, w, h)
+            assert_frame_equals_oracle(r, img, ref)
+        elif share < 0.8:
+            rb = int(rng.integers(0, gh)); re = int(rng.integers(rb + 1, gh + 1))
+            r.setTileRows(rb, re)
+            img = r.draw(sc)
+            _, band = oracle_run(oracle_mod, sc, w, h, row_begin=rb, row_end=re)
+            e = band["e"]
+            assert r.timings().num_sort_elements == e, what
+            assert np.array_equal(r.debugRead(gs.BUF_SORTED_TILE), band["tile"][:e]), what
+            assert np.array_equal(r.debugRead(gs.BUF_SORTED_DEPTH), band["depth"][:e]), what
+            assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), band["id"][:e]), what
+            rows = slice(rb * 16, min(re * 16, h))
+            assert np.array_equal(img[rows], band["image"][rows]), what
+        else:
+            world = int(rng.integers(2, 5)); rank = int(rng.integers(0, world))
+            r.setTileRowsInterleaved(rank, world)
+            img = r.draw(sc)
+            _, ref = oracle_run(oracle_mod, sc, w, h)
+            e, gw = ref["e"], r.sceneInfo().tiles_x
+            rows = gsdist.interleaved_rows(gh, rank, world)
+            mine = np.isin(ref["tile"][:e] // gw, rows)
+            assert np.array_equal(r.debugRead(gs.BUF_SORTED_TILE), ref["tile"][:e][mine]), what
+            assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), ref["id"][:e][mine]), what
+            for row in rows:
+                assert np.array_equal(img[row * 16:row * 16 + 16], ref["image"][row * 16:row * 16 + 16]), what
+        r.cleanup()
+
+
 def test_host_timers(small_cloud):
     """RECORD_CPU_TIMES figures (Renderer.cpp:399-456) through gs_get_host_timings."""
     w, h = 320, 180

@@ -58,8 +58,9 @@ def morton_codes(pos: np.ndarray) -> np.ndarray:
     min_pos = np.minimum(np.float32(np.finfo(np.float32).max), pos.min(axis=0))
     max_pos = np.maximum(np.float32(np.finfo(np.float32).tiny), pos.max(axis=0))
     delta = (max_pos - min_pos).astype(np.float32)
-    m = ((pos - min_pos) / delta * np.float32(1023.0)).astype(np.float32)
-    q = m.astype(np.uint32)  # glm::uvec3(vec3): truncation
+    with np.errstate(invalid="ignore", divide="ignore"):       # a single splat: delta = 0, as in the reference
+        m = ((pos - min_pos) / delta * np.float32(1023.0)).astype(np.float32)
+        q = np.nan_to_num(m, nan=0.0, posinf=0.0, neginf=0.0).astype(np.uint32)  # glm::uvec3(vec3): truncation
 
     def part(x):
         x = x & np.uint32(0x3FF)
