@@ -21,7 +21,8 @@ constexpr int kBins = 1 << kRadixBits; // RS_BIN_COUNT
 constexpr int kSortThreads = 256;
 constexpr int kSortKeysPerThread = 8;
 constexpr int kSortTile = kSortThreads * kSortKeysPerThread; // 2048 keys
-constexpr int kSegments = 1024;               // reduce segments = Count workgroups; each owns a contiguous run of groups
+constexpr int kSegments = 512;                // reduce segments = Count workgroups; each owns a contiguous run of groups
+                                              // (measured: 512 beats 256 and 1024 at configs A-E)
 constexpr int kCoarse = 64;                   // coarse reduce segments (kSegments / kCoarse segments each): second Reduce level
 constexpr int kMaxSortPasses = 16;            // 64 key bits / 4
 

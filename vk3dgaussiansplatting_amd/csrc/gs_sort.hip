@@ -45,6 +45,7 @@ constexpr int kSortWaves = kSortThreads / 64;
 // W16: the word the digit lives in is stored as 16 bits (tile ids of a frame; the upper depth half in passes 4-7).
 // ---------------------------------------------------------------------------------------------
 constexpr int kCountKeysPerLane = kSortTile / 64;   // 32
+constexpr int kCountMaxK = 128;                     // groups per segment whose counts are kept in LDS (8 KB)
 static_assert(kCountKeysPerLane % 8 == 0, "k_count consumes the group in chunks of 8 keys per lane");
 
 template <bool W16>
@@ -119,13 +120,13 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
                                                          uint32_t* __restrict__ coarse,
                                                          uint32_t sh) {
     __shared__ uint32_t s_pack[kSortWaves][8];      // wave-private: packed totals of the group the wave just counted
-    __shared__ uint32_t s_tot[kSortWaves][kBins];   // per-wave share of the segment totals
+    __shared__ uint32_t s_hist[kCountMaxK][kBins];  // digit counts of the segment's groups (the first kCountMaxK of them)
     const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // segment = blockIdx.x owns groups [seg*K, min(seg*K + K, G)); wave w takes groups seg*K + w, + 4, ...
     const uint32_t grp_end = (blockIdx.x * K + K < G) ? blockIdx.x * K + K : G;
-    uint32_t grp = blockIdx.x * K + (uint32_t)wave;
-    uint32_t seg_total = 0;     // lanes 0..15: the wave's share of the segment's total of digit `lane`
+    const uint32_t grp0 = blockIdx.x * K;
+    uint32_t grp = grp0 + (uint32_t)wave;
     CountRegs<W16> cur;
     if (grp < grp_end) count_load<W16>(word, grp, e, lane, cur);
     while (grp < grp_end) {
@@ -153,25 +154,32 @@ __global__ __launch_bounds__(kSortThreads) void k_count(const SortParams* __rest
             const int widx = (lane & 3) * 2 + (lane >> 3);
             const int half = (lane >> 2) & 1;
             const uint32_t t = (s_pack[wave][widx] >> (16 * half)) & 0xFFFFu;
-            table[lane * G + grp] = t;               // RadixSortCount.comp:89, bin-major
-            seg_total += t;
+            const uint32_t j = grp - grp0;
+            if (j < (uint32_t)kCountMaxK) s_hist[j][lane] = t;
+            else table[lane * G + grp] = t;          // segments of more than kCountMaxK groups (E > 268 M): raw counts, see below
         }
         __builtin_amdgcn_wave_barrier();   // ... nor the next group's writes above these reads
         if (nxt_grp < grp_end) cur = nxt;
         grp = nxt_grp;
     }
-    if (lane < kBins) s_tot[wave][lane] = seg_total;
     __syncthreads();
+    // ScanAdd inside the segment (RadixSortScanAdd.comp:34-66), here rather than in every Scatter workgroup: the table
+    // gets, per group and digit, the number of keys of that digit in the EARLIER groups of the segment (bin-major,
+    // RadixSortCount.comp:89); the segment totals go to the reduce buffer (RadixSortReduce.comp:34-72).
     if (tid < kBins) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int k = 0; k < kSortWaves; ++k) t += s_tot[k][tid];
-        seg_sum[tid * kSegments + blockIdx.x] = t;   // Reduce (RadixSortReduce.comp:34-72); zero for empty segments
+        const uint32_t n_grp = grp_end > grp0 ? grp_end - grp0 : 0u;
+        uint32_t run = 0;
+        for (uint32_t j = 0; j < n_grp; ++j) {
+            const uint32_t t = j < (uint32_t)kCountMaxK ? s_hist[j][tid] : table[tid * G + grp0 + j];
+            table[tid * G + grp0 + j] = run;
+            run += t;
+        }
+        seg_sum[tid * kSegments + blockIdx.x] = run;   // zero for empty segments
         // Reduce, second level: kCoarse coarse segments of kSegments / kCoarse segments each, summed with one
         // agent-scope atomic add per digit and workgroup (no return value, nothing waits for it; the launch boundary
         // publishes it).  Scatter's prologue scans these 16 x kCoarse totals itself -- there is no Scan launch.
-        if (t != 0u)
-            (void)__hip_atomic_fetch_add(&coarse[tid * kCoarse + blockIdx.x / (kSegments / kCoarse)], t,
+        if (run != 0u)
+            (void)__hip_atomic_fetch_add(&coarse[tid * kCoarse + blockIdx.x / (kSegments / kCoarse)], run,
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -251,14 +259,15 @@ __device__ __forceinline__ void scatter_group(
     //      + digit d in earlier coarse segments + in earlier segments of this coarse segment + in earlier groups of
     //      this segment (RadixSortScan.comp:29-71 and RadixSortScanAdd.comp:34-66, evaluated where they are used).
     constexpr uint32_t kFinePerCoarse = kSegments / kCoarse;
-    const uint32_t seg = grp / K, j = grp - seg * K;                  // j < K (K <= 64 up to 134 M elements)
+    const uint32_t seg = grp / K;
     const uint32_t cseg = seg / kFinePerCoarse, jf = seg - cseg * kFinePerCoarse;
     const int sd = lane & 15, sq = lane >> 4;
     // thread t: digit t >> 4, coarse segments 4 (t & 15) .. + 3
     static_assert(kCoarse == 64 && kSortThreads == 256, "one 16-byte load per thread covers the coarse totals");
     const uint4 cv = reinterpret_cast<const uint4*>(coarse)[tid];
-    uint32_t pre = 0;
-    for (uint32_t l = (uint32_t)sq; l < j; l += 4u) pre += table[sd * G + seg * K + l];
+    // the table already holds the group's prefix inside its segment (k_count); lanes of row 0 take it, every row
+    // adds its share of the segment totals ahead inside the coarse segment
+    uint32_t pre = sq == 0 ? table[sd * G + grp] : 0u;
     for (uint32_t l = (uint32_t)sq; l < jf; l += 4u) pre += seg_sum[sd * kSegments + cseg * kFinePerCoarse + l];
 
     uint32_t lo[R], hi[R], id[R];
