@@ -72,3 +72,27 @@ def _cached_synth_clouds():
     synth.generate = cached
     yield
     synth.generate = orig
+
+
+def extreme_cloud(n=4000, k=500, w=200, h=120, seed=2024):
+    """Saturating conversions, huge and tiny footprints, splats on the cull boundaries, opacity 0 and 1, large SH
+    coefficients, zero quaternions / scales -- all finite.  Used by the GPU parity test and (n = 1200, k = 150) by the
+    Common.glsl cross-check fixture."""
+    from vk3dgaussiansplatting_amd import synth
+    rng = np.random.default_rng(seed)
+    aos = synth.generate(n, w, h, -2.5, seed=99, morton=False)
+    # scales from 1e-7 to 1e4 (radius saturates the int conversion for the largest)
+    aos[:, 4:7] = np.exp(rng.uniform(np.log(1e-7), np.log(1e4), (n, 3))).astype(np.float32)
+    # a block of splats hugging the near plane and the 1.3 NDC side planes
+    aos[:k, 2] = np.float32(0.1) + np.float32(1e-6) * rng.integers(0, 40, k).astype(np.float32)
+    aos[:k, 0] = aos[:k, 2] * np.float32(w / h) * rng.choice(np.float32([1.2999, 1.3, 1.3001, -1.3, 0.0]), k)
+    aos[:k, 1] = aos[:k, 2] * rng.choice(np.float32([1.2999, 1.3, 1.3001, -1.3, 0.5]), k)
+    # far beyond the far plane (depth key saturates) -- there is no far cull in the reference
+    aos[k:2 * k, 2] = rng.uniform(90, 5000, k).astype(np.float32)
+    aos[k:2 * k, 0] = aos[k:2 * k, 2] * rng.uniform(-1, 1, k).astype(np.float32)
+    aos[k:2 * k, 1] = aos[k:2 * k, 2] * rng.uniform(-0.7, 0.7, k).astype(np.float32)
+    aos[:, 15] = rng.choice(np.float32([0.0, 1.0, 0.5, 1e-3, 0.999]), n)          # opacity
+    aos[::7, 12:15] = rng.uniform(-100, 100, (len(aos[::7]), 3)).astype(np.float32)  # SH dc
+    aos[::11, 8:12] = 0.0                                                             # zero quaternion
+    aos[::13, 4:7] = 0.0                                                              # zero scale
+    return aos

@@ -39,6 +39,21 @@ def run(aos, view, proj, cam_pos, w, h):
     return out
 
 
+def extreme_inputs():
+    """A second, hostile input set: tests/conftest.py's extreme_cloud (scales 1e-7 .. 1e4, splats on the cull planes,
+    beyond the far plane, zero quaternions / scales, SH dc up to 100) under a rotated camera.  The records themselves
+    are stored in the fixture, so it does not depend on numpy's generators."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    from conftest import extreme_cloud
+    import oracle
+    w, h = 200, 120
+    aos = extreme_cloud(1200, 150, w, h)
+    pos = np.array([0.05, -0.02, -0.3], np.float32)
+    view, proj = oracle.camera_matrices(pos, 0.1, -0.05, w / h)    # only a matrix generator here (itself pinned by glm)
+    return aos, view, proj, pos, w, h
+
+
 if __name__ == "__main__":
     if not os.path.exists(EXE):
         sys.exit("build oracle/_ref/ref_glsl_xcheck first (make -C oracle ref; needs /root/reference)")
@@ -46,4 +61,9 @@ if __name__ == "__main__":
     out = run(g["aos"], g["view"], g["proj"], g["cam_pos"], int(g["width"]), int(g["height"]))
     path = os.path.join(GOLDEN, "ref_common_glsl.npz")
     np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+    aos, view, proj, pos, w, h = extreme_inputs()
+    out = run(aos, view, proj, pos, w, h)
+    path = os.path.join(GOLDEN, "ref_common_glsl_extreme.npz")
+    np.savez_compressed(path, aos=aos, view=view, proj=proj, cam_pos=pos, width=np.uint32(w), height=np.uint32(h), **out)
     print("wrote", path, os.path.getsize(path), "bytes")

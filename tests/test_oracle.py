@@ -32,17 +32,22 @@ def test_committed_fixture_is_what_the_reference_code_produces():
     assert out == open(os.path.join(GOLDEN, "ref_glm_smath.json"), "rb").read()
 
 
-def test_common_glsl_cross_check(oracle_mod):
-    """CROSS-CHECK, not a pin: tests/golden/ref_common_glsl.npz is what the reference's own Common.glsl text returns
-    when compiled as C++ over its vendored glm (oracle/ref_glsl_xcheck.cpp) for the 600 golden splats.  The
-    oracle's covariance (getRotMat + getCovarianceMatrix, Common.glsl:17-78), screen position (:80-89) and colour in
-    all three SH modes (:94-170) are bit-identical to it for every splat that survives the culls -- which rules out
-    a shared misreading of constructors, product order or operand order.  (glm folds `tan(FOV_Y * 0.5f)` with tanf;
-    the oracle folds it in double: same float here.)  Where the reference is mounted the committed dump is
-    regenerated and compared first."""
+@pytest.mark.parametrize("which", ["golden", "extreme"])
+def test_common_glsl_cross_check(oracle_mod, which):
+    """CROSS-CHECK, not a pin: tests/golden/ref_common_glsl*.npz is what the reference's own Common.glsl text returns
+    when compiled as C++ over its vendored glm (oracle/ref_glsl_xcheck.cpp) -- for the 600 golden splats, and for 1200
+    hostile ones (scales 1e-7 .. 1e4, splats on the cull planes and beyond the far plane, zero quaternions / scales,
+    SH dc up to 100; rotated camera).  The oracle's covariance (getRotMat + getCovarianceMatrix, Common.glsl:17-78),
+    screen position (:80-89) and colour in all three SH modes (:94-170) are bit-identical to it for every splat that
+    survives the culls -- which rules out a shared misreading of constructors, product order or operand order.
+    (glm folds `tan(FOV_Y * 0.5f)` with tanf; the oracle folds it in double: same float here.)  Where the reference
+    is mounted the committed dumps are regenerated and compared first."""
     from conftest import ROOT
-    g = np.load(os.path.join(GOLDEN, "small_scene.npz"))
-    x = np.load(os.path.join(GOLDEN, "ref_common_glsl.npz"))
+    if which == "golden":
+        g = np.load(os.path.join(GOLDEN, "small_scene.npz"))
+        x = np.load(os.path.join(GOLDEN, "ref_common_glsl.npz"))
+    else:
+        g = x = np.load(os.path.join(GOLDEN, "ref_common_glsl_extreme.npz"))
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_glsl_xcheck")
     if os.path.isdir("/root/reference/vkGaussianSplatting") and os.path.exists(exe):
         import importlib.util
@@ -52,6 +57,8 @@ def test_common_glsl_cross_check(oracle_mod):
         fresh = mod.run(g["aos"], g["view"], g["proj"], g["cam_pos"], int(g["width"]), int(g["height"]))
         for k, v in fresh.items():
             assert v.tobytes() == x[k].tobytes(), k
+        if which == "extreme":                               # the stored inputs are what the helper still generates
+            assert mod.extreme_inputs()[0].tobytes() == g["aos"].tobytes()
     w, h = int(g["width"]), int(g["height"])
     import ctypes
     tan_oracle = np.array([oracle_mod.lib().gso_tan_half_fov(ctypes.c_float(3.1415 * 0.5))], np.float32)

@@ -114,6 +114,29 @@ def test_golden_fixture(sh_mode):
     r.cleanup()
 
 
+def test_common_glsl_cross_check_extreme():
+    """The HIP path against tests/golden/ref_common_glsl_extreme.npz directly (no oracle code runs): 1200 hostile
+    splats through the reference's own Common.glsl text over its glm -- covariance of every splat the frame keeps
+    and colour of every emitting one, bit for bit, in all three SH modes.  A cross-check, not a pin."""
+    x = np.load(os.path.join(GOLDEN, "ref_common_glsl_extreme.npz"))
+    w, h = int(x["width"]), int(x["height"])
+    for sh_mode in (0, 1, 2):
+        rm = gs.ResourceManager()
+        rm.setGaussians(x["aos"])
+        sc = gs.Scene(rm, aspect_ratio=w / h)
+        sc.camera.viewMatrix, sc.camera.projectionMatrix = x["view"], x["proj"]
+        sc.camera.position = x["cam_pos"]
+        sc.camera.setShMode(sh_mode)
+        r = make_renderer(sc, w, h)
+        r.draw(sc)
+        emits = np.zeros(x["aos"].shape[0], bool)
+        emits[r.debugRead(gs.BUF_SORTED_ID)] = True
+        assert emits.sum() > 300
+        assert np.array_equal(r.debugRead(gs.BUF_COLOR)[emits, :3].view(np.uint32), x["color"][sh_mode][emits].view(np.uint32))
+        assert np.array_equal(r.debugRead(gs.BUF_COV)[emits, :3].view(np.uint32), x["cov"][emits].view(np.uint32))
+        r.cleanup()
+
+
 def test_init_sort_list_stage(oracle_mod, small_cloud):
     """Emission order is the canonical one: ascending splat index, then row-major tile (N7/N8)."""
     w, h = 320, 180
@@ -375,25 +398,9 @@ def test_extreme_but_finite_inputs(oracle_mod):
     """Saturating conversions, huge and tiny footprints, splats on the cull boundaries, opacity 0 and 1,
     large SH coefficients: the HIP path must make exactly the oracle's decisions (counter, keys, ranges,
     pixels), including list overflow caused by the screen-filling splats."""
-    rng = np.random.default_rng(2024)
+    from conftest import extreme_cloud
     w, h = 200, 120
-    n = 4000
-    aos = synth.generate(n, w, h, -2.5, seed=99, morton=False)
-    # scales from 1e-7 to 1e4 (radius saturates the int conversion for the largest)
-    aos[:, 4:7] = np.exp(rng.uniform(np.log(1e-7), np.log(1e4), (n, 3))).astype(np.float32)
-    # a block of splats hugging the near plane and the 1.3 NDC side planes
-    k = 500
-    aos[:k, 2] = np.float32(0.1) + np.float32(1e-6) * rng.integers(0, 40, k).astype(np.float32)
-    aos[:k, 0] = aos[:k, 2] * np.float32(w / h) * rng.choice(np.float32([1.2999, 1.3, 1.3001, -1.3, 0.0]), k)
-    aos[:k, 1] = aos[:k, 2] * rng.choice(np.float32([1.2999, 1.3, 1.3001, -1.3, 0.5]), k)
-    # far beyond the far plane (depth key saturates) -- there is no far cull in the reference
-    aos[k:2 * k, 2] = rng.uniform(90, 5000, k).astype(np.float32)
-    aos[k:2 * k, 0] = aos[k:2 * k, 2] * rng.uniform(-1, 1, k).astype(np.float32)
-    aos[k:2 * k, 1] = aos[k:2 * k, 2] * rng.uniform(-0.7, 0.7, k).astype(np.float32)
-    aos[:, 15] = rng.choice(np.float32([0.0, 1.0, 0.5, 1e-3, 0.999]), n)          # opacity
-    aos[::7, 12:15] = rng.uniform(-100, 100, (len(aos[::7]), 3)).astype(np.float32)  # SH dc
-    aos[::11, 8:12] = 0.0                                                             # zero quaternion
-    aos[::13, 4:7] = 0.0                                                              # zero scale
+    aos = extreme_cloud(4000, 500, w, h)
     sc = make_scene(aos, w, h)
     _, ref = oracle_run(oracle_mod, sc, w, h)
     assert np.isfinite(ref["stage1"]["cov"]).all() and np.isfinite(ref["stage1"]["color"]).all()
