@@ -6,6 +6,9 @@
 //     getCovarianceMatrix    Common.glsl:32-78
 //     getScreenSpacePosition Common.glsl:80-89
 //     getShColor/getShEval4  Common.glsl:94-170
+// and, cut out of ComputeShaders/InitSortList.comp by the Makefile (see below),
+//     getGaussianTileExtents InitSortList.comp:47-68
+//     getDepthKey            InitSortList.comp:70-80
 // tests/test_oracle.py compares oracle/gs_oracle.c against the committed dump.  What this catches is a
 // shared MISREADING of the shader text by the two restatements in this repo (column-major constructors,
 // matrix product order, swizzles, operand order); what it cannot do is pin GLSL's arithmetic: glm is a
@@ -46,9 +49,19 @@ using namespace glm;
 #define inout
 #include "Common/Common.glsl"   // -I /root/reference/vkGaussianSplatting/Resources/Shaders
 
+// The two helper functions of ComputeShaders/InitSortList.comp, getGaussianTileExtents (:47-68) and getDepthKey (:70-80),
+// are pure apart from reading the camera UBO and the push constants.  The Makefile cuts exactly those lines out of the
+// reference file into oracle/_ref/initsortlist_fns.inc (a build intermediate, never committed); the two data blocks
+// they read are declared here with the members the shader declares (InitSortList.comp:13-17, 38-43).
+struct { mat4 viewMat; mat4 projMat; } ubo;
+struct { vec4 clipPlanes; vec4 camPos; uvec4 resolution; } pc;
+#include "initsortlist_fns.inc"   // -I oracle/_ref
+
 // input : u32 n, width, height; f32 view[16], proj[16], cam_pos[3]; f32 aos[n][84]
 // output: f32 rot[n][9] (column-major), cov[n][3], screen[n][2], color[3 modes][n][3], viewpos_glm[n][4],
-//         viewpos_in[n][4], f32 tan_half_fov (what glm folds `tan(FOV_Y * 0.5f)` to)
+//         viewpos_in[n][4], f32 tan_half_fov (what glm folds `tan(FOV_Y * 0.5f)` to),
+//         u32 extents[n][4] (getGaussianTileExtents on the cov above), u32 depth_key[n], u32 depth_key_defined[n]
+//         (0 where the normalised depth reaches 1: `uint(1.0 * 2^32)` is out of range, undefined in GLSL and in C++)
 int main(int argc, char** argv) {
     if (argc != 3) { std::fprintf(stderr, "usage: %s input.bin output.bin\n", argv[0]); return 2; }
     FILE* f = std::fopen(argv[1], "rb");
@@ -65,6 +78,13 @@ int main(int argc, char** argv) {
     std::memcpy(&viewMat[0][0], view_f, 64);   // glm is column-major like the UBO (Renderer.cpp:531-538)
     std::memcpy(&projMat[0][0], proj_f, 64);
     const float width = (float)hdr[1], height = (float)hdr[2];
+    ubo.viewMat = viewMat; ubo.projMat = projMat;
+    pc.clipPlanes = vec4(0.1f, 100.0f, (float)n, 0.0f);          // Subrenderer.cpp:152-160, Camera.cpp:4-5
+    pc.camPos = vec4(cam[0], cam[1], cam[2], 0.0f);
+    pc.resolution = uvec4(hdr[1], hdr[2], 0u, 0u);
+    const ivec2 gridSize((int(pc.resolution.x) + TILE_SIZE - 1) / TILE_SIZE,          // InitSortList.comp:107-110
+                         (int(pc.resolution.y) + TILE_SIZE - 1) / TILE_SIZE);
+    std::vector<uint32_t> ext((size_t)n * 4), dkey(n), dkey_ok(n);
 
     std::vector<float> rot((size_t)n * 9), cov((size_t)n * 3), scr((size_t)n * 2), col((size_t)3 * n * 3),
         vpg((size_t)n * 4), vpi((size_t)n * 4);
@@ -98,6 +118,11 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 3; ++i) col[((size_t)mode * n + g) * 3 + i] = rgb[i];
         }
         for (int i = 0; i < 4; ++i) { vpg[(size_t)g * 4 + i] = viewPosGlm[i]; vpi[(size_t)g * 4 + i] = viewPos[i]; }
+        const uvec4 e = getGaussianTileExtents(g, viewPos, gridSize, c, width, height);   // InitSortList.comp:121
+        for (int i = 0; i < 4; ++i) ext[(size_t)g * 4 + i] = e[i];
+        const float nd = (-viewPos.z - pc.clipPlanes.x) / (pc.clipPlanes.y - pc.clipPlanes.x);
+        dkey_ok[g] = (nd < 1.0f) ? 1u : 0u;                       // NaN and >= 1: the conversion below is undefined
+        dkey[g] = dkey_ok[g] ? getDepthKey(viewPos.z) : 0u;       // InitSortList.comp:104
     }
     const float tan_half = tan(FOV_Y * 0.5f);   // glm::tan(float), as Common.glsl:53 reads under glm
     FILE* o = std::fopen(argv[2], "wb");
@@ -109,6 +134,9 @@ int main(int argc, char** argv) {
     std::fwrite(vpg.data(), 4, vpg.size(), o);
     std::fwrite(vpi.data(), 4, vpi.size(), o);
     std::fwrite(&tan_half, 4, 1, o);
+    std::fwrite(ext.data(), 4, ext.size(), o);
+    std::fwrite(dkey.data(), 4, dkey.size(), o);
+    std::fwrite(dkey_ok.data(), 4, dkey_ok.size(), o);
     std::fclose(o);
     return 0;
 }

@@ -29,11 +29,14 @@ def run(aos, view, proj, cam_pos, w, h):
         subprocess.run([EXE, fin, fout], check=True)
         raw = np.fromfile(fout, "<f4")
     sizes = [("rot", (n, 9)), ("cov", (n, 3)), ("screen", (n, 2)), ("color", (3, n, 3)), ("viewpos_glm", (n, 4)),
-             ("viewpos_in", (n, 4)), ("tan_half_fov", (1,))]
+             ("viewpos_in", (n, 4)), ("tan_half_fov", (1,)), ("extents", (n, 4)), ("depth_key", (n,)),
+             ("depth_key_defined", (n,))]
     out, off = {}, 0
     for name, shape in sizes:
         cnt = int(np.prod(shape))
         out[name] = raw[off:off + cnt].reshape(shape).copy()
+        if name in ("extents", "depth_key", "depth_key_defined"):
+            out[name] = out[name].view(np.uint32)
         off += cnt
     assert off == raw.size
     return out

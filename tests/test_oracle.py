@@ -39,7 +39,8 @@ def test_common_glsl_cross_check(oracle_mod, which):
     hostile ones (scales 1e-7 .. 1e4, splats on the cull planes and beyond the far plane, zero quaternions / scales,
     SH dc up to 100; rotated camera).  The oracle's covariance (getRotMat + getCovarianceMatrix, Common.glsl:17-78),
     screen position (:80-89) and colour in all three SH modes (:94-170) are bit-identical to it for every splat that
-    survives the culls -- which rules out a shared misreading of constructors, product order or operand order.
+    survives the culls, and so are the tile extents and depth keys that lines 45-80 of InitSortList.comp give --
+    which rules out a shared misreading of constructors, product order, operand order, truncation or clamps.
     (glm folds `tan(FOV_Y * 0.5f)` with tanf; the oracle folds it in double: same float here.)  Where the reference
     is mounted the committed dumps are regenerated and compared first."""
     from conftest import ROOT
@@ -73,6 +74,17 @@ def test_common_glsl_cross_check(oracle_mod, which):
             assert np.array_equal(s1["cov"][vis, :3].view(np.uint32), x["cov"][vis].view(np.uint32))
             scr = np.stack([s1["splats"]["screen_x"], s1["splats"]["screen_y"]], axis=1)
             assert np.array_equal(scr[vis].view(np.uint32), x["screen"][vis].view(np.uint32))
+            # the two helper functions of InitSortList.comp, run from the reference's own lines 45-80: tile extents
+            # (getGaussianTileExtents, :47-68 -- int() truncation towards zero, the + 1, the clamps) and depth keys
+            # (getDepthKey, :70-80) wherever `uint(nd * 2^32)` is defined (nd < 1; at nd = 1 GLSL leaves it undefined and
+            # the restatement saturates, N2)
+            sp = s1["splats"]
+            ext = np.stack([sp["min_x"], sp["min_y"], sp["max_x"], sp["max_y"]], axis=1)
+            assert np.array_equal(ext[vis], x["extents"][vis])
+            ok = vis & (x["depth_key_defined"] == 1)
+            assert ok.sum() > 400 and np.array_equal(sp["depth_key"][ok], x["depth_key"][ok])
+            sat = vis & (x["depth_key_defined"] == 0)
+            assert np.all(sp["depth_key"][sat] == 0xFFFFFFFF)
     # for the record: glm's own mat4 * vec4 associates (m0 x + m1 y) + (m2 z + m3 w); the restatements (and the dump's
     # inputs) use GLSL's textual left-to-right order.  They agree to a few ulp, not bit for bit.
     a, b = x["viewpos_glm"].astype(np.float64), x["viewpos_in"].astype(np.float64)

@@ -134,6 +134,23 @@ def test_common_glsl_cross_check_extreme():
         assert emits.sum() > 300
         assert np.array_equal(r.debugRead(gs.BUF_COLOR)[emits, :3].view(np.uint32), x["color"][sh_mode][emits].view(np.uint32))
         assert np.array_equal(r.debugRead(gs.BUF_COV)[emits, :3].view(np.uint32), x["cov"][emits].view(np.uint32))
+        if sh_mode == 0:
+            # the emitted list against the reference's own getGaussianTileExtents / getDepthKey (InitSortList.comp:45-80
+            # run over its glm): every splat's elements are its extents rectangle in row-major order, ascending splat
+            # index (the canonical order), with its depth key (where `uint(nd * 2^32)` is defined)
+            r.debugInitSortList(sc)
+            tile, depth, ident = (r.debugRead(b) for b in (gs.BUF_UNSORTED_TILE, gs.BUF_UNSORTED_DEPTH, gs.BUF_UNSORTED_ID))
+            gw = r.sceneInfo().tiles_x
+            want_t, want_i, want_d = [], [], []
+            for g in np.nonzero(emits)[0]:
+                x0, y0, x1, y1 = (int(v) for v in x["extents"][g])
+                ys, xs = np.meshgrid(np.arange(y0, y1), np.arange(x0, x1), indexing="ij")
+                want_t.append((ys * gw + xs).ravel()); want_i.append(np.full(ys.size, g)); want_d.append(np.full(ys.size, x["depth_key"][g]))
+            want_t, want_i, want_d = (np.concatenate(v).astype(np.uint32) for v in (want_t, want_i, want_d))
+            assert np.array_equal(tile, want_t) and np.array_equal(ident, want_i)
+            defined = x["depth_key_defined"][ident] == 1
+            assert defined.sum() > 1000 and np.array_equal(depth[defined], want_d[defined])
+            assert np.all(depth[~defined] == 0xFFFFFFFF)
         r.cleanup()
 
 
