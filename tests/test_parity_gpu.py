@@ -918,3 +918,85 @@ def test_camera_sequence_has_no_frame_to_frame_state(oracle_mod, small_cloud, so
     img = r.draw(scenes[1])
     assert_frame_equals_oracle(r, img, refs[1])
     r.cleanup()
+
+
+def test_rccl_calls_of_the_sharded_frame_single_rank(tmp_path):
+    """The collectives `bench.py --gpus N` and dist.ShardedFrame issue, through the "nccl" backend (= RCCL) on the one
+    GPU a test box has: process group with device_id, async gather of uint8 strips to rank 0 on a side stream ordered
+    behind the producing stream, all_reduce(MAX) of a float64, all_gather, barrier.  World size 1 is all one card
+    allows (RCCL refuses two ranks on one device); the N > 1 plumbing is covered over gloo in tests/test_dist.py and
+    tests/test_bench_launcher.py.  Runs in a child process so that this process never holds a communicator."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, torch, torch.distributed as tdist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        tdist.init_process_group(backend="nccl", device_id=dev)
+        st = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(st)
+        strip = torch.randint(0, 256, (272, 3840, 4), dtype=torch.uint8, device=dev)
+        out = [torch.zeros_like(strip)]
+        with torch.cuda.stream(st):
+            work = tdist.gather(strip, out, dst=0, async_op=True)
+            work.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], strip)
+        el = torch.tensor([1.25], dtype=torch.float64, device=dev)
+        tdist.all_reduce(el, op=tdist.ReduceOp.MAX)
+        stats = torch.arange(8, dtype=torch.float64, device=dev)
+        got = [torch.zeros_like(stats)]
+        tdist.all_gather(got, stats)
+        tdist.barrier()
+        torch.cuda.synchronize()
+        assert float(el.item()) == 1.25 and torch.equal(got[0], stats)
+        tdist.destroy_process_group()
+        print("rccl-ok")
+    """)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "rccl-ok" in p.stdout, p.stderr[-2000:]
+
+
+def test_emit_slices_of_heavy_blocks(oracle_mod):
+    """k_emit gives every workgroup at most 4096 output elements: the further slices of a project block whose 256 splats
+    emit more are run by helper workgroups from records registered in atomic arrival order.  A cloud of large splats
+    (every block far beyond one slice, no overflow) must give the canonical unsorted list -- ascending splat index,
+    row-major tiles (N7/N8) -- on the full grid, in a contiguous band and in an interleaved share, frame after frame
+    (the two helper counters alternate)."""
+    w, h = 640, 360
+    gw, gh = oracle_mod.grid(w, h)
+    n = 3000
+    aos = synth.generate(n, w, h, -0.3, seed=77)
+    sc = make_scene(aos, w, h)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    s1, e = ref["stage1"], ref["e"]
+    assert s1["counter"] == e, "test cloud must not overflow"
+    per_splat = np.bincount(s1["id"][:e], minlength=n)
+    per_block = np.add.reduceat(per_splat, np.arange(0, n, 256))
+    assert per_block.max() > 8 * 4096 and per_block.min() > 4096, per_block
+    r = make_renderer(sc, w, h)
+    for _ in range(3):
+        r.debugInitSortList(sc)
+        assert int(r.debugRead(gs.BUF_COUNT)[0]) == e
+        assert np.array_equal(r.debugRead(gs.BUF_UNSORTED_TILE), s1["tile"][:e])
+        assert np.array_equal(r.debugRead(gs.BUF_UNSORTED_DEPTH), s1["depth"][:e])
+        assert np.array_equal(r.debugRead(gs.BUF_UNSORTED_ID), s1["id"][:e])
+    assert_frame_equals_oracle(r, r.draw(sc), ref)
+    rows_of = s1["tile"][:e] // gw
+    for label, rows in (("band", list(range(7, 16))), ("interleaved", list(range(1, gh, 3)))):
+        if label == "band":
+            r.setTileRows(rows[0], rows[-1] + 1)
+        else:
+            r.setTileRowsInterleaved(1, 3)
+        mine = np.isin(rows_of, rows)
+        for _ in range(2):
+            r.debugInitSortList(sc)
+            assert int(r.debugRead(gs.BUF_COUNT)[0]) == mine.sum()
+            assert np.array_equal(r.debugRead(gs.BUF_UNSORTED_TILE), s1["tile"][:e][mine])
+            assert np.array_equal(r.debugRead(gs.BUF_UNSORTED_DEPTH), s1["depth"][:e][mine])
+            assert np.array_equal(r.debugRead(gs.BUF_UNSORTED_ID), s1["id"][:e][mine])
+        img = r.draw(sc)
+        for row in rows:
+            assert np.array_equal(img[row * 16:row * 16 + 16], ref["image"][row * 16:row * 16 + 16])
+    r.cleanup()

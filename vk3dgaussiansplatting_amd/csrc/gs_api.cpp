@@ -46,6 +46,7 @@ struct gs_ctx {
     SceneBuffers scene{};
     SplatScratch scratch{};
     uint32_t num_blocks = 0;
+    uint32_t emit_parity = 0;     // FrameParams::parity of the last InitSortList launch
     SharedScene* shared = nullptr;    // owner of `scene`'s arrays (this context holds one reference)
 
     // resolution-dependent
@@ -111,6 +112,7 @@ void free_scene(gs_ctx* c) {
     c->scene = SceneBuffers{};
     free_dev(c->scratch.raster); free_dev(c->scratch.depth_key); free_dev(c->scratch.tiles_touched);
     free_dev(c->scratch.extents); free_dev(c->scratch.block_sums); free_dev(c->scratch.block_offsets);
+    free_dev(c->scratch.help_list); free_dev(c->scratch.help_count); free_dev(c->scratch.help_slot);
     c->n = 0;
 }
 
@@ -182,6 +184,7 @@ FrameParams make_frame_params(const gs_ctx* c, const float* view, const float* p
     fp.ndc_cull = c->cfg.ndc_cull; fp.in_view_limit = c->cfg.in_view_limit;
     fp.tan_fov_y = (float)std::tan((double)(c->cfg.fov_y * 0.5f));   // Common.glsl:53, host-folded
     fp.hi16 = c->hi16 ? 1u : 0u;
+    fp.parity = 0u;       // set by the InitSortList launch sites
     fp.w_frob2 = 0.0f;
     for (int col = 0; col < 3; ++col)
         for (int row = 0; row < 3; ++row) fp.w_frob2 += view[col * 4 + row] * view[col * 4 + row];
@@ -206,6 +209,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     // ranges need clearing here: the 0xFF sentinel fill of both lists (Subrenderer.cpp:42-46,
     // RadixSort.cpp:676-692) is unobservable once every later stage runs over E instead of C.
     // (the ranges and the sort's coarse totals are cleared inside k_scan_blocks: no fill launches in a frame)
+    fp.parity = (c->emit_parity ^= 1u);
     launch_project(fp, c->scene, c->scratch, st);
     launch_scan_blocks(fp, c->scratch, c->sort.params, c->ranges, c->sort.coarse, st);
     launch_emit(fp, c->scratch, c->sort, st);
@@ -459,6 +463,13 @@ static int alloc_scratch(gs_ctx* c, uint32_t n) {
     HIP_TRY(c, hipMemsetAsync(c->scratch.block_sums, 0, padded * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->scratch.block_offsets, 0, padded * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->scratch.raster, 0, N * sizeof(SplatRaster), c->stream));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.help_list, (size_t)kEmitHelpCap * sizeof(uint2)));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.help_count, 2 * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.help_slot, (size_t)c->num_blocks * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->scratch.help_count, 0, 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->scratch.help_list, 0, (size_t)kEmitHelpCap * sizeof(uint2), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->scratch.help_slot, 0xFF, (size_t)c->num_blocks * sizeof(uint32_t), c->stream));
+    c->emit_parity = 0;
     return GS_OK;
 }
 
@@ -657,7 +668,8 @@ int gs_debug_init_sort_list(gs_ctx* c, const float view[16], const float proj[16
     if (!c->n || !c->capacity) return fail(c, GS_ERR_NO_SCENE, "gs_debug_init_sort_list: scene/resolution not set");
     if (!view || !proj || !cam_pos || sh_mode > 2u) return fail(c, GS_ERR_INVALID, "gs_debug_init_sort_list: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
-    const FrameParams fp = make_frame_params(c, view, proj, cam_pos, sh_mode);
+    FrameParams fp = make_frame_params(c, view, proj, cam_pos, sh_mode);
+    fp.parity = (c->emit_parity ^= 1u);
     launch_project(fp, c->scene, c->scratch, c->stream);
     launch_scan_blocks(fp, c->scratch, c->sort.params, c->ranges, c->sort.coarse, c->stream);
     launch_emit(fp, c->scratch, c->sort, c->stream);

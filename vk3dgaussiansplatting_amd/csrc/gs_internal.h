@@ -54,6 +54,7 @@ struct FrameParams {
     float tan_fov_y;      // tan(FOV_Y*0.5f), folded on the host (Common.glsl:53)
     uint32_t hi16;        // sort list stores the compact tile ids as uint16 (at most 65535 owned tiles)
     float w_frob2;        // squared Frobenius norm of the upper-left 3x3 of view (host-folded, for the band bound)
+    uint32_t parity;      // InitSortList launches alternate between the two helper counters of SplatScratch
 };
 
 // Device-side dispatch record: the role of RadixIndirectDispatch (ShaderStructs.h:45-57) +
@@ -100,7 +101,21 @@ struct SplatScratch {
     uint2* extents;          // [N]  packed u16: .x = minx | miny<<16, .y = maxx | maxy<<16 (row-clamped)
     uint32_t* block_sums;    // [ceil(N/kProjThreads)]  tile counts per project workgroup
     uint32_t* block_offsets; // same size, exclusive scan
+    // k_emit load balance: a project workgroup whose 256 splats emit more than kEmitSlice elements registers one
+    // helper record {block, slice} per further slice; k_emit runs them as extra workgroups.
+    uint2* help_list;        // [kEmitHelpCap]
+    uint32_t* help_count;    // [2]: records registered this frame / cleared for the next one (FrameParams::parity)
+    uint32_t* help_slot;     // [ceil(N/kProjThreads)]: first record of a heavy block, kEmitNoHelp if the list was full
 };
+constexpr uint32_t kEmitSlice = 4096;      // output elements per k_emit workgroup (a multiple of its 1024-element round)
+constexpr uint32_t kEmitHelpCap = 65536;   // enough for 2^28 elements; beyond that the owner workgroup does the rest itself
+constexpr uint32_t kEmitNoHelp = 0xFFFFFFFFu;
+// helper workgroups of a k_emit launch = records k_project may register: the slices after the first number at most
+// E / kEmitSlice <= capacity / kEmitSlice over all blocks (more only when the list overflows its capacity)
+__host__ __device__ inline uint32_t emit_helpers(uint32_t capacity) {
+    const uint32_t by_capacity = capacity / kEmitSlice + 1u;
+    return by_capacity < kEmitHelpCap ? by_capacity : kEmitHelpCap;
+}
 
 struct SortBuffers {
     uint32_t *lo[2], *hi[2], *id[2]; // ping-pong: depth word, tile word, gaussian index; [capacity]

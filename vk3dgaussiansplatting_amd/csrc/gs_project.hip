@@ -391,11 +391,27 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
             if (i < valid * 3u && s_wave_emits[i / 192u]) out[i] = s_raster[i];
         }
     }
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
+    uint32_t t = 0;
 #pragma unroll
-        for (int w = 0; w < kProjThreads / 64; ++w) t += s_wave_sum[w];
-        sc.block_sums[blockIdx.x] = t;
+    for (int w = 0; w < kProjThreads / 64; ++w) t += s_wave_sum[w];
+    if (threadIdx.x == 0) sc.block_sums[blockIdx.x] = t;
+    // k_emit walks a workgroup's output range kEmitSlice elements per workgroup: a block that emits more (a few
+    // hundred near splats hold half of a tile-row band's elements) registers the slices after the first as helper
+    // records.  The order of the records depends on atomic arrival; what each one writes does not.
+    if (t > kEmitSlice) {
+        __shared__ uint32_t s_slot;
+        const uint32_t extra = (t - 1u) / kEmitSlice;
+        if (threadIdx.x == 0) {
+            uint32_t slot = atomicAdd(&sc.help_count[fp.parity], extra);
+            // no room (only when the element count overflows the list capacity): the owner does every slice
+            if ((uint64_t)slot + extra > (uint64_t)emit_helpers(fp.capacity)) slot = kEmitNoHelp;
+            sc.help_slot[blockIdx.x] = slot;
+            s_slot = slot;
+        }
+        __syncthreads();
+        const uint32_t slot = s_slot;
+        if (slot != kEmitNoHelp)
+            for (uint32_t i = threadIdx.x; i < extra; i += kProjThreads) sc.help_list[slot + i] = make_uint2(blockIdx.x, i + 1u);
     }
 }
 
@@ -409,7 +425,9 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict
                                                        uint32_t* __restrict__ block_offsets,
                                                        uint32_t num_blocks, uint32_t capacity,
                                                        SortParams* params, uint4* __restrict__ zero_a, uint32_t n16_a,
-                                                       uint4* __restrict__ zero_b, uint32_t n16_b) {
+                                                       uint4* __restrict__ zero_b, uint32_t n16_b,
+                                                       uint32_t* __restrict__ next_help_count) {
+    if (threadIdx.x == 0) *next_help_count = 0u;     // the helper counter the NEXT InitSortList launch adds to
     for (uint32_t i = threadIdx.x; i < n16_a; i += 1024u) zero_a[i] = make_uint4(0u, 0u, 0u, 0u);
     for (uint32_t i = threadIdx.x; i < n16_b; i += 1024u) zero_b[i] = make_uint4(0u, 0u, 0u, 0u);
     __shared__ uint64_t s_wave_tot[16];
@@ -453,15 +471,20 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict
     }
 }
 
-// Emit: workgroup b owns splats [b*256, b*256+256) and therefore output elements
+// Emit: the splats [b*256, b*256+256) of project workgroup b own the output elements
 // [block_offsets[b], +block_sums[b]).  Threads walk the OUTPUT range (coalesced stores); which splat
 // owns an element is resolved per chunk in LDS from the scan of the 256 tile counts (see the loop).
+// Workgroup b < num_blocks takes the first kEmitSlice elements of block b; the further slices of heavy blocks are
+// the helper records k_project registered, run by the workgroups >= num_blocks of the same launch (those beyond the
+// record count leave at once).  Without that split the launch lasted as long as its heaviest block: at 3840x2160 one
+// block of near splats emits 105 k elements (102 rounds), and in a 1/8 tile-row band 186 blocks hold 55 % of the list.
 constexpr int kEmitChunk = 4 * kProjThreads;   // output elements resolved per round of k_emit
+static_assert(kEmitSlice % kEmitChunk == 0, "a slice is a whole number of rounds");
 
 __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, const SplatScratch sc,
                                                         uint32_t* __restrict__ out_lo,
                                                         uint32_t* __restrict__ out_hi,
-                                                        uint32_t* __restrict__ out_id) {
+                                                        uint32_t* __restrict__ out_id, uint32_t num_blocks) {
     __shared__ uint32_t s_incl[kProjThreads];   // inclusive scan of tile counts
     __shared__ uint32_t s_wave_tot[kProjThreads / 64];
     __shared__ uint2 s_ext[kProjThreads];
@@ -470,14 +493,30 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
     __shared__ uint32_t s_wmax[kProjThreads / 64];
     const uint32_t n = fp.num_gaussians;
     const int tid = threadIdx.x;
-    const uint32_t g = blockIdx.x * kProjThreads + tid;
+    uint32_t blk = blockIdx.x, slice = 0u;
+    if (blk >= num_blocks) {                               // helper workgroup
+        const uint32_t h = blk - num_blocks;
+        if (h >= sc.help_count[fp.parity]) return;
+        const uint2 rec = sc.help_list[h];
+        blk = rec.x; slice = rec.y;
+        // a registration that found no room still advanced the counter: records behind it are stale.  A record is
+        // this frame's iff its block says so.
+        if (blk >= num_blocks || slice == 0u) return;
+        const uint32_t first = sc.help_slot[blk];
+        if (first == kEmitNoHelp || h - first + 1u != slice) return;
+        const uint32_t t = sc.block_sums[blk];
+        if (t <= kEmitSlice || slice > (t - 1u) / kEmitSlice) return;
+    }
+    const uint32_t g = blk * kProjThreads + tid;
     // every global read of the workgroup is issued up front (one memory latency instead of a chain);
     // extents/depth of splats that emit nothing are stale or uninitialised and never used
-    const uint32_t total = sc.block_sums[blockIdx.x];
+    const uint32_t total = sc.block_sums[blk];
     // a context with a subset of the tile rows has mostly empty workgroups (some never wrote their per-splat
     // arrays, see k_project): look at the total first there
     if (!owns_every_row(fp) && total == 0) return;
-    const uint32_t base = sc.block_offsets[blockIdx.x];
+    const uint32_t base = sc.block_offsets[blk];
+    // the owner of a heavy block whose helper records did not fit the list walks every slice itself
+    const bool alone = slice == 0u && total > kEmitSlice && sc.help_slot[blk] == kEmitNoHelp;
     const uint32_t cnt = g < n ? sc.tiles_touched[g] : 0u;
     const uint2 my_ext = g < n ? sc.extents[g] : make_uint2(0u, 0u);
     const uint32_t my_depth = g < n ? sc.depth_key[g] : 0u;
@@ -493,12 +532,14 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
     s_incl[tid] = wbase + inc;
     __syncthreads();
 
-    const uint32_t g0 = blockIdx.x * kProjThreads;
+    const uint32_t g0 = blk * kProjThreads;
     const uint32_t my_excl = s_incl[tid] - cnt;
+    const uint32_t c_begin = slice * kEmitSlice;
+    const uint32_t c_end = alone || total - c_begin < kEmitSlice ? total : c_begin + kEmitSlice;
     // Owner of every output element: the list is cut into chunks of kEmitChunk elements; each splat marks the
     // first element it owns inside the chunk with its index + 1 and a prefix maximum spreads the marks (splat
     // index grows with the start offset), instead of one 8-step binary search per element.
-    for (uint32_t c0 = 0; c0 < total; c0 += kEmitChunk) {
+    for (uint32_t c0 = c_begin; c0 < c_end; c0 += kEmitChunk) {
 #pragma unroll
         for (int k = 0; k < kEmitChunk / kProjThreads; ++k) s_owner[k * kProjThreads + tid] = 0u;
         __syncthreads();
@@ -572,15 +613,15 @@ void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParam
     const uint32_t n16_coarse = (uint32_t)(kMaxSortPasses * kBins * kCoarse) / 4u;
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, sc.block_sums,
                        sc.block_offsets, blocks, fp.capacity, params, reinterpret_cast<uint4*>(ranges), n16_ranges,
-                       reinterpret_cast<uint4*>(coarse), n16_coarse);
+                       reinterpret_cast<uint4*>(coarse), n16_coarse, sc.help_count + (fp.parity ^ 1u));
 }
 
 void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb,
                  hipStream_t stream) {
     const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(kProjThreads), 0, stream, fp, sc, sb.lo[0],
-                       sb.hi[0], sb.id[0]);
+    hipLaunchKernelGGL(k_emit, dim3(blocks + emit_helpers(fp.capacity)), dim3(kProjThreads), 0, stream, fp, sc, sb.lo[0],
+                       sb.hi[0], sb.id[0], blocks);
 }
 
 } // namespace gs
