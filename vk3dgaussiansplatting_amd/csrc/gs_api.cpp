@@ -6,6 +6,7 @@
 #include "../../include/gsplat.h"
 #include "gs_internal.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -113,6 +114,7 @@ void free_scene(gs_ctx* c) {
     free_dev(c->scratch.raster); free_dev(c->scratch.depth_key); free_dev(c->scratch.tiles_touched);
     free_dev(c->scratch.extents); free_dev(c->scratch.block_sums); free_dev(c->scratch.block_offsets);
     free_dev(c->scratch.help_list); free_dev(c->scratch.help_count); free_dev(c->scratch.help_slot);
+    free_dev(c->scratch.band_list);
     c->n = 0;
 }
 
@@ -185,9 +187,18 @@ FrameParams make_frame_params(const gs_ctx* c, const float* view, const float* p
     fp.tan_fov_y = (float)std::tan((double)(c->cfg.fov_y * 0.5f));   // Common.glsl:53, host-folded
     fp.hi16 = c->hi16 ? 1u : 0u;
     fp.parity = 0u;       // set by the InitSortList launch sites
-    fp.w_frob2 = 0.0f;
-    for (int col = 0; col < 3; ++col)
-        for (int row = 0; row < 3; ++row) fp.w_frob2 += view[col * 4 + row] * view[col * 4 + row];
+    // |W|_2^2 <= min(trace, largest absolute row sum) of M = W^T W (Gershgorin); exactly 1 (+ rounding) for a rigid view
+    double m[3][3], tr = 0.0, gersh = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            m[i][j] = 0.0;
+            for (int k = 0; k < 3; ++k) m[i][j] += (double)view[i * 4 + k] * (double)view[j * 4 + k];
+        }
+    for (int i = 0; i < 3; ++i) {
+        tr += m[i][i];
+        gersh = std::max(gersh, std::fabs(m[i][0]) + std::fabs(m[i][1]) + std::fabs(m[i][2]));
+    }
+    fp.w_norm2 = (float)(std::min(tr, gersh) * (1.0 + 1e-5));
     return fp;
 }
 
@@ -464,9 +475,10 @@ static int alloc_scratch(gs_ctx* c, uint32_t n) {
     HIP_TRY(c, hipMemsetAsync(c->scratch.block_offsets, 0, padded * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->scratch.raster, 0, N * sizeof(SplatRaster), c->stream));
     HIP_TRY(c, hipMalloc((void**)&c->scratch.help_list, (size_t)kEmitHelpCap * sizeof(uint2)));
-    HIP_TRY(c, hipMalloc((void**)&c->scratch.help_count, 2 * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.help_count, 4 * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.band_list, (size_t)c->num_blocks * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void**)&c->scratch.help_slot, (size_t)c->num_blocks * sizeof(uint32_t)));
-    HIP_TRY(c, hipMemsetAsync(c->scratch.help_count, 0, 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->scratch.help_count, 0, 4 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->scratch.help_list, 0, (size_t)kEmitHelpCap * sizeof(uint2), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->scratch.help_slot, 0xFF, (size_t)c->num_blocks * sizeof(uint32_t), c->stream));
     c->emit_parity = 0;

@@ -53,7 +53,8 @@ struct FrameParams {
     float ndc_cull, in_view_limit;
     float tan_fov_y;      // tan(FOV_Y*0.5f), folded on the host (Common.glsl:53)
     uint32_t hi16;        // sort list stores the compact tile ids as uint16 (at most 65535 owned tiles)
-    float w_frob2;        // squared Frobenius norm of the upper-left 3x3 of view (host-folded, for the band bound)
+    float w_norm2;        // upper bound on the squared spectral norm of the upper-left 3x3 of view (host-folded, for the
+                          // band bound; 1 for a rigid view matrix)
     uint32_t parity;      // InitSortList launches alternate between the two helper counters of SplatScratch
 };
 
@@ -104,10 +105,17 @@ struct SplatScratch {
     // k_emit load balance: a project workgroup whose 256 splats emit more than kEmitSlice elements registers one
     // helper record {block, slice} per further slice; k_emit runs them as extra workgroups.
     uint2* help_list;        // [kEmitHelpCap]
-    uint32_t* help_count;    // [2]: records registered this frame / cleared for the next one (FrameParams::parity)
+    uint32_t* help_count;    // [4]: [p] helper records registered by the InitSortList launch of parity p, [2 + p] its band
+                             // survivors (below); k_scan_blocks clears the pair of the next launch (FrameParams::parity)
     uint32_t* help_slot;     // [ceil(N/kProjThreads)]: first record of a heavy block, kEmitNoHelp if the list was full
+    // A context that owns a subset of the tile rows: the project blocks k_band_cull could not reject, in arrival order,
+    // block | skipped-waves mask << 28.
+    uint32_t* band_list;     // [ceil(N/kProjThreads)]
 };
-constexpr uint32_t kEmitSlice = 4096;      // output elements per k_emit workgroup (a multiple of its 1024-element round)
+#ifndef GS_EMIT_SLICE
+#define GS_EMIT_SLICE 4096
+#endif
+constexpr uint32_t kEmitSlice = GS_EMIT_SLICE;      // output elements per k_emit workgroup (a multiple of its 1024-element round)
 constexpr uint32_t kEmitHelpCap = 65536;   // enough for 2^28 elements; beyond that the owner workgroup does the rest itself
 constexpr uint32_t kEmitNoHelp = 0xFFFFFFFFu;
 // helper workgroups of a k_emit launch = records k_project may register: the slices after the first number at most

@@ -10,6 +10,7 @@
 // Arithmetic follows the reference expression by expression, left to right, with contraction off
 // (build flag -ffp-contract=off), IEEE division and sqrt: sort keys and tile extents are bit-exact
 // against oracle/gs_oracle.c.  Paths are relative to /root/reference/vkGaussianSplatting/Resources/Shaders/.
+#include <cstdlib>
 #include "gs_device_utils.h"
 #include "gs_internal.h"
 
@@ -171,14 +172,18 @@ __device__ __forceinline__ bool owns_every_row(const FrameParams& fp) {
 
 // Conservative bound on a splat's radius in pixels from its view-space position and the upload-time bound sig2 on the
 // largest eigenvalue of its 3-D covariance: radius = ceil(3 sqrt(lambda_max(Sigma'))) and lambda_max(Sigma') <=
-// |J|_F^2 |W|_F^2 lambda_max(Sigma) + 0.3, with J, W as in getCovarianceMatrix (Common.glsl:49-69; tx, ty = the clamped
-// x/z, y/z).  Widened by 2 % + 2 px.
+// |J|_2^2 |W|_2^2 lambda_max(Sigma) + 0.3, with J, W as in getCovarianceMatrix (Common.glsl:49-69; tx, ty = the clamped
+// x/z, y/z).  |J|_2^2 is the larger eigenvalue of J J^T = [[fx^2 (1 + tx^2), fx fy tx ty], [., fy^2 (1 + ty^2)]] / z^2,
+// |W|_2^2 comes from the host (1 for a rigid view matrix).  Spectral norms: with Frobenius norms the radius came out
+// up to 2.4 times too large and a 1/8 band kept a third of the blocks.  Widened by 2 % + 2 px.  Monotone in |tx|, |ty|,
+// 1 / |vz| and sig2, which the box test relies on.
 __device__ __forceinline__ float radius_bound(const FrameParams& fp, float tx, float ty, float vz, float sig2) {
     const float wdt = (float)fp.width, hgt = (float)fp.height;
     const float tfx = fp.tan_fov_y * wdt / hgt;
     const float fx = wdt / (2.0f * tfx), fy = hgt / (2.0f * fp.tan_fov_y);
-    const float j2 = (fx * fx * (1.0f + tx * tx) + fy * fy * (1.0f + ty * ty)) / (vz * vz);
-    const float lam = j2 * fp.w_frob2 * sig2 * 1.02f + 0.31f;
+    const float a = fx * fx * (1.0f + tx * tx), c = fy * fy * (1.0f + ty * ty), b = fx * fy * tx * ty;
+    const float j2 = (0.5f * (a + c) + sqrtf(0.25f * (a - c) * (a - c) + b * b)) / (vz * vz);
+    const float lam = j2 * fp.w_norm2 * sig2 * 1.02f + 0.31f;
     return 3.0f * sqrtf(lam) + 2.0f;
 }
 
@@ -196,9 +201,70 @@ __device__ __forceinline__ bool misses_owned_rows(const FrameParams& fp, float y
     return owned_rows_below(fp, y1) - owned_rows_below(fp, y0) <= 0;
 }
 
+// The box around 64 consecutive splat positions (b0 = min xyz, max x; b1 = max yz, largest sig2; from the upload --
+// the arrays are in Morton order, so it is small) against the owned tile rows.  If all eight corners are beyond the
+// near plane, every splat's screen y lies between the corners' extremes and its radius is below the bound taken at the
+// nearest corner depth; true when that range misses every owned row: none of the 64 splats emits anything.  A NaN /
+// infinite corner, or one at or behind the near plane, keeps the wave.
+__device__ __forceinline__ bool box_misses_owned_rows(const FrameParams& fp, const float4 b0, const float4 b1) {
+    const float hgt = (float)fp.height;
+    const float lim_x = fp.tan_fov_y * (float)fp.width / hgt * fp.in_view_limit, lim_y = fp.tan_fov_y * fp.in_view_limit;
+    float ymin = 3.0e38f, ymax = -3.0e38f, zmin = 3.0e38f, txm = 0.0f, tym = 0.0f;
+    bool in_front = true;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float vp[4], q[4];
+        mat4_mul_vec4(fp.view, (c & 1) ? b0.w : b0.x, (c & 2) ? b1.x : b0.y, (c & 4) ? b1.y : b0.z, 1.0f, vp);
+        mat4_mul_vec4(fp.proj, vp[0], vp[1], vp[2], vp[3], q);
+        const float depth = -vp[2];
+        const float sy = (1.0f - q[1] / q[3]) * 0.5f * hgt;
+        in_front = in_front && depth > fp.near_plane && q[3] > 0.0f && (sy - sy == 0.0f);
+        ymin = fminf(ymin, sy); ymax = fmaxf(ymax, sy); zmin = fminf(zmin, depth);
+        // x/z and y/z are monotone along any segment in front of the camera: their extremes over the box are at corners
+        txm = fmaxf(txm, fabsf(vp[0] / vp[2])); tym = fmaxf(tym, fabsf(vp[1] / vp[2]));
+    }
+    if (!in_front) return false;
+    txm = fminf(txm * 1.0001f, lim_x); tym = fminf(tym * 1.0001f, lim_y);        // the clamp of Common.glsl:60-61
+    const float rmax = radius_bound(fp, txm, tym, zmin, b1.z);
+    // 1 px of slack for the rounding of the corner projections against the per-splat ones
+    return misses_owned_rows(fp, ymin - rmax - 1.0f, ymax + rmax + 1.0f);
+}
+
+// First kernel of InitSortList in a context that owns a subset of the tile rows (multi-GPU): one THREAD per project
+// block tests the boxes of its four waves and appends the blocks that may emit to band_list (with the mask of the
+// waves that cannot), so that k_project runs over the survivors only.  A 1/8 band keeps 15-20 % of the blocks; testing
+// inside k_project cost a workgroup launch, a dependent load and a barrier per rejected block (22.8 k of them at
+// 5.8 M splats: 60 us of an 82 us launch).  A rejected block gets its zero block sum here and nothing else: k_emit
+// leaves on a zero sum before it reads anything per splat.
+__global__ __launch_bounds__(256) void k_band_cull(const FrameParams fp, const SceneBuffers scene, const SplatScratch sc,
+                                                   uint32_t num_blocks) {
+    static_assert(kProjThreads / 64 == 4, "four wave records per project block");
+    const uint32_t wrec = blockIdx.x * 256u + threadIdx.x;            // one thread per wave record, four per block
+    const uint32_t b = wrec >> 2;
+    const uint32_t n = fp.num_gaussians;
+    bool skip = true;                                                 // a wave past the last splat
+    if (b < num_blocks && (uint64_t)wrec * 64u < n) {
+        const float4 b0 = reinterpret_cast<const float4*>(scene.block_bounds)[(size_t)wrec * 2 + 0];
+        const float4 b1 = reinterpret_cast<const float4*>(scene.block_bounds)[(size_t)wrec * 2 + 1];
+        skip = box_misses_owned_rows(fp, b0, b1);
+    }
+    const int lane = lane_id();
+    const uint32_t mask = (uint32_t)(__ballot(skip) >> (lane & ~3)) & 0xFu;     // the four waves of my block
+    const bool leader = (lane & 3) == 0 && b < num_blocks;
+    const bool survives = leader && mask != 0xFu;
+    if (leader && !survives) sc.block_sums[b] = 0u;
+    const uint64_t vote = __ballot(survives);
+    if (vote == 0ull) return;
+    const int first = (int)__builtin_ctzll(vote);
+    uint32_t base = 0u;
+    if (lane == first) base = atomicAdd(&sc.help_count[2u + fp.parity], (uint32_t)__builtin_popcountll(vote));
+    base = __shfl(base, first, 64);
+    if (survives) sc.band_list[base + (uint32_t)__builtin_popcountll(vote & ((1ull << lane) - 1ull))] = b | (mask << 28);
+}
+
 __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
                                                            const SceneBuffers scene,
-                                                           const SplatScratch sc) {
+                                                           const SplatScratch sc, const uint32_t num_blocks) {
     __shared__ uint32_t s_wave_sum[kProjThreads / 64];
     __shared__ uint32_t s_wave_emits[kProjThreads / 64];
     // The 48-byte raster records of the workgroup's 256 splats are staged here and written out as one
@@ -206,48 +272,23 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
     // as 32-byte partial writes (WRITE_SIZE 355 MB per frame against 219 MB of payload, config C).
     __shared__ float4 s_raster[kProjThreads * 3];
     const uint32_t n = fp.num_gaussians;
-    const uint32_t g = blockIdx.x * kProjThreads + threadIdx.x;
+    const bool band = !owns_every_row(fp);
+    // One workgroup per block of 256 splats; a context that owns a subset of the tile rows walks the blocks k_band_cull
+    // kept (fewer workgroups than blocks, a loop) and skips the waves it marked: only zero tile counts are written for
+    // their splats (k_emit reads the counts of a workgroup that emits anything); RenderGaussians never sees their records.
+    const bool listed = band && fp.row_stride == 1u;    // interleaved rows: every block reaches some owned row
+    const uint32_t work = listed ? sc.help_count[2u + fp.parity] : num_blocks;
+    for (uint32_t item = blockIdx.x; item < work; item += gridDim.x) {
+    uint32_t blk = item;
+    bool wave_skip = false;
+    if (listed) {
+        const uint32_t rec = sc.band_list[item];
+        blk = rec & 0x0FFFFFFFu;
+        wave_skip = ((rec >> 28) >> wave_id()) & 1u;
+    }
+    const uint32_t g = blk * kProjThreads + threadIdx.x;
     uint32_t count = 0;
     float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0;   // culled splats: zero record
-    const bool band = !owns_every_row(fp);
-
-    // A context that owns a subset of the tile rows first tests each wave as a whole: the box around its 64 splat
-    // positions (the arrays are in Morton order, so it is small) and their largest sig2, from the upload.  Lanes 0..7
-    // project one corner each.  If all eight corners are beyond the near plane, every splat's screen y lies between
-    // the corners' extremes and its radius is below the bound taken at the nearest corner depth; when that range
-    // misses every owned row the wave emits nothing: one 32-byte read instead of 64 positions (and everything after).
-    // Only zero tile counts are written for its splats (k_emit reads the counts of a workgroup that emits anything);
-    // RenderGaussians never sees their records.
-    bool wave_skip = false;
-    if (band) {
-        const uint32_t wrec = blockIdx.x * (kProjThreads / 64) + (uint32_t)wave_id();
-        const int c = lane_id() & 7;
-        const float4 b0 = reinterpret_cast<const float4*>(scene.block_bounds)[wrec * 2 + 0];
-        const float4 b1 = reinterpret_cast<const float4*>(scene.block_bounds)[wrec * 2 + 1];
-        const float hgt = (float)fp.height;
-        const float tfx = fp.tan_fov_y * (float)fp.width / hgt;
-        float vp[4], q[4];
-        mat4_mul_vec4(fp.view, (c & 1) ? b0.w : b0.x, (c & 2) ? b1.x : b0.y, (c & 4) ? b1.y : b0.z, 1.0f, vp);
-        mat4_mul_vec4(fp.proj, vp[0], vp[1], vp[2], vp[3], q);
-        const float depth = -vp[2];
-        const float sy = (1.0f - q[1] / q[3]) * 0.5f * hgt;
-        // a NaN / infinite corner, or one at or behind the near plane, keeps the wave
-        const bool corner_ok = depth > fp.near_plane && q[3] > 0.0f && (sy - sy == 0.0f);
-        float ymin = sy, ymax = sy, zmin = depth;
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
-            ymin = fminf(ymin, __shfl_xor(ymin, off, 64));
-            ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
-            zmin = fminf(zmin, __shfl_xor(zmin, off, 64));
-        }
-        const bool in_front = (__ballot(corner_ok) & 0xFFull) == 0xFFull;
-        if (in_front) {
-            const float rmax = radius_bound(fp, tfx * fp.in_view_limit, fp.tan_fov_y * fp.in_view_limit, zmin, b1.z);
-            // 1 px of slack for the rounding of the corner projections against the per-splat ones
-            wave_skip = misses_owned_rows(fp, ymin - rmax - 1.0f, ymax + rmax + 1.0f);
-        }
-        wave_skip = __builtin_amdgcn_readfirstlane((int)wave_skip) != 0;   // lanes 0..7 agree; make it wave-uniform
-    }
 
     if (g < n && !wave_skip) {
         const float px = scene.pos[g], py = scene.pos[(size_t)n + g], pz = scene.pos[2 * (size_t)n + g];
@@ -382,7 +423,7 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
     }
     __syncthreads();
     {
-        const uint32_t first = blockIdx.x * kProjThreads;
+        const uint32_t first = blk * kProjThreads;
         const uint32_t valid = (n - first) < (uint32_t)kProjThreads ? (n - first) : (uint32_t)kProjThreads;
         float4* out = reinterpret_cast<float4*>(sc.raster + first);
 #pragma unroll
@@ -394,7 +435,7 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
     uint32_t t = 0;
 #pragma unroll
     for (int w = 0; w < kProjThreads / 64; ++w) t += s_wave_sum[w];
-    if (threadIdx.x == 0) sc.block_sums[blockIdx.x] = t;
+    if (threadIdx.x == 0) sc.block_sums[blk] = t;
     // k_emit walks a workgroup's output range kEmitSlice elements per workgroup: a block that emits more (a few
     // hundred near splats hold half of a tile-row band's elements) registers the slices after the first as helper
     // records.  The order of the records depends on atomic arrival; what each one writes does not.
@@ -405,13 +446,15 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
             uint32_t slot = atomicAdd(&sc.help_count[fp.parity], extra);
             // no room (only when the element count overflows the list capacity): the owner does every slice
             if ((uint64_t)slot + extra > (uint64_t)emit_helpers(fp.capacity)) slot = kEmitNoHelp;
-            sc.help_slot[blockIdx.x] = slot;
+            sc.help_slot[blk] = slot;
             s_slot = slot;
         }
         __syncthreads();
         const uint32_t slot = s_slot;
         if (slot != kEmitNoHelp)
-            for (uint32_t i = threadIdx.x; i < extra; i += kProjThreads) sc.help_list[slot + i] = make_uint2(blockIdx.x, i + 1u);
+            for (uint32_t i = threadIdx.x; i < extra; i += kProjThreads) sc.help_list[slot + i] = make_uint2(blk, i + 1u);
+    }
+    __syncthreads();   // the LDS staging is reused by the next block
     }
 }
 
@@ -427,7 +470,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict
                                                        SortParams* params, uint4* __restrict__ zero_a, uint32_t n16_a,
                                                        uint4* __restrict__ zero_b, uint32_t n16_b,
                                                        uint32_t* __restrict__ next_help_count) {
-    if (threadIdx.x == 0) *next_help_count = 0u;     // the helper counter the NEXT InitSortList launch adds to
+    if (threadIdx.x == 0) { next_help_count[0] = 0u; next_help_count[2] = 0u; }   // what the NEXT InitSortList launch adds to
     for (uint32_t i = threadIdx.x; i < n16_a; i += 1024u) zero_a[i] = make_uint4(0u, 0u, 0u, 0u);
     for (uint32_t i = threadIdx.x; i < n16_b; i += 1024u) zero_b[i] = make_uint4(0u, 0u, 0u, 0u);
     __shared__ uint64_t s_wave_tot[16];
@@ -598,11 +641,17 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
     }
 }
 
+constexpr uint32_t kBandProjectGrid = 4096;   // workgroups of k_project in a context with a subset of the tile rows
+
 void launch_project(const FrameParams& fp, const SceneBuffers& scene, const SplatScratch& sc,
                     hipStream_t stream) {
     const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_project, dim3(blocks), dim3(kProjThreads), 0, stream, fp, scene, sc);
+    const bool listed = !(fp.row_begin == 0u && fp.row_end == fp.grid_h) && fp.row_stride == 1u;   // a contiguous band
+    if (listed) hipLaunchKernelGGL(k_band_cull, dim3((blocks * 4u + 255u) / 256u), dim3(256), 0, stream, fp, scene, sc, blocks);
+    static const uint32_t band_grid = [] { const char* e = getenv("GS_BAND_GRID"); return e ? (uint32_t)atoi(e) : kBandProjectGrid; }();
+    const uint32_t grid = listed && band_grid && blocks > band_grid ? band_grid : blocks;
+    hipLaunchKernelGGL(k_project, dim3(grid), dim3(kProjThreads), 0, stream, fp, scene, sc, blocks);
 }
 
 void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParams* params,

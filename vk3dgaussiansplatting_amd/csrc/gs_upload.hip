@@ -30,18 +30,28 @@ __global__ __launch_bounds__(256) void k_aos_to_soa(const float* __restrict__ ch
             } else s.opacity[g] = tile[r][12 + 3];
         }
         if (part == 3u) {
-            // |R|_F^2 * max(scale)^2 >= largest eigenvalue of Sigma = (R S)(R S)^T, with R as Common.glsl:17-30
+            // |R|_2^2 * max(scale)^2 >= largest eigenvalue of Sigma = (R S)(R S)^T, with R as Common.glsl:17-30
             // builds it from the (not necessarily unit) quaternion
             const float q0 = tile[r][8], x = tile[r][9], y = tile[r][10], z = tile[r][11];
             const float e[9] = {1.0f - 2.0f * y * y - 2.0f * z * z, 2.0f * x * y - 2.0f * q0 * z, 2.0f * x * z + 2.0f * q0 * y,
                                 2.0f * x * y + 2.0f * q0 * z, 1.0f - 2.0f * x * x - 2.0f * z * z, 2.0f * y * z - 2.0f * q0 * x,
                                 2.0f * x * z - 2.0f * q0 * y, 2.0f * y * z + 2.0f * q0 * x, 1.0f - 2.0f * x * x - 2.0f * y * y};
-            float f2 = 0.0f;
+            // |R|_2^2 <= min(trace, largest absolute row sum) of R R^T (Gershgorin): 1 for a unit quaternion, where the
+            // Frobenius norm alone says 3
+            float f2 = 0.0f, gersh = 0.0f;
 #pragma unroll
             for (int k = 0; k < 9; ++k) f2 += e[k] * e[k];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float row = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) row += fabsf(e[3 * i] * e[3 * j] + e[3 * i + 1] * e[3 * j + 1] + e[3 * i + 2] * e[3 * j + 2]);
+                gersh = fmaxf(gersh, row);
+            }
+            const float r2 = (gersh < f2 ? gersh : f2) * 1.0001f;      // a NaN takes f2, NaN again: the splat is kept
             const float s0 = fabsf(tile[r][4]), s1 = fabsf(tile[r][5]), s2 = fabsf(tile[r][6]);
             const float sm = fmaxf(s0, fmaxf(s1, s2));
-            s.sig2[g] = f2 * sm * sm;
+            s.sig2[g] = r2 * sm * sm;
         }
     }
 }
