@@ -262,7 +262,12 @@ __global__ __launch_bounds__(256) void k_band_cull(const FrameParams fp, const S
     if (survives) sc.band_list[base + (uint32_t)__builtin_popcountll(vote & ((1ull << lane) - 1ull))] = b | (mask << 28);
 }
 
-__global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
+// Seven workgroups per CU: left to itself the compiler hoists the 48 SH loads and takes 117 VGPRs (four waves per SIMD);
+// held to 72 it needs 65 without spilling, and the launch is 30 us shorter at config C (209 against 239 us).
+#ifndef GS_PROJECT_MINBLOCKS
+#define GS_PROJECT_MINBLOCKS 7
+#endif
+__global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(const FrameParams fp,
                                                            const SceneBuffers scene,
                                                            const SplatScratch sc, const uint32_t num_blocks) {
     __shared__ uint32_t s_wave_sum[kProjThreads / 64];
@@ -273,16 +278,16 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
     __shared__ float4 s_raster[kProjThreads * 3];
     const uint32_t n = fp.num_gaussians;
     const bool band = !owns_every_row(fp);
-    // One workgroup per block of 256 splats; a context that owns a subset of the tile rows walks the blocks k_band_cull
-    // kept (fewer workgroups than blocks, a loop) and skips the waves it marked: only zero tile counts are written for
-    // their splats (k_emit reads the counts of a workgroup that emits anything); RenderGaussians never sees their records.
+    // One workgroup per block of 256 splats.  A contiguous band of tile rows: workgroup i takes the i-th block k_band_cull
+    // kept (those beyond the count leave at once) and skips the waves it marked: only zero tile counts are written for
+    // their splats (k_emit reads the counts of a workgroup that emits anything); RenderGaussians never sees their
+    // records.  No loop over blocks here: as a loop body the kernel took 115 VGPRs instead of 65.
     const bool listed = band && fp.row_stride == 1u;    // interleaved rows: every block reaches some owned row
-    const uint32_t work = listed ? sc.help_count[2u + fp.parity] : num_blocks;
-    for (uint32_t item = blockIdx.x; item < work; item += gridDim.x) {
-    uint32_t blk = item;
+    uint32_t blk = blockIdx.x;
     bool wave_skip = false;
     if (listed) {
-        const uint32_t rec = sc.band_list[item];
+        if (blk >= sc.help_count[2u + fp.parity]) return;
+        const uint32_t rec = sc.band_list[blk];
         blk = rec & 0x0FFFFFFFu;
         wave_skip = ((rec >> 28) >> wave_id()) & 1u;
     }
@@ -454,8 +459,6 @@ __global__ __launch_bounds__(kProjThreads) void k_project(const FrameParams fp,
         if (slot != kEmitNoHelp)
             for (uint32_t i = threadIdx.x; i < extra; i += kProjThreads) sc.help_list[slot + i] = make_uint2(blk, i + 1u);
     }
-    __syncthreads();   // the LDS staging is reused by the next block
-    }
 }
 
 // One workgroup of 1024 threads: exclusive scan of block_sums (u64 running total so an overflowing
@@ -517,9 +520,9 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict
 // Emit: the splats [b*256, b*256+256) of project workgroup b own the output elements
 // [block_offsets[b], +block_sums[b]).  Threads walk the OUTPUT range (coalesced stores); which splat
 // owns an element is resolved per chunk in LDS from the scan of the 256 tile counts (see the loop).
-// Workgroup b < num_blocks takes the first kEmitSlice elements of block b; the further slices of heavy blocks are
-// the helper records k_project registered, run by the workgroups >= num_blocks of the same launch (those beyond the
-// record count leave at once).  Without that split the launch lasted as long as its heaviest block: at 3840x2160 one
+// The owner workgroup of block b takes its first kEmitSlice elements; the further slices of heavy blocks are the helper
+// records k_project registered, run by the first `helpers` workgroups of the same launch (those beyond the record
+// count leave at once).  Without that split the launch lasted as long as its heaviest block: at 3840x2160 one
 // block of near splats emits 105 k elements (102 rounds), and in a 1/8 tile-row band 186 blocks hold 55 % of the list.
 constexpr int kEmitChunk = 4 * kProjThreads;   // output elements resolved per round of k_emit
 static_assert(kEmitSlice % kEmitChunk == 0, "a slice is a whole number of rounds");
@@ -527,7 +530,8 @@ static_assert(kEmitSlice % kEmitChunk == 0, "a slice is a whole number of rounds
 __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, const SplatScratch sc,
                                                         uint32_t* __restrict__ out_lo,
                                                         uint32_t* __restrict__ out_hi,
-                                                        uint32_t* __restrict__ out_id, uint32_t num_blocks) {
+                                                        uint32_t* __restrict__ out_id, uint32_t num_blocks,
+                                                        uint32_t helpers) {
     __shared__ uint32_t s_incl[kProjThreads];   // inclusive scan of tile counts
     __shared__ uint32_t s_wave_tot[kProjThreads / 64];
     __shared__ uint2 s_ext[kProjThreads];
@@ -536,9 +540,11 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
     __shared__ uint32_t s_wmax[kProjThreads / 64];
     const uint32_t n = fp.num_gaussians;
     const int tid = threadIdx.x;
-    uint32_t blk = blockIdx.x, slice = 0u;
-    if (blk >= num_blocks) {                               // helper workgroup
-        const uint32_t h = blk - num_blocks;
+    // the helper workgroups come FIRST in the launch: the slices of the heaviest blocks start with the launch, and the
+    // workgroups without a record are gone before the owners arrive
+    uint32_t blk = blockIdx.x - helpers, slice = 0u;
+    if (blockIdx.x < helpers) {
+        const uint32_t h = blockIdx.x;
         if (h >= sc.help_count[fp.parity]) return;
         const uint2 rec = sc.help_list[h];
         blk = rec.x; slice = rec.y;
@@ -641,17 +647,13 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
     }
 }
 
-constexpr uint32_t kBandProjectGrid = 4096;   // workgroups of k_project in a context with a subset of the tile rows
-
 void launch_project(const FrameParams& fp, const SceneBuffers& scene, const SplatScratch& sc,
                     hipStream_t stream) {
     const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
     if (blocks == 0) return;
     const bool listed = !(fp.row_begin == 0u && fp.row_end == fp.grid_h) && fp.row_stride == 1u;   // a contiguous band
     if (listed) hipLaunchKernelGGL(k_band_cull, dim3((blocks * 4u + 255u) / 256u), dim3(256), 0, stream, fp, scene, sc, blocks);
-    static const uint32_t band_grid = [] { const char* e = getenv("GS_BAND_GRID"); return e ? (uint32_t)atoi(e) : kBandProjectGrid; }();
-    const uint32_t grid = listed && band_grid && blocks > band_grid ? band_grid : blocks;
-    hipLaunchKernelGGL(k_project, dim3(grid), dim3(kProjThreads), 0, stream, fp, scene, sc, blocks);
+    hipLaunchKernelGGL(k_project, dim3(blocks), dim3(kProjThreads), 0, stream, fp, scene, sc, blocks);
 }
 
 void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParams* params,
@@ -669,8 +671,9 @@ void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffer
                  hipStream_t stream) {
     const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_emit, dim3(blocks + emit_helpers(fp.capacity)), dim3(kProjThreads), 0, stream, fp, sc, sb.lo[0],
-                       sb.hi[0], sb.id[0], blocks);
+    const uint32_t helpers = emit_helpers(fp.capacity);
+    hipLaunchKernelGGL(k_emit, dim3(helpers + blocks), dim3(kProjThreads), 0, stream, fp, sc, sb.lo[0],
+                       sb.hi[0], sb.id[0], blocks, helpers);
 }
 
 } // namespace gs
