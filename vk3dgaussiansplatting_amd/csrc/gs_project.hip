@@ -217,11 +217,13 @@ __device__ __forceinline__ bool box_misses_owned_rows(const FrameParams& fp, con
         mat4_mul_vec4(fp.view, (c & 1) ? b0.w : b0.x, (c & 2) ? b1.x : b0.y, (c & 4) ? b1.y : b0.z, 1.0f, vp);
         mat4_mul_vec4(fp.proj, vp[0], vp[1], vp[2], vp[3], q);
         const float depth = -vp[2];
-        const float sy = (1.0f - q[1] / q[3]) * 0.5f * hgt;
+        // hardware reciprocals (1 ulp): far inside the 1 px / 0.01 % slack below
+        const float sy = (1.0f - q[1] * __builtin_amdgcn_rcpf(q[3])) * 0.5f * hgt;
         in_front = in_front && depth > fp.near_plane && q[3] > 0.0f && (sy - sy == 0.0f);
         ymin = fminf(ymin, sy); ymax = fmaxf(ymax, sy); zmin = fminf(zmin, depth);
         // x/z and y/z are monotone along any segment in front of the camera: their extremes over the box are at corners
-        txm = fmaxf(txm, fabsf(vp[0] / vp[2])); tym = fmaxf(tym, fabsf(vp[1] / vp[2]));
+        const float rz = __builtin_amdgcn_rcpf(vp[2]);
+        txm = fmaxf(txm, fabsf(vp[0] * rz)); tym = fmaxf(tym, fabsf(vp[1] * rz));
     }
     if (!in_front) return false;
     txm = fminf(txm * 1.0001f, lim_x); tym = fminf(tym * 1.0001f, lim_y);        // the clamp of Common.glsl:60-61
@@ -236,10 +238,13 @@ __device__ __forceinline__ bool box_misses_owned_rows(const FrameParams& fp, con
 // inside k_project cost a workgroup launch, a dependent load and a barrier per rejected block (22.8 k of them at
 // 5.8 M splats: 60 us of an 82 us launch).  A rejected block gets its zero block sum here and nothing else: k_emit
 // leaves on a zero sum before it reads anything per splat.
-__global__ __launch_bounds__(256) void k_band_cull(const FrameParams fp, const SceneBuffers scene, const SplatScratch sc,
-                                                   uint32_t num_blocks) {
+constexpr int kCullThreads = 256;
+__global__ __launch_bounds__(kCullThreads) void k_band_cull(const FrameParams fp, const SceneBuffers scene, const SplatScratch sc,
+                                                            uint32_t num_blocks) {
     static_assert(kProjThreads / 64 == 4, "four wave records per project block");
-    const uint32_t wrec = blockIdx.x * 256u + threadIdx.x;            // one thread per wave record, four per block
+    __shared__ uint32_t s_cnt[kCullThreads / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t wrec = blockIdx.x * (uint32_t)kCullThreads + threadIdx.x;   // one thread per wave record, four per block
     const uint32_t b = wrec >> 2;
     const uint32_t n = fp.num_gaussians;
     bool skip = true;                                                 // a wave past the last splat
@@ -248,18 +253,27 @@ __global__ __launch_bounds__(256) void k_band_cull(const FrameParams fp, const S
         const float4 b1 = reinterpret_cast<const float4*>(scene.block_bounds)[(size_t)wrec * 2 + 1];
         skip = box_misses_owned_rows(fp, b0, b1);
     }
-    const int lane = lane_id();
+    const int lane = lane_id(), wave = wave_id();
     const uint32_t mask = (uint32_t)(__ballot(skip) >> (lane & ~3)) & 0xFu;     // the four waves of my block
     const bool leader = (lane & 3) == 0 && b < num_blocks;
     const bool survives = leader && mask != 0xFu;
     if (leader && !survives) sc.block_sums[b] = 0u;
+    // one returning atomic per workgroup (on one address they complete at about 90 per microsecond)
     const uint64_t vote = __ballot(survives);
-    if (vote == 0ull) return;
-    const int first = (int)__builtin_ctzll(vote);
-    uint32_t base = 0u;
-    if (lane == first) base = atomicAdd(&sc.help_count[2u + fp.parity], (uint32_t)__builtin_popcountll(vote));
-    base = __shfl(base, first, 64);
-    if (survives) sc.band_list[base + (uint32_t)__builtin_popcountll(vote & ((1ull << lane) - 1ull))] = b | (mask << 28);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__builtin_popcountll(vote);
+    __syncthreads();
+    uint32_t before = 0u, total = 0u;
+#pragma unroll
+    for (int w = 0; w < kCullThreads / 64; ++w) {
+        const uint32_t c = s_cnt[w];
+        before += w < wave ? c : 0u;
+        total += c;
+    }
+    if (total == 0u) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&sc.help_count[2u + fp.parity], total);
+    __syncthreads();
+    if (survives)
+        sc.band_list[s_base + before + (uint32_t)__builtin_popcountll(vote & ((1ull << lane) - 1ull))] = b | (mask << 28);
 }
 
 // Seven workgroups per CU: left to itself the compiler hoists the 48 SH loads and takes 117 VGPRs (four waves per SIMD);
@@ -652,7 +666,8 @@ void launch_project(const FrameParams& fp, const SceneBuffers& scene, const Spla
     const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
     if (blocks == 0) return;
     const bool listed = !(fp.row_begin == 0u && fp.row_end == fp.grid_h) && fp.row_stride == 1u;   // a contiguous band
-    if (listed) hipLaunchKernelGGL(k_band_cull, dim3((blocks * 4u + 255u) / 256u), dim3(256), 0, stream, fp, scene, sc, blocks);
+    if (listed) hipLaunchKernelGGL(k_band_cull, dim3((blocks * 4u + (uint32_t)kCullThreads - 1u) / (uint32_t)kCullThreads), dim3(kCullThreads), 0, stream,
+                                   fp, scene, sc, blocks);
     hipLaunchKernelGGL(k_project, dim3(blocks), dim3(kProjThreads), 0, stream, fp, scene, sc, blocks);
 }
 
