@@ -51,8 +51,10 @@ def parse_args(argv=None):
                     help="default: C (the headline shape) on one GPU, D (the 4K frame BASELINE.json names for the "
                          "tile-row shard) on several")
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
-    ap.add_argument("--sort", default="radix4", choices=["radix4", "bucket"],
-                    help="radix4 = the contractual nine-stage sort (default); bucket = GS_SORT_TILE_BUCKET")
+    ap.add_argument("--sort", default="radix4", choices=["radix4", "bucket", "splat_first"],
+                    help="radix4 = the contractual nine-stage sort (default); bucket = GS_SORT_TILE_BUCKET; "
+                         "splat_first = GS_SORT_RADIX4_SPLAT_FIRST (the same twelve 4-bit passes, the depth ones before "
+                         "the splats are replicated into tiles)")
     ap.add_argument("--render-kernel", default="auto", choices=["auto", "1", "2", "4", "16"],
                     help="gs_config.render_kernel: auto, 1/2/4 = px per lane with independent waves, 16 = workgroup per tile")
     ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2, 3],
@@ -217,7 +219,7 @@ def main():
     cam.setRotation(0.0, 0.0)
     cam.recalculate()
     mode = gs.GS_RENDER_EXACT if args.mode == "exact" else gs.GS_RENDER_FAST
-    sort_ids = {"radix4": gs.GS_SORT_RADIX4, "bucket": gs.GS_SORT_TILE_BUCKET}
+    sort_ids = {"radix4": gs.GS_SORT_RADIX4, "bucket": gs.GS_SORT_TILE_BUCKET, "splat_first": gs.GS_SORT_RADIX4_SPLAT_FIRST}
     interleaved = args.rows == "interleaved" and world > 1
 
     def make(record, sort=None, share=None, render_mode=None):
@@ -393,6 +395,19 @@ def main():
         extras["alt_sorter"] = {"sort_algorithm": other, "ms_per_step": round(ms_a, 4), "value": round(n / ms_a / 1000.0, 2),
                                 "note": "GS_SORT_TILE_BUCKET = tile-word radix passes + per-tile LDS depth sort behind the "
                                         "GpuSort seam; bit-identical output; one frame slot"}
+        if args.sort != "splat_first":
+            rs_ = Ring(1, sort="splat_first", owner=owner)
+            ms_s = rs_.timed(min(args.steps, 300), 20)
+            same = bool(torch.equal(rs_.sf.strips[0], sf_main.strips[0]))
+            rs_.close()
+            extras["splat_first_sorter"] = {
+                "sort_algorithm": "splat_first", "ms_per_step": round(ms_s, 4), "value": round(n / ms_s / 1000.0, 2),
+                "image_identical_to_default": same,
+                "note": "GS_SORT_RADIX4_SPLAT_FIRST = the same twelve 4-bit Count/Scan/Scatter passes in another order: the "
+                        "eight passes over the depth word run on the (depth, splat) list of the emitting splats, "
+                        "InitSortList's emit walks that list, the four stable tile-word passes finish; bit-identical "
+                        "keys, ranges and pixels; one frame slot.  Not the default: the default keeps the reference's "
+                        "stage order (InitSortList, then all passes over the 64-bit keys)"}
         if args.mode == "exact":
             rf_ = Ring(1, owner=owner, render_mode=gs.GS_RENDER_FAST)
             ms_f = rf_.timed(min(args.steps, 300), 20)

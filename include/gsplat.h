@@ -48,6 +48,12 @@ extern "C" {
 #define GS_SORT_RADIX4 0u       /* the contractual nine-stage 4-bit LSD radix sort over all key bits (default) */
 #define GS_SORT_TILE_BUCKET 1u  /* alternative back-end, identical output: the global 4-bit passes sort by the tile word
                                    only, then every tile's run is depth-sorted inside LDS (csrc/gs_tilesort.hip) */
+#define GS_SORT_RADIX4_SPLAT_FIRST 2u /* the same twelve 4-bit passes in another order, identical output: the depth word
+                                     of a key is a property of the SPLAT, so the eight passes over it run on the
+                                     (depth, splat) list of the emitting splats BEFORE a splat is replicated into its
+                                     tiles; InitSortList's emit then walks the splats in depth order and the four
+                                     tile-word passes -- stable -- finish the order by (tile, depth).  Moves a third of
+                                     the bytes.  Not the default: the default keeps the reference's stage order. */
 
 /* render arithmetic */
 #define GS_RENDER_EXACT 0u      /* bit-identical to the CPU oracle (no contraction, pinned exp) */

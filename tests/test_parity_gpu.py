@@ -30,6 +30,9 @@ def make_scene(aos, w, h, pos=(0.0, 0.0, 0.0), yaw=0.0, pitch=0.0, sh_mode=0):
     return sc
 
 
+ALL_SORTS = (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET, gs.GS_SORT_RADIX4_SPLAT_FIRST)
+
+
 def make_renderer(sc, w, h, mode=gs.GS_RENDER_EXACT, sort=gs.GS_SORT_RADIX4, kernel=gs.GS_RENDER_KERNEL_AUTO):
     r = gs.Renderer(w, h, render_mode=mode, warmup_frames=0, sort_algorithm=sort, render_kernel=kernel)
     r.init(sc.getResourceManager())
@@ -214,7 +217,7 @@ def test_empty_view_and_single_splat(oracle_mod, small_cloud):
     r.cleanup()
 
 
-@pytest.mark.parametrize("sort", [gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET])
+@pytest.mark.parametrize("sort", ALL_SORTS)
 def test_overflow_truncates_like_reference(oracle_mod, sort):
     """E > C: elements past the capacity are dropped (InitSortList.comp:140-148), status is a warning."""
     w, h = 320, 180
@@ -379,13 +382,13 @@ def full_size_parity(oracle_mod, name, sorts, capacity, sort_bits, pixel_tile_ro
 def test_config_b_full_frame(oracle_mod):
     """BASELINE config B (Train-7k shape: 559,263 gaussians @ 1280x720, E = 3.48 M), both sort back-ends: keys, ranges
     and EVERY pixel of the frame bit-exact (README.md:76)."""
-    full_size_parity(oracle_mod, "B", (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET), 2**23, 44, e_readme=3_487_911)
+    full_size_parity(oracle_mod, "B", ALL_SORTS, 2**23, 44, e_readme=3_487_911)
 
 
 def test_config_c_full_frame(oracle_mod):
     """BASELINE config C, the headline (Garden-30k shape: 5,834,784 gaussians @ 1920x1080, E = 13.1 M, README.md:61):
     keys, ranges and all 1920x1080 pixels bit-exact, both sort back-ends."""
-    full_size_parity(oracle_mod, "C", (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET), 2**24, 48, e_readme=13_098_506)
+    full_size_parity(oracle_mod, "C", ALL_SORTS, 2**24, 48, e_readme=13_098_506)
 
 
 def test_config_c_hard_full_frame(oracle_mod):
@@ -393,13 +396,13 @@ def test_config_c_hard_full_frame(oracle_mod):
     needle / disc splats, a few dozen screen-filling ones, opacities near 1; tile lists from 29 to 24,063 entries):
     keys, ranges and all 1920x1080 pixels bit-exact, both sort back-ends -- long and short per-tile runs, early
     saturation, splats that cover every tile."""
-    full_size_parity(oracle_mod, "Chard", (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET), 2**24, 48, e_readme=13_098_506)
+    full_size_parity(oracle_mod, "Chard", ALL_SORTS, 2**24, 48, e_readme=13_098_506)
 
 
 def test_config_d_4k_full_frame(oracle_mod):
     """BASELINE config D shape (Garden-30k @ 3840x2160, 32,400 tiles, E = 33 M): keys, ranges and all 3840x2160
     pixels bit-exact, both sort back-ends."""
-    full_size_parity(oracle_mod, "D", (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET), 2**26, 48)
+    full_size_parity(oracle_mod, "D", ALL_SORTS, 2**26, 48)
 
 
 def test_config_e_full_size(oracle_mod):
@@ -407,7 +410,7 @@ def test_config_e_full_size(oracle_mod):
     k_project / k_emit at N = 5e7 and the 64-bit element counter; counter, keys, payload order, ranges bit-exact,
     pixels bit-exact on six tile rows spread over the frame (a full-frame CPU blend of 6.5 k-entry tile lists
     would take minutes)."""
-    e = full_size_parity(oracle_mod, "E", (gs.GS_SORT_RADIX4,), 2**26, 48, pixel_tile_rows=(0, 13, 27, 34, 50, 67))
+    e = full_size_parity(oracle_mod, "E", (gs.GS_SORT_RADIX4, gs.GS_SORT_RADIX4_SPLAT_FIRST), 2**26, 48, pixel_tile_rows=(0, 13, 27, 34, 50, 67))
     assert e > 50_000_000
 
 
@@ -421,7 +424,7 @@ def test_extreme_but_finite_inputs(oracle_mod):
     sc = make_scene(aos, w, h)
     _, ref = oracle_run(oracle_mod, sc, w, h)
     assert np.isfinite(ref["stage1"]["cov"]).all() and np.isfinite(ref["stage1"]["color"]).all()
-    for sort in (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET):
+    for sort in ALL_SORTS:
         r = make_renderer(sc, w, h, sort=sort)
         img = r.draw(sc)
         assert_frame_equals_oracle(r, img, ref)
@@ -709,7 +712,7 @@ def test_shared_scene_frames_in_flight(oracle_mod, small_cloud):
     slots[2].cleanup()
 
 
-@pytest.mark.parametrize("sort", [gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET])
+@pytest.mark.parametrize("sort", ALL_SORTS)
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_interleaved_tile_rows(oracle_mod, small_cloud, world, sort):
     """gs_set_tile_rows_interleaved: rank r of R renders tile rows r, r + R, ...  Its sorted list is the full frame's
@@ -786,7 +789,7 @@ def test_band_exceeding_the_launch_estimate(oracle_mod):
     _, band = oracle_run(oracle_mod, sc, w, h, row_begin=11, row_end=12)
     e = band["e"]
     assert e > (512 * 2 // 23 + 64) * 2048, "the band does not exceed the launch estimate"
-    for sort in (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET):
+    for sort in ALL_SORTS:
         r = make_renderer(sc, w, h, sort=sort)
         r.setTileRows(11, 12)
         img = r.draw(sc)
@@ -815,7 +818,7 @@ def test_randomized_frames(oracle_mod):
         pos = tuple(float(x) for x in rng.uniform(-1.0, 1.0, 3) * np.array([1.0, 0.5, 2.0]))
         yaw, pitch = float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.3, 0.3))
         sh_mode = int(rng.integers(0, 3))
-        sort = gs.GS_SORT_RADIX4 if rng.random() < 0.7 else gs.GS_SORT_TILE_BUCKET
+        sort = ALL_SORTS[int(rng.choice(3, p=[0.45, 0.2, 0.35]))]
         kernel = kernels[int(rng.integers(0, len(kernels)))]
         sc = make_scene(aos, w, h, pos=pos, yaw=yaw, pitch=pitch, sh_mode=sh_mode)
         r = make_renderer(sc, w, h, sort=sort, kernel=kernel)
@@ -895,7 +898,7 @@ def test_grid_beyond_16_bit_tile_ids(oracle_mod):
     r.cleanup()
 
 
-@pytest.mark.parametrize("sort", [gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET])
+@pytest.mark.parametrize("sort", ALL_SORTS)
 def test_camera_sequence_has_no_frame_to_frame_state(oracle_mod, small_cloud, sort):
     """Poses A, B, C, A, B through ONE context (graph replay of the radix passes, reused 16-bit / shrunken sort-list
     buffers, raster records of earlier frames still in memory): every frame equals the oracle's frame of its pose,

@@ -28,6 +28,7 @@ GS_RENDER_KERNEL_AUTO, GS_RENDER_KERNEL_WAVE_1PX, GS_RENDER_KERNEL_WAVE_2PX = 0,
 GS_RENDER_KERNEL_WAVE_4PX, GS_RENDER_KERNEL_WORKGROUP = 4, 16
 GS_SORT_RADIX4 = 0
 GS_SORT_TILE_BUCKET = 1
+GS_SORT_RADIX4_SPLAT_FIRST = 2
 
 (BUF_SORTED_TILE, BUF_SORTED_DEPTH, BUF_SORTED_ID, BUF_RANGES, BUF_COLOR, BUF_COV, BUF_COUNT,
  BUF_UNSORTED_TILE, BUF_UNSORTED_DEPTH, BUF_UNSORTED_ID, BUF_IMAGE) = range(11)

@@ -68,7 +68,9 @@ struct gs_ctx {
     // as one hipGraph launch: 36 launches -> 1 on the host side.  Built lazily, dropped when anything it baked in
     // changes.  Not used while per-Scatter events are recorded (record_timings == 2).
     hipGraphExec_t sort_graph = nullptr;
-    int sort_graph_result = 0;
+    hipGraphExec_t presort_graph = nullptr;   // GS_SORT_RADIX4_SPLAT_FIRST: the eight depth passes over the splat list
+    hipEvent_t pre_ev[3] = {};        // ... after the splat list / after its passes / after the emit
+    int sort_graph_result = 0, presort_result = 1;
     bool sort_graph_failed = false;
     bool depth_dropped = false;   // last frame's tile-word passes did not carry the depth words (see k_scatter)
 
@@ -115,6 +117,8 @@ void free_scene(gs_ctx* c) {
     free_dev(c->scratch.extents); free_dev(c->scratch.block_sums); free_dev(c->scratch.block_offsets);
     free_dev(c->scratch.help_list); free_dev(c->scratch.help_count); free_dev(c->scratch.help_slot);
     free_dev(c->scratch.band_list);
+    free_dev(c->scratch.block_flags); free_dev(c->scratch.flag_offsets);
+    free_dev(c->scratch.sorted_sums); free_dev(c->scratch.aux_params);
     c->n = 0;
 }
 
@@ -125,6 +129,7 @@ void free_sort(SortBuffers& s) {
 
 void drop_sort_graph(gs_ctx* c) {
     if (c->sort_graph) { (void)hipGraphExecDestroy(c->sort_graph); c->sort_graph = nullptr; }
+    if (c->presort_graph) { (void)hipGraphExecDestroy(c->presort_graph); c->presort_graph = nullptr; }
     c->sort_graph_failed = false;
 }
 
@@ -221,15 +226,63 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     // RadixSort.cpp:676-692) is unobservable once every later stage runs over E instead of C.
     // (the ranges and the sort's coarse totals are cleared inside k_scan_blocks: no fill launches in a frame)
     fp.parity = (c->emit_parity ^= 1u);
+    const bool splat_first = c->cfg.sort_algorithm == GS_SORT_RADIX4_SPLAT_FIRST;
+    fp.splat_first = splat_first ? 1u : 0u;
+    const bool bucket = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET;
+    const bool per_pass_events = c->cfg.record_timings >= 2;
+    const float tile_share = c->grid_h ? (float)c->rows_owned / (float)c->grid_h : 1.0f;
+    // one capture-or-replay of a run of radix passes (nothing executes during capture)
+    auto radix_passes = [&](hipGraphExec_t& exec, int& result, auto&& launch) -> int {
+        if (!per_pass_events && !exec && !c->sort_graph_failed) {
+            hipGraph_t graph = nullptr;
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok) {
+                result = launch(nullptr);
+                ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!ok) { exec = nullptr; c->sort_graph_failed = true; (void)hipGetLastError(); }
+        }
+        if (!per_pass_events && exec) {
+            if (hipGraphLaunch(exec, st) != hipSuccess) return -1;
+            return result;
+        }
+        return launch(per_pass_events ? c->scatter_ev : nullptr);
+    };
     launch_project(fp, c->scene, c->scratch, st);
     launch_scan_blocks(fp, c->scratch, c->sort.params, c->ranges, c->sort.coarse, st);
+    if (splat_first) {
+        // GS_SORT_RADIX4_SPLAT_FIRST: the eight passes over the depth word run on the list of emitting splats, the emit
+        // walks that list, the tile-word passes finish.  InitSortList = project + lists + emit, RadixSort = all passes.
+        launch_splat_list(fp, c->scratch, c->sort, st);
+        if (int r = check_launch(c, "InitSortList")) return r;
+        if (tm) HIP_TRY(c, hipEventRecord(c->pre_ev[0], st));
+        int presorted = 1;
+        const int got = radix_passes(c->presort_graph, c->presort_result, [&](hipEvent_t* evs) {
+            // the frame's own depth passes (shrinking depth words, payload as wide as the tile ids) over the splat list
+            return launch_radix_sort(c->sort, c->n, 32u, st, evs, 0u, true, c->hi16, 1.0f, /*start*/ 1, /*coarse_pass*/ 0,
+                                     c->scratch.aux_params);
+        });
+        if (got < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+        presorted = got;
+        if (int r = check_launch(c, "RadixSort")) return r;
+        if (tm) HIP_TRY(c, hipEventRecord(c->pre_ev[1], st));
+        launch_gather_sorted(fp, c->scratch, c->sort, presorted, st);
+        launch_emit_sorted(fp, c->scratch, c->sort, presorted, st);
+        if (int r = check_launch(c, "InitSortList")) return r;
+        if (tm) HIP_TRY(c, hipEventRecord(c->pre_ev[2], st));
+        const int sorted = radix_passes(c->sort_graph, c->sort_graph_result, [&](hipEvent_t* evs) {
+            return launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, evs ? evs + 16 : nullptr, 32u, true, c->hi16,
+                                     tile_share, /*start*/ 0, /*coarse_pass*/ 8);
+        });
+        if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+        c->sorted_index = sorted;
+    } else {
     launch_emit(fp, c->scratch, c->sort, st);
     if (int r = check_launch(c, "InitSortList")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[2], st));
     // gpuSort->computeSort (RadixSort.cpp:207-653)
-    const bool bucket = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET;
-    const bool per_pass_events = c->cfg.record_timings >= 2;
-    const float tile_share = c->grid_h ? (float)c->rows_owned / (float)c->grid_h : 1.0f;
     if (!per_pass_events && !c->sort_graph && !c->sort_graph_failed) {
         // capture the passes once (nothing executes during capture)
         hipGraph_t graph = nullptr;
@@ -251,6 +304,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
                                             per_pass_events ? c->scatter_ev : nullptr,
                                             bucket ? 32u : 0u, !bucket, c->hi16, tile_share);
     }
+    }   // !splat_first
     c->depth_dropped = !bucket;
     if (int r = check_launch(c, "RadixSort")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[3], st));
@@ -300,8 +354,19 @@ int finish_frame(gs_ctx* c) {
     HIP_TRY(c, hipMemcpy(&sp, c->sort.params, sizeof(sp), hipMemcpyDeviceToHost));
     gs_timings t{};
     if (c->cfg.record_timings) {
+        if (c->cfg.sort_algorithm == GS_SORT_RADIX4_SPLAT_FIRST) {
+            // project + lists | depth passes | gather + emit | tile-word passes
+            float a = 0.0f, b = 0.0f, d = 0.0f, e = 0.0f;
+            HIP_TRY(c, hipEventElapsedTime(&a, c->ev[1], c->pre_ev[0]));
+            HIP_TRY(c, hipEventElapsedTime(&b, c->pre_ev[0], c->pre_ev[1]));
+            HIP_TRY(c, hipEventElapsedTime(&d, c->pre_ev[1], c->pre_ev[2]));
+            HIP_TRY(c, hipEventElapsedTime(&e, c->pre_ev[2], c->ev[3]));
+            t.init_sort_list_ms = a + d;
+            t.radix_sort_ms = b + e;
+        } else {
         HIP_TRY(c, hipEventElapsedTime(&t.init_sort_list_ms, c->ev[1], c->ev[2]));
         HIP_TRY(c, hipEventElapsedTime(&t.radix_sort_ms, c->ev[2], c->ev[3]));
+        }
         HIP_TRY(c, hipEventElapsedTime(&t.find_ranges_ms, c->ev[3], c->ev[4]));
         HIP_TRY(c, hipEventElapsedTime(&t.render_ms, c->ev[4], c->ev[5]));
         HIP_TRY(c, hipEventElapsedTime(&t.total_ms, c->ev[0], c->ev[6]));
@@ -314,7 +379,30 @@ int finish_frame(gs_ctx* c) {
             t.radix_sort_ms += tile_ms;
         }
     }
-    if (c->cfg.record_timings >= 2) {
+    if (c->cfg.record_timings >= 2 && c->cfg.sort_algorithm == GS_SORT_RADIX4_SPLAT_FIRST) {
+        // "full" = the eight depth passes over the SPLAT list, "tile" = the tile-word passes over the elements
+        float sum_pre = 0.0f, sum_tile = 0.0f, bytes_pre = 0.0f;
+        const uint32_t n_tile = (c->band_sort_bits - 32u) / kRadixBits;
+        for (uint32_t k = 0; k < 8u; ++k) {
+            float ms = 0.0f;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->scatter_ev[2 * k], c->scatter_ev[2 * k + 1]));
+            sum_pre += ms;
+            int lo_in, lo_out;
+            scatter_depth_bytes(k * kRadixBits, 0u, true, &lo_in, &lo_out);
+            bytes_pre += (float)(lo_in + lo_out) + 2.0f * (c->hi16 ? 2.0f : 4.0f) + 8.0f;   // depth + count + splat, r + w
+        }
+        for (uint32_t k = 0; k < n_tile; ++k) {
+            float ms = 0.0f;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->scatter_ev[16 + 2 * k], c->scatter_ev[16 + 2 * k + 1]));
+            sum_tile += ms;
+        }
+        t.scatter_ms_avg = sum_pre / 8.0f;
+        t.scatter_launches = 8;
+        t.scatter_bytes_per_elem = bytes_pre / 8.0f;   // per SPLAT of the list
+        t.scatter_tile_ms_avg = n_tile ? sum_tile / (float)n_tile : 0.0f;
+        t.scatter_tile_launches = n_tile;
+        t.scatter_tile_bytes_per_elem = 2.0f * (c->hi16 ? 2.0f : 4.0f) + 8.0f;
+    } else if (c->cfg.record_timings >= 2) {
         const uint32_t first_bit = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET ? 32u : 0u;
         const uint32_t passes = (c->band_sort_bits - first_bit) / kRadixBits;
         // launches that move all 24 bytes per element (k_scatter<true>) and the tile-word passes of the frame
@@ -372,7 +460,7 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
     gs_config cfg;
     if (cfg_in) cfg = *cfg_in; else gs_default_config(&cfg);
     if (cfg.tile_size != 16) return fail(nullptr, GS_ERR_INVALID, "gs_create: only tile_size 16 is supported");
-    if (cfg.sort_algorithm > GS_SORT_TILE_BUCKET) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown sort_algorithm");
+    if (cfg.sort_algorithm > GS_SORT_RADIX4_SPLAT_FIRST) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown sort_algorithm");
     if (cfg.render_mode > GS_RENDER_FAST) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown render_mode");
     if (cfg.render_kernel != GS_RENDER_KERNEL_AUTO && cfg.render_kernel != GS_RENDER_KERNEL_WAVE_1PX &&
         cfg.render_kernel != GS_RENDER_KERNEL_WAVE_2PX && cfg.render_kernel != GS_RENDER_KERNEL_WAVE_4PX &&
@@ -403,6 +491,12 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
             return fail(nullptr, GS_ERR_HIP, msg);
         }
     for (auto& ev : c->alt_ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) {
+            std::string msg = std::string("gs_create: ") + hipGetErrorString(e);
+            gs_destroy(c);
+            return fail(nullptr, GS_ERR_HIP, msg);
+        }
+    for (auto& ev : c->pre_ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) {
             std::string msg = std::string("gs_create: ") + hipGetErrorString(e);
             gs_destroy(c);
@@ -442,6 +536,7 @@ int gs_destroy(gs_ctx* c) {
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : c->scatter_ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : c->alt_ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : c->pre_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->join_ev) (void)hipEventDestroy(c->join_ev);
     if (c->helper_stream) { (void)hipStreamSynchronize(c->helper_stream); (void)hipStreamDestroy(c->helper_stream); }
@@ -482,6 +577,16 @@ static int alloc_scratch(gs_ctx* c, uint32_t n) {
     HIP_TRY(c, hipMemsetAsync(c->scratch.help_list, 0, (size_t)kEmitHelpCap * sizeof(uint2), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->scratch.help_slot, 0xFF, (size_t)c->num_blocks * sizeof(uint32_t), c->stream));
     c->emit_parity = 0;
+    if (c->cfg.sort_algorithm == GS_SORT_RADIX4_SPLAT_FIRST) {
+        HIP_TRY(c, hipMalloc((void**)&c->scratch.block_flags, padded * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void**)&c->scratch.flag_offsets, padded * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void**)&c->scratch.sorted_sums, padded * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void**)&c->scratch.aux_params, 2 * sizeof(SortParams)));
+        HIP_TRY(c, hipMemsetAsync(c->scratch.block_flags, 0, padded * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->scratch.flag_offsets, 0, padded * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->scratch.sorted_sums, 0, padded * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->scratch.aux_params, 0, 2 * sizeof(SortParams), c->stream));
+    }
     return GS_OK;
 }
 
@@ -606,7 +711,7 @@ static int apply_tile_rows(gs_ctx* c, uint32_t row_begin, uint32_t row_end, uint
     const uint32_t owned_tiles = c->rows_owned * c->grid_w;
     c->band_sort_bits = num_sort_bits_for(owned_tiles ? owned_tiles : 1u);
     c->hi16 = owned_tiles <= 65535u;
-    if (c->sort_graph) {
+    if (c->sort_graph || c->presort_graph) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));   // the graph may still be executing
         drop_sort_graph(c);
     }

@@ -56,6 +56,8 @@ struct FrameParams {
     float w_norm2;        // upper bound on the squared spectral norm of the upper-left 3x3 of view (host-folded, for the
                           // band bound; 1 for a rigid view matrix)
     uint32_t parity;      // InitSortList launches alternate between the two helper counters of SplatScratch
+    uint32_t splat_first; // GS_SORT_RADIX4_SPLAT_FIRST: k_project also counts the emitting splats per block and leaves the
+                          // helper records of k_emit to k_gather_sorted
 };
 
 // Device-side dispatch record: the role of RadixIndirectDispatch (ShaderStructs.h:45-57) +
@@ -111,6 +113,11 @@ struct SplatScratch {
     // A context that owns a subset of the tile rows: the project blocks k_band_cull could not reject, in arrival order,
     // block | skipped-waves mask << 28.
     uint32_t* band_list;     // [ceil(N/kProjThreads)]
+    // GS_SORT_RADIX4_SPLAT_FIRST only (null otherwise)
+    uint32_t* block_flags;   // [blocks, padded like block_sums]  emitting splats per project workgroup
+    uint32_t* flag_offsets;  // same size, exclusive scan
+    uint32_t* sorted_sums;   // [blocks, padded]  tile counts per 256 positions of the sorted splat list
+    SortParams* aux_params;  // [2]: the splat list's dispatch record; scratch for the second scan
 };
 #ifndef GS_EMIT_SLICE
 #define GS_EMIT_SLICE 4096
@@ -148,19 +155,29 @@ inline void scatter_depth_bytes(uint32_t shift, uint32_t first_bit, bool drop_de
 // ---- launchers (each enqueues on `stream`, no host sync) ------------------------------------
 void launch_project(const FrameParams& fp, const SceneBuffers& scene, const SplatScratch& sc,
                     hipStream_t stream);
+// sums == nullptr: block_sums -> block_offsets, the frame's clears, the IndirectSetup record in `params`.
 void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParams* params,
                         uint32_t* ranges, uint32_t* coarse, hipStream_t stream);
 void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb,
                  hipStream_t stream);
+// GS_SORT_RADIX4_SPLAT_FIRST (gs_project.hip): the (depth word | tile count | splat) list of the emitting splats into
+// sort buffers [1] (lo, hi, id), with its dispatch record in sc.aux_params[0]; then, once that list is sorted by depth
+// (buffers [sorted]), the sums of its tile counts + their scan; then the emit in depth order into buffers [0].
+void launch_splat_list(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb, hipStream_t stream);
+void launch_gather_sorted(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb, int sorted, hipStream_t stream);
+void launch_emit_sorted(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb, int sorted, hipStream_t stream);
 // Sorts buffers [0] -> result index returned (0 or 1) after num_sort_bits/4 passes.
 // scatter_events: optional 2*passes events recorded right before / after every Scatter launch.
 // Passes run over key bits [first_bit, num_sort_bits) of tile << 32 | depth (in a frame the tile word is the compact
 // tile id of FrameParams: a context that owns a subset of the tile rows sorts over fewer significant bits).
 // drop_depth_payload: the tile-word passes (bits >= 32) do not carry the depth words (frame path only).
 // hi16: the hi arrays hold 16-bit tile ids (frame path, at most 65535 owned tiles).
+// start: the ping-pong buffer the list lies in; coarse_pass: first slab of sb.coarse to use (one per pass; two sorts
+// in one frame must not share slabs); params: dispatch record of this list (default sb.params).
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events = nullptr, uint32_t first_bit = 0,
-                      bool drop_depth_payload = false, bool hi16 = false, float share = 1.0f);
+                      bool drop_depth_payload = false, bool hi16 = false, float share = 1.0f,
+                      int start = 0, uint32_t coarse_pass = 0, const SortParams* params = nullptr);
 // GS_SORT_TILE_BUCKET: per-tile depth sort of the owned tiles (gs_tilesort.hip)
 int init_tile_sort();
 void launch_tile_sort(const FrameParams& fp, const uint32_t* ranges, uint32_t* lo, uint32_t* id,

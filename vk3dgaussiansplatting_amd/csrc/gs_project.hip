@@ -201,6 +201,27 @@ __device__ __forceinline__ bool misses_owned_rows(const FrameParams& fp, float y
     return owned_rows_below(fp, y1) - owned_rows_below(fp, y0) <= 0;
 }
 
+// k_emit walks at most kEmitSlice output elements per workgroup: a block of 256 splats (consecutive indices, or
+// consecutive positions of the depth-sorted list) that emits more registers the slices after the first as helper
+// records.  Whole workgroup; t is uniform.
+__device__ __forceinline__ void register_emit_helpers(const FrameParams& fp, const SplatScratch& sc, uint32_t blk, uint32_t t) {
+    if (t > kEmitSlice) {
+        __shared__ uint32_t s_slot;
+        const uint32_t extra = (t - 1u) / kEmitSlice;
+        if (threadIdx.x == 0) {
+            uint32_t slot = atomicAdd(&sc.help_count[fp.parity], extra);
+            // no room (only when the element count overflows the list capacity): the owner does every slice
+            if ((uint64_t)slot + extra > (uint64_t)emit_helpers(fp.capacity)) slot = kEmitNoHelp;
+            sc.help_slot[blk] = slot;
+            s_slot = slot;
+        }
+        __syncthreads();
+        const uint32_t slot = s_slot;
+        if (slot != kEmitNoHelp)
+            for (uint32_t i = threadIdx.x; i < extra; i += kProjThreads) sc.help_list[slot + i] = make_uint2(blk, i + 1u);
+    }
+}
+
 // The box around 64 consecutive splat positions (b0 = min xyz, max x; b1 = max yz, largest sig2; from the upload --
 // the arrays are in Morton order, so it is small) against the owned tile rows.  If all eight corners are beyond the
 // near plane, every splat's screen y lies between the corners' extremes and its radius is below the bound taken at the
@@ -257,7 +278,7 @@ __global__ __launch_bounds__(kCullThreads) void k_band_cull(const FrameParams fp
     const uint32_t mask = (uint32_t)(__ballot(skip) >> (lane & ~3)) & 0xFu;     // the four waves of my block
     const bool leader = (lane & 3) == 0 && b < num_blocks;
     const bool survives = leader && mask != 0xFu;
-    if (leader && !survives) sc.block_sums[b] = 0u;
+    if (leader && !survives) { sc.block_sums[b] = 0u; if (fp.splat_first) sc.block_flags[b] = 0u; }
     // one returning atomic per workgroup (on one address they complete at about 90 per microsecond)
     const uint64_t vote = __ballot(survives);
     if (lane == 0) s_cnt[wave] = (uint32_t)__builtin_popcountll(vote);
@@ -286,6 +307,7 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
                                                            const SplatScratch sc, const uint32_t num_blocks) {
     __shared__ uint32_t s_wave_sum[kProjThreads / 64];
     __shared__ uint32_t s_wave_emits[kProjThreads / 64];
+    __shared__ uint32_t s_wave_flags[kProjThreads / 64];
     // The 48-byte raster records of the workgroup's 256 splats are staged here and written out as one
     // contiguous 12 KB block of full cache lines: per-lane 16-byte stores at a 48-byte stride reached HBM
     // as 32-byte partial writes (WRITE_SIZE 355 MB per frame against 219 MB of payload, config C).
@@ -432,8 +454,10 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
     s_raster[threadIdx.x * 3 + 2] = rec2;
     // per-workgroup total -> block_sums (input of the scan that replaces the atomic counter)
     const uint32_t wsum = wave_sum_to_lane63(count);
+    const uint32_t wflags = (uint32_t)__popcll(__ballot(count != 0u));   // emitting splats (GS_SORT_RADIX4_SPLAT_FIRST)
     if (lane_id() == 63) {
         s_wave_sum[wave_id()] = wsum;
+        s_wave_flags[wave_id()] = wflags;
         // A context that owns a tile-row band (multi-GPU) never reads the records of splats that emit nothing
         // into the band -- RenderGaussians reaches records only through the sorted list -- so a wave whose 64
         // splats all emit nothing skips its 3 KB of the block (most waves of a narrow band; the arrays are in
@@ -454,25 +478,15 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
     uint32_t t = 0;
 #pragma unroll
     for (int w = 0; w < kProjThreads / 64; ++w) t += s_wave_sum[w];
-    if (threadIdx.x == 0) sc.block_sums[blk] = t;
+    if (threadIdx.x == 0) {
+        sc.block_sums[blk] = t;
+        if (fp.splat_first) sc.block_flags[blk] = s_wave_flags[0] + s_wave_flags[1] + s_wave_flags[2] + s_wave_flags[3];
+    }
     // k_emit walks a workgroup's output range kEmitSlice elements per workgroup: a block that emits more (a few
     // hundred near splats hold half of a tile-row band's elements) registers the slices after the first as helper
-    // records.  The order of the records depends on atomic arrival; what each one writes does not.
-    if (t > kEmitSlice) {
-        __shared__ uint32_t s_slot;
-        const uint32_t extra = (t - 1u) / kEmitSlice;
-        if (threadIdx.x == 0) {
-            uint32_t slot = atomicAdd(&sc.help_count[fp.parity], extra);
-            // no room (only when the element count overflows the list capacity): the owner does every slice
-            if ((uint64_t)slot + extra > (uint64_t)emit_helpers(fp.capacity)) slot = kEmitNoHelp;
-            sc.help_slot[blk] = slot;
-            s_slot = slot;
-        }
-        __syncthreads();
-        const uint32_t slot = s_slot;
-        if (slot != kEmitNoHelp)
-            for (uint32_t i = threadIdx.x; i < extra; i += kProjThreads) sc.help_list[slot + i] = make_uint2(blk, i + 1u);
-    }
+    // records.  The order of the records depends on atomic arrival; what each one writes does not.  (With
+    // GS_SORT_RADIX4_SPLAT_FIRST k_emit walks the splats in depth order: k_gather_sorted registers its blocks.)
+    if (!fp.splat_first) register_emit_helpers(fp, sc, blk, t);
 }
 
 // One workgroup of 1024 threads: exclusive scan of block_sums (u64 running total so an overflowing
@@ -481,15 +495,22 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
 // entries at upload): one pass to sum, one block scan, one pass to write -- no row-by-row carry chain.
 // It also does the frame's clears (computeInitSortList's fills, Subrenderer.cpp:42-60): the tile ranges and the
 // per-pass coarse digit totals of the sort -- two fill launches less per frame.
-__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict__ block_sums,
-                                                       uint32_t* __restrict__ block_offsets,
-                                                       uint32_t num_blocks, uint32_t capacity,
-                                                       SortParams* params, uint4* __restrict__ zero_a, uint32_t n16_a,
+struct ScanJob { const uint32_t* sums; uint32_t* offsets; SortParams* params; uint32_t capacity; };
+__global__ __launch_bounds__(1024) void k_scan_blocks(const ScanJob job0, const ScanJob job1, uint32_t num_blocks,
+                                                       uint4* __restrict__ zero_a, uint32_t n16_a,
                                                        uint4* __restrict__ zero_b, uint32_t n16_b,
                                                        uint32_t* __restrict__ next_help_count) {
-    if (threadIdx.x == 0) { next_help_count[0] = 0u; next_help_count[2] = 0u; }   // what the NEXT InitSortList launch adds to
-    for (uint32_t i = threadIdx.x; i < n16_a; i += 1024u) zero_a[i] = make_uint4(0u, 0u, 0u, 0u);
-    for (uint32_t i = threadIdx.x; i < n16_b; i += 1024u) zero_b[i] = make_uint4(0u, 0u, 0u, 0u);
+    // workgroup 0: the list of elements (+ the clears); workgroup 1, when launched: a second, independent scan
+    const ScanJob job = blockIdx.x == 0 ? job0 : job1;
+    const uint32_t* __restrict__ block_sums = job.sums;
+    uint32_t* __restrict__ block_offsets = job.offsets;
+    SortParams* params = job.params;
+    const uint32_t capacity = job.capacity;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0 && next_help_count) { next_help_count[0] = 0u; next_help_count[2] = 0u; }   // what the NEXT InitSortList launch adds to
+        for (uint32_t i = threadIdx.x; i < n16_a; i += 1024u) zero_a[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t i = threadIdx.x; i < n16_b; i += 1024u) zero_b[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     __shared__ uint64_t s_wave_tot[16];
     __shared__ uint64_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -541,18 +562,25 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict
 constexpr int kEmitChunk = 4 * kProjThreads;   // output elements resolved per round of k_emit
 static_assert(kEmitSlice % kEmitChunk == 0, "a slice is a whole number of rounds");
 
+// SORTED (GS_SORT_RADIX4_SPLAT_FIRST): "splat g" is position g of the depth-sorted splat list -- its tile count rode
+// through the depth passes as the payload, the splat index too, the extents are gathered through it -- and no depth
+// word is written: the list is already in depth order, the tile-word passes that follow are stable and nothing later
+// reads depth words.
+template <bool SORTED>
 __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, const SplatScratch sc,
                                                         uint32_t* __restrict__ out_lo,
                                                         uint32_t* __restrict__ out_hi,
                                                         uint32_t* __restrict__ out_id, uint32_t num_blocks,
-                                                        uint32_t helpers) {
+                                                        uint32_t helpers, const uint32_t* __restrict__ sorted_ids,
+                                                        const uint32_t* __restrict__ sorted_counts) {
+    const uint32_t* __restrict__ sums = SORTED ? sc.sorted_sums : sc.block_sums;
     __shared__ uint32_t s_incl[kProjThreads];   // inclusive scan of tile counts
     __shared__ uint32_t s_wave_tot[kProjThreads / 64];
     __shared__ uint2 s_ext[kProjThreads];
     __shared__ uint32_t s_depth[kProjThreads];
     __shared__ uint32_t s_owner[kEmitChunk];
     __shared__ uint32_t s_wmax[kProjThreads / 64];
-    const uint32_t n = fp.num_gaussians;
+    const uint32_t n = SORTED ? sc.aux_params[0].num_elems : fp.num_gaussians;
     const int tid = threadIdx.x;
     // the helper workgroups come FIRST in the launch: the slices of the heaviest blocks start with the launch, and the
     // workgroups without a record are gone before the owners arrive
@@ -567,22 +595,32 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
         if (blk >= num_blocks || slice == 0u) return;
         const uint32_t first = sc.help_slot[blk];
         if (first == kEmitNoHelp || h - first + 1u != slice) return;
-        const uint32_t t = sc.block_sums[blk];
+        const uint32_t t = sums[blk];
         if (t <= kEmitSlice || slice > (t - 1u) / kEmitSlice) return;
     }
     const uint32_t g = blk * kProjThreads + tid;
     // every global read of the workgroup is issued up front (one memory latency instead of a chain);
     // extents/depth of splats that emit nothing are stale or uninitialised and never used
-    const uint32_t total = sc.block_sums[blk];
+    const uint32_t total = sums[blk];
     // a context with a subset of the tile rows has mostly empty workgroups (some never wrote their per-splat
     // arrays, see k_project): look at the total first there
     if (!owns_every_row(fp) && total == 0) return;
     const uint32_t base = sc.block_offsets[blk];
     // the owner of a heavy block whose helper records did not fit the list walks every slice itself
     const bool alone = slice == 0u && total > kEmitSlice && sc.help_slot[blk] == kEmitNoHelp;
-    const uint32_t cnt = g < n ? sc.tiles_touched[g] : 0u;
-    const uint2 my_ext = g < n ? sc.extents[g] : make_uint2(0u, 0u);
-    const uint32_t my_depth = g < n ? sc.depth_key[g] : 0u;
+    uint32_t cnt = 0u, my_depth = 0u;              // SORTED: my_depth carries the splat index instead
+    uint2 my_ext = make_uint2(0u, 0u);
+    if (g < n) {
+        if constexpr (SORTED) {
+            my_depth = sorted_ids[g];
+            cnt = fp.hi16 ? (uint32_t)reinterpret_cast<const uint16_t*>(sorted_counts)[g] : sorted_counts[g];
+            my_ext = sc.extents[my_depth];           // the one gather of this path: 8 bytes per emitting splat
+        } else {
+            cnt = sc.tiles_touched[g];
+            my_ext = sc.extents[g];
+            my_depth = sc.depth_key[g];
+        }
+    }
     if (total == 0) return;
     if (base >= fp.capacity) return;             // whole block dropped (overflow, :143)
     s_ext[tid] = my_ext;
@@ -652,8 +690,8 @@ __global__ __launch_bounds__(kProjThreads) void k_emit(const FrameParams fp, con
                 if (out < fp.capacity) {                                  // :143
                     if (fp.hi16) reinterpret_cast<uint16_t*>(out_hi)[out] = (uint16_t)tile_key;
                     else out_hi[out] = tile_key;
-                    out_lo[out] = s_depth[s];
-                    out_id[out] = g0 + s;
+                    if constexpr (SORTED) out_id[out] = s_depth[s];
+                    else { out_lo[out] = s_depth[s]; out_id[out] = g0 + s; }
                 }
             }
         }
@@ -677,9 +715,12 @@ void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParam
     // ranges: [grid_w * grid_h][2] uint32 (hipMalloc'd, so 16-byte aligned; padded to a multiple of 16 bytes by the caller)
     const uint32_t n16_ranges = (fp.grid_w * fp.grid_h * 2u + 3u) / 4u;
     const uint32_t n16_coarse = (uint32_t)(kMaxSortPasses * kBins * kCoarse) / 4u;
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, sc.block_sums,
-                       sc.block_offsets, blocks, fp.capacity, params, reinterpret_cast<uint4*>(ranges), n16_ranges,
-                       reinterpret_cast<uint4*>(coarse), n16_coarse, sc.help_count + (fp.parity ^ 1u));
+    const ScanJob elements{sc.block_sums, sc.block_offsets, params, fp.capacity};
+    // GS_SORT_RADIX4_SPLAT_FIRST: the emitting splats are scanned beside the elements (a second workgroup)
+    const ScanJob splats{sc.block_flags, sc.flag_offsets, sc.aux_params, fp.num_gaussians};
+    hipLaunchKernelGGL(k_scan_blocks, dim3(fp.splat_first ? 2 : 1), dim3(1024), 0, stream, elements, splats, blocks,
+                       reinterpret_cast<uint4*>(ranges), n16_ranges, reinterpret_cast<uint4*>(coarse), n16_coarse,
+                       sc.help_count + (fp.parity ^ 1u));
 }
 
 void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb,
@@ -687,8 +728,87 @@ void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffer
     const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
     if (blocks == 0) return;
     const uint32_t helpers = emit_helpers(fp.capacity);
-    hipLaunchKernelGGL(k_emit, dim3(helpers + blocks), dim3(kProjThreads), 0, stream, fp, sc, sb.lo[0],
-                       sb.hi[0], sb.id[0], blocks, helpers);
+    hipLaunchKernelGGL((k_emit<false>), dim3(helpers + blocks), dim3(kProjThreads), 0, stream, fp, sc, sb.lo[0],
+                       sb.hi[0], sb.id[0], blocks, helpers, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+}
+
+// ---- GS_SORT_RADIX4_SPLAT_FIRST ------------------------------------------------------------------------------------
+// The list the eight depth passes sort: (depth word | tile count | splat) of every splat that emits anything, in splat
+// order.  The tile count rides as the payload in the place of the tile word (16 bits wide when the tile ids are), so the
+// passes are the frame's own depth passes -- same kernels, same shrinking depth words -- over a list a quarter as long.
+// The truncation of InitSortList.comp:143 is applied here, where the reference applies it: an element is dropped when
+// its position in SPLAT order is beyond the capacity, so every count is clipped against that position before
+// anything is reordered (only an overflowing frame clips anything).
+__global__ __launch_bounds__(kProjThreads) void k_splat_list(const FrameParams fp, const SplatScratch sc,
+                                                              uint32_t* __restrict__ out_depth, uint32_t* __restrict__ out_count,
+                                                              uint32_t* __restrict__ out_id) {
+    __shared__ uint32_t s_cnt[kProjThreads / 64], s_flag[kProjThreads / 64];
+    const uint32_t blk = blockIdx.x, g = blk * kProjThreads + threadIdx.x;
+    if (sc.block_sums[blk] == 0u) return;            // nothing emits (or k_band_cull rejected the block: stale arrays)
+    const uint32_t cnt = g < fp.num_gaussians ? sc.tiles_touched[g] : 0u;
+    const uint32_t dk = cnt != 0u ? sc.depth_key[g] : 0u;
+    const uint64_t off0 = sc.block_offsets[blk];     // saturated at 2^32 - 1: beyond any capacity
+    const uint32_t fpos0 = sc.flag_offsets[blk];
+    const uint32_t inc = wave_inclusive_scan(cnt);
+    const uint64_t fb = __ballot(cnt != 0u);
+    if (lane_id() == 63) { s_cnt[wave_id()] = inc; s_flag[wave_id()] = (uint32_t)__popcll(fb); }
+    __syncthreads();
+    uint64_t off = off0 + (inc - cnt);
+    uint32_t pos = fpos0 + (uint32_t)__popcll(fb & ((1ull << lane_id()) - 1ull));
+    for (int w = 0; w < wave_id(); ++w) { off += s_cnt[w]; pos += s_flag[w]; }
+    if (cnt != 0u) {
+        const uint64_t room = off < fp.capacity ? (uint64_t)fp.capacity - off : 0ull;
+        const uint32_t kept = room < cnt ? (uint32_t)room : cnt;
+        out_depth[pos] = dk;
+        if (fp.hi16) reinterpret_cast<uint16_t*>(out_count)[pos] = (uint16_t)kept;   // <= owned tiles <= 65535
+        else out_count[pos] = kept;
+        out_id[pos] = g;
+    }
+}
+
+// Sums of the tile counts per 256 positions of the sorted list (input of the second scan) and k_emit's helper records.
+__global__ __launch_bounds__(kProjThreads) void k_sorted_sums(const FrameParams fp, const SplatScratch sc,
+                                                               const uint32_t* __restrict__ sorted_counts) {
+    __shared__ uint32_t s_sum[kProjThreads / 64];
+    const uint32_t ve = sc.aux_params[0].num_elems;
+    const uint32_t blk = blockIdx.x, i = blk * kProjThreads + threadIdx.x;
+    if (blk * kProjThreads >= ve) {
+        if (threadIdx.x == 0) sc.sorted_sums[blk] = 0u;
+        return;
+    }
+    uint32_t cnt = 0u;
+    if (i < ve) cnt = fp.hi16 ? (uint32_t)reinterpret_cast<const uint16_t*>(sorted_counts)[i] : sorted_counts[i];
+    const uint32_t wsum = wave_sum_to_lane63(cnt);
+    if (lane_id() == 63) s_sum[wave_id()] = wsum;
+    __syncthreads();
+    const uint32_t t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    if (threadIdx.x == 0) sc.sorted_sums[blk] = t;
+    register_emit_helpers(fp, sc, blk, t);
+}
+
+void launch_splat_list(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb, hipStream_t stream) {
+    const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_splat_list, dim3(blocks), dim3(kProjThreads), 0, stream, fp, sc, sb.lo[1], sb.hi[1], sb.id[1]);
+}
+
+void launch_gather_sorted(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb, int sorted, hipStream_t stream) {
+    const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_sorted_sums, dim3(blocks), dim3(kProjThreads), 0, stream, fp, sc, (const uint32_t*)sb.hi[sorted]);
+    // the offsets of the 256-position blocks of the sorted list (the dispatch record of the elements stays the first
+    // scan's: same length, and it knows about an overflow)
+    const ScanJob sorted_blocks{sc.sorted_sums, sc.block_offsets, sc.aux_params + 1, fp.capacity};
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, sorted_blocks, sorted_blocks, blocks,
+                       (uint4*)nullptr, 0u, (uint4*)nullptr, 0u, (uint32_t*)nullptr);
+}
+
+void launch_emit_sorted(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb, int sorted, hipStream_t stream) {
+    const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
+    if (blocks == 0) return;
+    const uint32_t helpers = emit_helpers(fp.capacity);
+    hipLaunchKernelGGL((k_emit<true>), dim3(helpers + blocks), dim3(kProjThreads), 0, stream, fp, sc, (uint32_t*)nullptr,
+                       sb.hi[0], sb.id[0], blocks, helpers, (const uint32_t*)sb.id[sorted], (const uint32_t*)sb.hi[sorted]);
 }
 
 } // namespace gs

@@ -444,7 +444,9 @@ void k_scatter(const SortParams* __restrict__ params, const uint32_t* __restrict
 
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit,
-                      bool drop_depth_payload, bool hi16, float share) {
+                      bool drop_depth_payload, bool hi16, float share, int start, uint32_t coarse_pass,
+                      const SortParams* params) {
+    if (!params) params = sb.params;
     uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
     // a context that owns a share of the tiles (tile-row band of a multi-GPU frame) launches Scatter over twice
     // that share of the capacity's groups; k_scatter walks on if a frame should hold more
@@ -454,7 +456,7 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
     }
     // sb.coarse (the coarse digit totals of every pass; Count adds into them with atomics) must be zero on entry:
     // k_scan_blocks clears it in a frame, k_set_sort_params for the stand-alone sorter
-    int src = 0;
+    int src = start;
     uint32_t pass = 0;
     for (uint32_t shift = first_bit; shift < num_sort_bits; shift += kRadixBits, ++pass) { // RadixSort.cpp:309
         const int dst = src ^ 1;
@@ -466,12 +468,12 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
         scatter_depth_bytes(shift, first_bit, drop_depth_payload, &cin, &cout);
         const bool lo16 = !tile_pass && cin == 2;
         const bool word16 = (tile_pass && hi16) || lo16;
-        uint32_t* coarse = sb.coarse + (size_t)pass * kBins * kCoarse;   // zeroed above; this pass's Count adds into it
+        uint32_t* coarse = sb.coarse + (size_t)(coarse_pass + pass) * kBins * kCoarse;   // zeroed above; this pass's Count adds into it
         if (word16)
-            hipLaunchKernelGGL((k_count<true>), dim3(kSegments), dim3(kCountThreads), 0, stream, sb.params,
+            hipLaunchKernelGGL((k_count<true>), dim3(kSegments), dim3(kCountThreads), 0, stream, params,
                                word, sb.table, sb.seg_sum, coarse, lo16 ? shift - 16u : shift & 31u);
         else
-            hipLaunchKernelGGL((k_count<false>), dim3(kSegments), dim3(kCountThreads), 0, stream, sb.params,
+            hipLaunchKernelGGL((k_count<false>), dim3(kSegments), dim3(kCountThreads), 0, stream, params,
                                word, sb.table, sb.seg_sum, coarse, shift & 31u);
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass], stream);
         // bytes of the depth word read / written by this pass (see k_scatter)
@@ -479,7 +481,7 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
         scatter_depth_bytes(shift, first_bit, drop_depth_payload, &lo_in, &lo_out);
         const uint32_t pgrid = max_groups;
 #define GS_LAUNCH_SCATTER(LO_IN, LO_OUT, HI16)                                                                       \
-        hipLaunchKernelGGL((k_scatter<LO_IN, LO_OUT, HI16>), dim3(pgrid), dim3(kSortThreads), 0, stream, sb.params, \
+        hipLaunchKernelGGL((k_scatter<LO_IN, LO_OUT, HI16>), dim3(pgrid), dim3(kSortThreads), 0, stream, params, \
                            sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],                  \
                            sb.table, sb.seg_sum, coarse, shift)
 #define GS_LAUNCH_SCATTER_H(LO_IN, LO_OUT) \
