@@ -498,7 +498,23 @@ def main():
                     "pair around every such launch, on its stream); moved: the bytes this layout really reads + writes "
                     "per element, over the same duration",
         }
-        if passes_tile:
+        if args.sort == "splat_first":
+            # the depth passes run over the splat list (a quarter of the elements, latency-bound launches): the dominant
+            # HBM kernel of the sort is the tile-word pass, and SURVEY 8(d)'s 24 B per element no longer describes what a
+            # launch has to move (a tile word + a splat index, read and written) -- so `achieved` is the moved bytes here
+            mv = moved_tile * e_rank / (scat_tile * 1e-3) / 1e9 if scat_tile > 0 else 0.0
+            roofline = {
+                "bound": "hbm", "kernel": "k_scatter<0, 0, .> (tile-word passes of GS_SORT_RADIX4_SPLAT_FIRST)",
+                "achieved": round(mv, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(mv / HBM_PEAK_GBPS, 4),
+                "traffic": None, "alg_bytes_per_launch": moved_tile * e_rank, "alg_bytes_per_element": moved_tile,
+                "avg_launch_ms": round(scat_tile, 5), "launches_per_frame": passes_tile,
+                "frac_of_measured_copy": round(mv / copy_gbps, 4) if copy_gbps else None,
+                "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
+                "depth_passes_over_splats": {"avg_launch_ms": round(scat, 5), "launches_per_frame": passes_full,
+                                             "bytes_per_splat": moved_full},
+                "note": "achieved = bytes moved per launch (tile word + splat index, read + written) over the mean launch "
+                        "duration (HIP event pair around every such launch)"}
+        elif passes_tile:
             mv = moved_tile * e_rank / (scat_tile * 1e-3) / 1e9 if scat_tile > 0 else 0.0
             roofline["tile_word_passes"] = {
                 "kernel": "k_scatter<0, 0, .> (tile-word passes: depth words not carried)",

@@ -13,7 +13,7 @@ rm = gs.ResourceManager(); rm.setGaussians(aos)
 sc = gs.Scene(rm, aspect_ratio=w / h); cam = sc.getCamera(); cam.setPosition((0, 0, 0)); cam.setRotation(0, 0); cam.recalculate()
 dev = torch.device("cuda:0")
 wts = torch.arange(1, w * h + 1, device=dev, dtype=torch.int64) * 2654435761 % 1000003
-for sort in (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET):
+for sort in (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET, gs.GS_SORT_RADIX4_SPLAT_FIRST):
     for kernel in (gs.GS_RENDER_KERNEL_AUTO, gs.GS_RENDER_KERNEL_WAVE_4PX):
         r = gs.Renderer(w, h, record_timings=0, warmup_frames=0, sort_algorithm=sort, render_kernel=kernel)
         r.init(rm); r.initForScene(sc)

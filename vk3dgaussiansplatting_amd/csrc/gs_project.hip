@@ -767,23 +767,48 @@ __global__ __launch_bounds__(kProjThreads) void k_splat_list(const FrameParams f
 }
 
 // Sums of the tile counts per 256 positions of the sorted list (input of the second scan) and k_emit's helper records.
+// One WAVE per 256 positions (four counts per lane, one 8- or 16-byte load), eight of them per workgroup: nothing
+// crosses waves.
+constexpr int kSumsBlocksPerWg = 8;
 __global__ __launch_bounds__(kProjThreads) void k_sorted_sums(const FrameParams fp, const SplatScratch sc,
-                                                               const uint32_t* __restrict__ sorted_counts) {
-    __shared__ uint32_t s_sum[kProjThreads / 64];
+                                                               const uint32_t* __restrict__ sorted_counts, uint32_t num_blocks) {
     const uint32_t ve = sc.aux_params[0].num_elems;
-    const uint32_t blk = blockIdx.x, i = blk * kProjThreads + threadIdx.x;
-    if (blk * kProjThreads >= ve) {
-        if (threadIdx.x == 0) sc.sorted_sums[blk] = 0u;
-        return;
+    const int lane = lane_id();
+#pragma unroll
+    for (int it = 0; it < kSumsBlocksPerWg / (kProjThreads / 64); ++it) {
+        const uint32_t blk = blockIdx.x * kSumsBlocksPerWg + (uint32_t)(it * (kProjThreads / 64) + wave_id());
+        if (blk >= num_blocks) return;
+        const uint32_t i0 = blk * kProjThreads + 4u * (uint32_t)lane;   // four consecutive positions
+        uint32_t c[4] = {0u, 0u, 0u, 0u};
+        if (i0 + 3u < ve) {
+            if (fp.hi16) {
+                const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(sorted_counts) + i0);
+                c[0] = v.x & 0xFFFFu; c[1] = v.x >> 16; c[2] = v.y & 0xFFFFu; c[3] = v.y >> 16;
+            } else {
+                const uint4 v = *reinterpret_cast<const uint4*>(sorted_counts + i0);
+                c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k < ve) c[k] = fp.hi16 ? (uint32_t)reinterpret_cast<const uint16_t*>(sorted_counts)[i0 + k] : sorted_counts[i0 + k];
+        }
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)wave_sum_to_lane63(c[0] + c[1] + c[2] + c[3]), 63);
+        if (lane == 0) sc.sorted_sums[blk] = t;
+        // k_emit's helper records for a heavy block (register_emit_helpers, by one wave)
+        if (t > kEmitSlice) {
+            const uint32_t extra = (t - 1u) / kEmitSlice;
+            uint32_t slot = 0u;
+            if (lane == 0) {
+                slot = atomicAdd(&sc.help_count[fp.parity], extra);
+                if ((uint64_t)slot + extra > (uint64_t)emit_helpers(fp.capacity)) slot = kEmitNoHelp;
+                sc.help_slot[blk] = slot;
+            }
+            slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+            if (slot != kEmitNoHelp)
+                for (uint32_t i = (uint32_t)lane; i < extra; i += 64u) sc.help_list[slot + i] = make_uint2(blk, i + 1u);
+        }
     }
-    uint32_t cnt = 0u;
-    if (i < ve) cnt = fp.hi16 ? (uint32_t)reinterpret_cast<const uint16_t*>(sorted_counts)[i] : sorted_counts[i];
-    const uint32_t wsum = wave_sum_to_lane63(cnt);
-    if (lane_id() == 63) s_sum[wave_id()] = wsum;
-    __syncthreads();
-    const uint32_t t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-    if (threadIdx.x == 0) sc.sorted_sums[blk] = t;
-    register_emit_helpers(fp, sc, blk, t);
 }
 
 void launch_splat_list(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb, hipStream_t stream) {
@@ -795,7 +820,8 @@ void launch_splat_list(const FrameParams& fp, const SplatScratch& sc, const Sort
 void launch_gather_sorted(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb, int sorted, hipStream_t stream) {
     const uint32_t blocks = (fp.num_gaussians + kProjThreads - 1) / kProjThreads;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_sorted_sums, dim3(blocks), dim3(kProjThreads), 0, stream, fp, sc, (const uint32_t*)sb.hi[sorted]);
+    hipLaunchKernelGGL(k_sorted_sums, dim3((blocks + kSumsBlocksPerWg - 1) / kSumsBlocksPerWg), dim3(kProjThreads), 0, stream, fp, sc,
+                       (const uint32_t*)sb.hi[sorted], blocks);
     // the offsets of the 256-position blocks of the sorted list (the dispatch record of the elements stays the first
     // scan's: same length, and it knows about an overflow)
     const ScanJob sorted_blocks{sc.sorted_sums, sc.block_offsets, sc.aux_params + 1, fp.capacity};
