@@ -1003,3 +1003,37 @@ def test_emit_slices_of_heavy_blocks(oracle_mod):
         for row in rows:
             assert np.array_equal(img[row * 16:row * 16 + 16], ref["image"][row * 16:row * 16 + 16])
     r.cleanup()
+
+
+@pytest.mark.parametrize("sort", ALL_SORTS)
+def test_frames_without_timers(oracle_mod, small_cloud, sort):
+    """record_timings = 0 is what production and bench.py's timed region run: the radix passes replay as a hipGraph,
+    and with GS_SORT_RADIX4_SPLAT_FIRST the whole chain from the splat list to FindRanges is ONE graph (camera-free
+    kernel arguments, the helper counter cleared by a memset node).  Frames from several cameras, a change of tile
+    rows in between (the graphs are dropped and captured again), back to the whole frame: always the oracle's list,
+    ranges and pixels."""
+    w, h = 320, 180
+    cams = [((0.0, 0.0, 0.0), 0.0, 0.0), ((0.4, 0.1, -1.0), 0.2, -0.1), ((-0.3, 0.2, 0.5), -0.25, 0.05)]
+    scenes = [make_scene(small_cloud, w, h, pos=p, yaw=y, pitch=t) for p, y, t in cams]
+    r = gs.Renderer(w, h, warmup_frames=0, sort_algorithm=sort, record_timings=0)
+    r.init(scenes[0].getResourceManager())
+    r.initForScene(scenes[0])
+    refs = [oracle_run(oracle_mod, sc, w, h)[1] for sc in scenes]
+    for rep in range(3):
+        for sc, ref in zip(scenes, refs):
+            img = r.draw(sc)
+            e = ref["e"]
+            assert np.array_equal(r.debugRead(gs.BUF_SORTED_TILE), ref["tile"][:e])
+            assert np.array_equal(r.debugRead(gs.BUF_SORTED_DEPTH), ref["depth"][:e])
+            assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), ref["id"][:e])
+            assert np.array_equal(r.debugRead(gs.BUF_RANGES), ref["ranges"])
+            assert np.array_equal(img, ref["image"])
+        if rep == 0:
+            r.setTileRows(3, 9)
+            _, band = oracle_run(oracle_mod, scenes[1], w, h, row_begin=3, row_end=9)
+            for _ in range(2):
+                img = r.draw(scenes[1])
+                assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), band["id"][:band["e"]])
+                assert np.array_equal(img[48:144], band["image"][48:144])
+            r.setTileRows(0, r.sceneInfo().tiles_y)
+    r.cleanup()

@@ -69,6 +69,8 @@ struct gs_ctx {
     // changes.  Not used while per-Scatter events are recorded (record_timings == 2).
     hipGraphExec_t sort_graph = nullptr;
     hipGraphExec_t presort_graph = nullptr;   // GS_SORT_RADIX4_SPLAT_FIRST: the eight depth passes over the splat list
+    hipGraphExec_t chain_graph = nullptr;     // ... without timers: everything from the splat list to FindRanges as one graph
+    int chain_result = 0;
     hipEvent_t pre_ev[3] = {};        // ... after the splat list / after its passes / after the emit
     int sort_graph_result = 0, presort_result = 1;
     bool sort_graph_failed = false;
@@ -130,6 +132,7 @@ void free_sort(SortBuffers& s) {
 void drop_sort_graph(gs_ctx* c) {
     if (c->sort_graph) { (void)hipGraphExecDestroy(c->sort_graph); c->sort_graph = nullptr; }
     if (c->presort_graph) { (void)hipGraphExecDestroy(c->presort_graph); c->presort_graph = nullptr; }
+    if (c->chain_graph) { (void)hipGraphExecDestroy(c->chain_graph); c->chain_graph = nullptr; }
     c->sort_graph_failed = false;
 }
 
@@ -252,32 +255,58 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     };
     launch_project(fp, c->scene, c->scratch, st);
     launch_scan_blocks(fp, c->scratch, c->sort.params, c->ranges, c->sort.coarse, st);
+    bool ranges_done = false;
     if (splat_first) {
         // GS_SORT_RADIX4_SPLAT_FIRST: the eight passes over the depth word run on the list of emitting splats, the emit
         // walks that list, the tile-word passes finish.  InitSortList = project + lists + emit, RadixSort = all passes.
-        launch_splat_list(fp, c->scratch, c->sort, st);
-        if (int r = check_launch(c, "InitSortList")) return r;
-        if (tm) HIP_TRY(c, hipEventRecord(c->pre_ev[0], st));
-        int presorted = 1;
-        const int got = radix_passes(c->presort_graph, c->presort_result, [&](hipEvent_t* evs) {
+        // Nothing between the first scan and RenderGaussians depends on the camera: those kernels take a FrameParams
+        // without it (and with a fixed helper counter, cleared by a memset in front of its user), so their arguments
+        // never change and the whole chain -- FindRanges included -- replays as ONE graph when no timers are asked for.
+        FrameParams fps = fp;
+        std::memset(fps.view, 0, sizeof(fps.view)); std::memset(fps.proj, 0, sizeof(fps.proj));
+        std::memset(fps.cam_pos, 0, sizeof(fps.cam_pos));
+        fps.sh_mode = 0u; fps.w_norm2 = 0.0f; fps.compact_out = 0u;
+        fps.parity = 0u;
+        auto depth_passes = [&](hipEvent_t* evs) {
             // the frame's own depth passes (shrinking depth words, payload as wide as the tile ids) over the splat list
             return launch_radix_sort(c->sort, c->n, 32u, st, evs, 0u, true, c->hi16, 1.0f, /*start*/ 1, /*coarse_pass*/ 0,
                                      c->scratch.aux_params);
-        });
-        if (got < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
-        presorted = got;
-        if (int r = check_launch(c, "RadixSort")) return r;
-        if (tm) HIP_TRY(c, hipEventRecord(c->pre_ev[1], st));
-        launch_gather_sorted(fp, c->scratch, c->sort, presorted, st);
-        launch_emit_sorted(fp, c->scratch, c->sort, presorted, st);
-        if (int r = check_launch(c, "InitSortList")) return r;
-        if (tm) HIP_TRY(c, hipEventRecord(c->pre_ev[2], st));
-        const int sorted = radix_passes(c->sort_graph, c->sort_graph_result, [&](hipEvent_t* evs) {
+        };
+        auto tile_passes = [&](hipEvent_t* evs) {
             return launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, evs ? evs + 16 : nullptr, 32u, true, c->hi16,
                                      tile_share, /*start*/ 0, /*coarse_pass*/ 8);
-        });
+        };
+        if (!tm) {
+            const int sorted = radix_passes(c->chain_graph, c->chain_result, [&](hipEvent_t*) {
+                (void)hipMemsetAsync(c->scratch.help_count, 0, sizeof(uint32_t), st);
+                launch_splat_list(fps, c->scratch, c->sort, st);
+                const int presorted = depth_passes(nullptr);
+                launch_gather_sorted(fps, c->scratch, c->sort, presorted, st);
+                launch_emit_sorted(fps, c->scratch, c->sort, presorted, st);
+                const int si = tile_passes(nullptr);
+                launch_find_ranges(fps, c->sort.hi[si], c->sort.params, c->ranges, st);
+                return si;
+            });
+            if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+            c->sorted_index = sorted;
+            ranges_done = true;
+        } else {
+        HIP_TRY(c, hipMemsetAsync(c->scratch.help_count, 0, sizeof(uint32_t), st));
+        launch_splat_list(fps, c->scratch, c->sort, st);
+        if (int r = check_launch(c, "InitSortList")) return r;
+        HIP_TRY(c, hipEventRecord(c->pre_ev[0], st));
+        const int presorted = radix_passes(c->presort_graph, c->presort_result, depth_passes);
+        if (presorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+        if (int r = check_launch(c, "RadixSort")) return r;
+        HIP_TRY(c, hipEventRecord(c->pre_ev[1], st));
+        launch_gather_sorted(fps, c->scratch, c->sort, presorted, st);
+        launch_emit_sorted(fps, c->scratch, c->sort, presorted, st);
+        if (int r = check_launch(c, "InitSortList")) return r;
+        HIP_TRY(c, hipEventRecord(c->pre_ev[2], st));
+        const int sorted = radix_passes(c->sort_graph, c->sort_graph_result, tile_passes);
         if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
         c->sorted_index = sorted;
+        }
     } else {
     launch_emit(fp, c->scratch, c->sort, st);
     if (int r = check_launch(c, "InitSortList")) return r;
@@ -309,7 +338,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     if (int r = check_launch(c, "RadixSort")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[3], st));
     // computeRanges (Subrenderer.cpp:172-216)
-    launch_find_ranges(fp, c->sort.hi[c->sorted_index], c->sort.params, c->ranges, st);
+    if (!ranges_done) launch_find_ranges(fp, c->sort.hi[c->sorted_index], c->sort.params, c->ranges, st);
     if (int r = check_launch(c, "FindRanges")) return r;
     if (bucket) {
         // second half of the alternative sorter: per-tile depth sort (needs the ranges)
@@ -711,7 +740,7 @@ static int apply_tile_rows(gs_ctx* c, uint32_t row_begin, uint32_t row_end, uint
     const uint32_t owned_tiles = c->rows_owned * c->grid_w;
     c->band_sort_bits = num_sort_bits_for(owned_tiles ? owned_tiles : 1u);
     c->hi16 = owned_tiles <= 65535u;
-    if (c->sort_graph || c->presort_graph) {
+    if (c->sort_graph || c->presort_graph || c->chain_graph) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));   // the graph may still be executing
         drop_sort_graph(c);
     }
