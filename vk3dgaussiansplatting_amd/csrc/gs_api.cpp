@@ -311,27 +311,24 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     launch_emit(fp, c->scratch, c->sort, st);
     if (int r = check_launch(c, "InitSortList")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[2], st));
-    // gpuSort->computeSort (RadixSort.cpp:207-653)
-    if (!per_pass_events && !c->sort_graph && !c->sort_graph_failed) {
-        // capture the passes once (nothing executes during capture)
-        hipGraph_t graph = nullptr;
-        bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess;
-        if (ok) {
-            c->sort_graph_result = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, nullptr,
-                                                     bucket ? 32u : 0u, !bucket, c->hi16, tile_share);
-            ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph != nullptr;
-        }
-        if (ok) ok = hipGraphInstantiate(&c->sort_graph, graph, nullptr, nullptr, 0) == hipSuccess;
-        if (graph) (void)hipGraphDestroy(graph);
-        if (!ok) { c->sort_graph = nullptr; c->sort_graph_failed = true; (void)hipGetLastError(); }
-    }
-    if (!per_pass_events && c->sort_graph) {
-        HIP_TRY(c, hipGraphLaunch(c->sort_graph, st));
-        c->sorted_index = c->sort_graph_result;
+    // gpuSort->computeSort (RadixSort.cpp:207-653).  The passes' arguments are fixed once resolution and tile rows are:
+    // captured once, replayed as a hipGraph.  Without timers FindRanges (same property) rides in the same graph.
+    auto all_passes = [&](hipEvent_t* evs) {
+        return launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, evs, bucket ? 32u : 0u, !bucket, c->hi16, tile_share);
+    };
+    if (!tm && !bucket) {
+        const int sorted = radix_passes(c->chain_graph, c->chain_result, [&](hipEvent_t*) {
+            const int si = all_passes(nullptr);
+            launch_find_ranges(fp, c->sort.hi[si], c->sort.params, c->ranges, st);
+            return si;
+        });
+        if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+        c->sorted_index = sorted;
+        ranges_done = true;
     } else {
-        c->sorted_index = launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st,
-                                            per_pass_events ? c->scatter_ev : nullptr,
-                                            bucket ? 32u : 0u, !bucket, c->hi16, tile_share);
+        const int sorted = radix_passes(c->sort_graph, c->sort_graph_result, all_passes);
+        if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+        c->sorted_index = sorted;
     }
     }   // !splat_first
     c->depth_dropped = !bucket;
