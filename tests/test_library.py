@@ -262,3 +262,16 @@ def test_oracle_under_sanitizers(tmp_path, san):
                          [os.path.join(ROOT, "tests", "host", "sanitize_oracle.c"),
                           os.path.join(ROOT, "oracle", "gs_oracle.c")])
     assert "sanitize_oracle ok" in out
+
+
+def test_python_constants_equal_the_header():
+    """Every `#define GS_X <integer>` of include/gsplat.h that the binding mirrors has the header's value."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "gsplat.h")).read()
+    seen = 0
+    for name, val in re.findall(r"^#define\s+(GS_[A-Z0-9_]+)\s+\(?(-?\d+)u?\)?", hdr, flags=re.M):
+        if hasattr(_lib, name):
+            assert getattr(_lib, name) == int(val), name
+            seen += 1
+    assert seen >= 12
+    assert _lib.GS_SORT_RADIX4_SPLAT_FIRST == 2
