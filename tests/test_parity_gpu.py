@@ -1003,13 +1003,21 @@ def test_emit_slices_of_heavy_blocks(oracle_mod):
         for row in rows:
             assert np.array_equal(img[row * 16:row * 16 + 16], ref["image"][row * 16:row * 16 + 16])
     r.cleanup()
+    # the depth-first sorter registers the helper records from the SORTED splat list (k_sorted_sums), with and without
+    # timers (one graph)
+    for record in (1, 0):
+        r = gs.Renderer(w, h, warmup_frames=0, sort_algorithm=gs.GS_SORT_RADIX4_SPLAT_FIRST, record_timings=record)
+        r.init(sc.getResourceManager()); r.initForScene(sc)
+        for _ in range(3):
+            assert_frame_equals_oracle(r, r.draw(sc), ref)
+        r.cleanup()
 
 
 @pytest.mark.parametrize("sort", ALL_SORTS)
 def test_frames_without_timers(oracle_mod, small_cloud, sort):
     """record_timings = 0 is what production and bench.py's timed region run: the radix passes replay as a hipGraph,
     and with GS_SORT_RADIX4_SPLAT_FIRST the whole chain from the splat list to FindRanges is ONE graph (camera-free
-    kernel arguments, the helper counter cleared by a memset node).  Frames from several cameras, a change of tile
+    kernel arguments, the helper counter cleared by the chain's first kernel).  Frames from several cameras, a change of tile
     rows in between (the graphs are dropped and captured again), back to the whole frame: always the oracle's list,
     ranges and pixels."""
     w, h = 320, 180

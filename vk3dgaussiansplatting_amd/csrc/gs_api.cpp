@@ -260,7 +260,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
         // GS_SORT_RADIX4_SPLAT_FIRST: the eight passes over the depth word run on the list of emitting splats, the emit
         // walks that list, the tile-word passes finish.  InitSortList = project + lists + emit, RadixSort = all passes.
         // Nothing between the first scan and RenderGaussians depends on the camera: those kernels take a FrameParams
-        // without it (and with a fixed helper counter, cleared by a memset in front of its user), so their arguments
+        // without it (and with a fixed helper counter, cleared by the first kernel of the chain), so their arguments
         // never change and the whole chain -- FindRanges included -- replays as ONE graph when no timers are asked for.
         FrameParams fps = fp;
         std::memset(fps.view, 0, sizeof(fps.view)); std::memset(fps.proj, 0, sizeof(fps.proj));
@@ -278,7 +278,6 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
         };
         if (!tm) {
             const int sorted = radix_passes(c->chain_graph, c->chain_result, [&](hipEvent_t*) {
-                (void)hipMemsetAsync(c->scratch.help_count, 0, sizeof(uint32_t), st);
                 launch_splat_list(fps, c->scratch, c->sort, st);
                 const int presorted = depth_passes(nullptr);
                 launch_gather_sorted(fps, c->scratch, c->sort, presorted, st);
@@ -291,7 +290,6 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
             c->sorted_index = sorted;
             ranges_done = true;
         } else {
-        HIP_TRY(c, hipMemsetAsync(c->scratch.help_count, 0, sizeof(uint32_t), st));
         launch_splat_list(fps, c->scratch, c->sort, st);
         if (int r = check_launch(c, "InitSortList")) return r;
         HIP_TRY(c, hipEventRecord(c->pre_ev[0], st));

@@ -744,6 +744,8 @@ __global__ __launch_bounds__(kProjThreads) void k_splat_list(const FrameParams f
                                                               uint32_t* __restrict__ out_id) {
     __shared__ uint32_t s_cnt[kProjThreads / 64], s_flag[kProjThreads / 64];
     const uint32_t blk = blockIdx.x, g = blk * kProjThreads + threadIdx.x;
+    // the helper counter k_sorted_sums adds to (sixteen launches later): this path always uses the one of parity 0
+    if (blk == 0u && threadIdx.x == 0u) sc.help_count[fp.parity] = 0u;
     if (sc.block_sums[blk] == 0u) return;            // nothing emits (or k_band_cull rejected the block: stale arrays)
     const uint32_t cnt = g < fp.num_gaussians ? sc.tiles_touched[g] : 0u;
     const uint32_t dk = cnt != 0u ? sc.depth_key[g] : 0u;
