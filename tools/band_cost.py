@@ -1,12 +1,13 @@
 """Per-rank cost of a tile-row share on ONE GPU: what a rank of an R-way sharded frame (dist.py) spends, without the
 gather.  For each R: the middle and the first contiguous band, and the interleaved share of rank R // 2.
-    python tools/band_cost.py [C|D|Chard]"""
+    python tools/band_cost.py [C|D|Chard] [radix4|splat_first|bucket]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import vk3dgaussiansplatting_amd as gs
 from vk3dgaussiansplatting_amd import synth, dist
 name = sys.argv[1] if len(sys.argv) > 1 else "C"
+sort = {"bucket": gs.GS_SORT_TILE_BUCKET, "splat_first": gs.GS_SORT_RADIX4_SPLAT_FIRST}.get(sys.argv[2] if len(sys.argv) > 2 else "", gs.GS_SORT_RADIX4)
 cfg = synth.CONFIGS[name]
 cache = f"/dev/shm/gs_cloud_{cfg['n']}_{cfg['mu']}_{cfg['seed']}_{cfg.get('kind', 'uniform')}.npy"
 if os.path.exists(cache):
@@ -28,7 +29,7 @@ for R in (1, 2, 4, 8):
     for label, setup in shares:
         res = {}
         for rec in (0, 1):
-            r = gs.Renderer(w, h, record_timings=rec, warmup_frames=0); r.init(rm); r.initForScene(sc, share_with=owner)
+            r = gs.Renderer(w, h, record_timings=rec, warmup_frames=0, sort_algorithm=sort); r.init(rm); r.initForScene(sc, share_with=owner)
             setup(r)
             for _ in range(20): r.drawDevice(sc, None, sync=False)
             r.synchronize()
