@@ -377,46 +377,64 @@ def main():
 
     # ---- extras: three frames in flight; the other sort back-end (identical output) ----
     extras = {}
-    if not args.no_extras:
-        if F != 3:
-            r3 = Ring(3, owner=owner)
-            ms3 = r3.timed(min(args.steps, 300), 20)
-            ok3 = all(bool(torch.equal(r3.sf.strips[0], r3.sf.strips[k])) for k in range(1, 3))
-            r3.close()
-            extras["frames_in_flight_3"] = {
-                "ms_per_step": round(ms3, 4), "value": round(n / ms3 / 1000.0, 2), "unit": "Msplats/s",
+
+    def extra(name, fn):
+        # an extra must never cost the line its headline: a failure is reported in its place
+        try:
+            extras[name] = fn()
+        except Exception as ex:  # noqa: BLE001
+            log(f"[bench] extra '{name}' failed: {ex!r}")
+            extras[name] = {"error": repr(ex)}
+
+    def x_three_slots():
+        r3 = Ring(3, owner=owner)
+        ms3 = r3.timed(min(args.steps, 300), 20)
+        ok3 = all(bool(torch.equal(r3.sf.strips[0], r3.sf.strips[k])) for k in range(1, 3))
+        r3.close()
+        return {"ms_per_step": round(ms3, 4), "value": round(n / ms3 / 1000.0, 2), "unit": "Msplats/s",
                 "frame_slots_identical": ok3,
                 "note": "throughput with GfxSettings::FRAMES_IN_FLIGHT = 3 frame slots overlapping on the GPU; the "
                         "reference's published frame time is GPU time per frame, so this is NOT what vs_baseline uses"}
+
+    def x_alt_sorter():
         other = "bucket" if args.sort == "radix4" else "radix4"
         ra = Ring(1, sort=other, owner=owner)
         ms_a = ra.timed(min(args.steps, 300), 20)
         ra.close()
-        extras["alt_sorter"] = {"sort_algorithm": other, "ms_per_step": round(ms_a, 4), "value": round(n / ms_a / 1000.0, 2),
-                                "note": "GS_SORT_TILE_BUCKET = tile-word radix passes + per-tile LDS depth sort behind the "
-                                        "GpuSort seam; bit-identical output; one frame slot"}
-        if args.sort != "splat_first":
-            rs_ = Ring(1, sort="splat_first", owner=owner)
-            ms_s = rs_.timed(min(args.steps, 300), 20)
-            same = bool(torch.equal(rs_.sf.strips[0], sf_main.strips[0]))
-            rs_.close()
-            extras["splat_first_sorter"] = {
-                "sort_algorithm": "splat_first", "ms_per_step": round(ms_s, 4), "value": round(n / ms_s / 1000.0, 2),
+        return {"sort_algorithm": other, "ms_per_step": round(ms_a, 4), "value": round(n / ms_a / 1000.0, 2),
+                "note": "GS_SORT_TILE_BUCKET = tile-word radix passes + per-tile LDS depth sort behind the "
+                        "GpuSort seam; bit-identical output; one frame slot"}
+
+    def x_splat_first():
+        rs_ = Ring(1, sort="splat_first", owner=owner)
+        ms_s = rs_.timed(min(args.steps, 300), 20)
+        same = bool(torch.equal(rs_.sf.strips[0], sf_main.strips[0]))
+        rs_.close()
+        return {"sort_algorithm": "splat_first", "ms_per_step": round(ms_s, 4), "value": round(n / ms_s / 1000.0, 2),
                 "image_identical_to_default": same,
                 "note": "GS_SORT_RADIX4_SPLAT_FIRST = the same twelve 4-bit Count/Scan/Scatter passes in another order: the "
-                        "eight passes over the depth word run on the (depth, splat) list of the emitting splats, "
-                        "InitSortList's emit walks that list, the four stable tile-word passes finish; bit-identical "
+                        "eight passes over the depth word run on the (depth | tile count | splat) list of the emitting "
+                        "splats, InitSortList's emit walks that list, the four stable tile-word passes finish; bit-identical "
                         "keys, ranges and pixels; one frame slot.  Not the default: the default keeps the reference's "
                         "stage order (InitSortList, then all passes over the 64-bit keys)"}
-        if args.mode == "exact":
-            rf_ = Ring(1, owner=owner, render_mode=gs.GS_RENDER_FAST)
-            ms_f = rf_.timed(min(args.steps, 300), 20)
-            rf_.close()
-            extras["fast_render_mode"] = {
-                "ms_per_step": round(ms_f, 4), "value": round(n / ms_f / 1000.0, 2),
+
+    def x_fast_render():
+        rf_ = Ring(1, owner=owner, render_mode=gs.GS_RENDER_FAST)
+        ms_f = rf_.timed(min(args.steps, 300), 20)
+        rf_.close()
+        return {"ms_per_step": round(ms_f, 4), "value": round(n / ms_f / 1000.0, 2),
                 "note": "GS_RENDER_FAST: fused multiply-adds + hardware exp2 in RenderGaussians; within north_star's tolerance "
                         "(<= 1 step per 8-bit channel against the oracle, tests), keys and ranges unchanged; the default and "
                         "the headline stay bit-exact"}
+
+    if not args.no_extras:
+        if F != 3:
+            extra("frames_in_flight_3", x_three_slots)
+        extra("alt_sorter", x_alt_sorter)
+        if args.sort != "splat_first":
+            extra("splat_first_sorter", x_splat_first)
+        if args.mode == "exact":
+            extra("fast_render_mode", x_fast_render)
     owner.setStream(None)
     owner.cleanup()
 
