@@ -873,14 +873,15 @@ def test_host_timers(small_cloud):
     r.cleanup()
 
 
-def test_grid_beyond_16_bit_tile_ids(oracle_mod):
+@pytest.mark.parametrize("sort", [gs.GS_SORT_RADIX4, gs.GS_SORT_RADIX4_SPLAT_FIRST])
+def test_grid_beyond_16_bit_tile_ids(oracle_mod, sort):
     """More than 65535 tiles: tile ids no longer fit the 16-bit sort-list words, so the frame falls back to 32-bit
-    tile words (gs_scene_info.tile_word_bytes == 4); a half-frame band of the same grid fits again (== 2).  Keys,
-    ranges and pixels equal the oracle's in both layouts."""
+    tile words (gs_scene_info.tile_word_bytes == 4; the depth-first sorter's tile counts ride as 32-bit words too); a
+    half-frame band of the same grid fits again (== 2).  Keys, ranges and pixels equal the oracle's in both layouts."""
     w, h = 4096, 4112                                          # 256 x 257 = 65792 tiles
     aos = synth.generate(600, w, h, -3.5, seed=5)
     sc = make_scene(aos, w, h)
-    r = make_renderer(sc, w, h)
+    r = make_renderer(sc, w, h, sort=sort)
     assert r.sceneInfo().tile_word_bytes == 4
     img = r.draw(sc)
     _, ref = oracle_run(oracle_mod, sc, w, h)
