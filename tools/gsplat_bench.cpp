@@ -4,7 +4,7 @@
 // Renderer.cpp:477-510 does, and print them.
 //
 //   gsplat_bench <scene.ply | --synthetic N> [--scene garden|train|bicycle|origin] [--res WxH]
-//                [--warmup F] [--frames F] [--fast] [--out frame.png|frame.ppm]
+//                [--warmup F] [--frames F] [--fast] [--sort radix4|splat_first|bucket] [--out frame.png|frame.ppm]
 #include "../include/gsplat.h"
 
 #include <cmath>
@@ -23,7 +23,7 @@ static uint64_t sm(uint64_t& s) {
 static float uni(uint64_t& s) { return (float)((sm(s) >> 40) * (1.0 / 16777216.0)); }
 
 int main(int argc, char** argv) {
-    std::string ply, scene = "origin", ppm;
+    std::string ply, scene = "origin", ppm, sort = "radix4";   // GPU_SORT_ALGORITHM (Renderer.h:33)
     uint32_t n_syn = 0, w = 1280, h = 720, warmup = 1000, frames = 1000;   // window 1280x720: Engine.cpp:35; WAIT_ELAPSED_*_FRAMES_FOR_AVG: Renderer.h:142-143
     bool fast = false;
     for (int i = 1; i < argc; ++i) {
@@ -35,12 +35,14 @@ int main(int argc, char** argv) {
         else if (a == "--frames" && i + 1 < argc) frames = (uint32_t)atol(argv[++i]);
         else if ((a == "--out" || a == "--ppm") && i + 1 < argc) ppm = argv[++i];
         else if (a == "--fast") fast = true;
+        else if (a == "--sort" && i + 1 < argc) sort = argv[++i];
         else ply = a;
     }
     if (ply.empty() && !n_syn) { fprintf(stderr, "usage: gsplat_bench <scene.ply | --synthetic N> [...]\n"); return 2; }
 
     gs_config cfg; gs_default_config(&cfg);
     cfg.render_mode = fast ? GS_RENDER_FAST : GS_RENDER_EXACT;
+    cfg.sort_algorithm = sort == "splat_first" ? GS_SORT_RADIX4_SPLAT_FIRST : sort == "bucket" ? GS_SORT_TILE_BUCKET : GS_SORT_RADIX4;
     cfg.record_timings = 1;                                  // RECORD_GPU_TIMES (GfxSettings.h:7) on: this is the benchmark build
     gs_ctx* ctx = nullptr;
     if (gs_create(&cfg, &ctx) != GS_OK) { fprintf(stderr, "[Log Error]: %s\n", gs_last_error(nullptr)); return 1; }
