@@ -936,10 +936,13 @@ def test_rccl_calls_of_the_sharded_frame_single_rank(tmp_path):
     behind the producing stream, all_reduce(MAX) of a float64, all_gather, barrier.  World size 1 is all one card
     allows (RCCL refuses two ranks on one device); the N > 1 plumbing is covered over gloo in tests/test_dist.py and
     tests/test_bench_launcher.py.  Runs in a child process so that this process never holds a communicator."""
-    import subprocess, sys, textwrap
+    import socket, subprocess, sys, textwrap
+    with socket.socket() as sk:                       # a port nobody listens on right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     code = textwrap.dedent("""
         import os, torch, torch.distributed as tdist
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="@PORT@", RANK="0", WORLD_SIZE="1")
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
         tdist.init_process_group(backend="nccl", device_id=dev)
@@ -962,7 +965,7 @@ def test_rccl_calls_of_the_sharded_frame_single_rank(tmp_path):
         assert float(el.item()) == 1.25 and torch.equal(got[0], stats)
         tdist.destroy_process_group()
         print("rccl-ok")
-    """)
+    """).replace("@PORT@", str(port))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0 and "rccl-ok" in p.stdout, p.stderr[-2000:]
