@@ -88,7 +88,11 @@ typedef struct gs_config {
 
 /* The five buckets of Renderer.cpp:471-475 (ms) + the sort element count ("Elements To Sort"
  * in README.md:43-93).  InitSortList includes the per-frame clears, RadixSort includes the
- * IndirectSetup-equivalent, exactly like the reference's timestamp placement (Renderer.cpp:557-622). */
+ * IndirectSetup-equivalent, exactly like the reference's timestamp placement (Renderer.cpp:557-622).
+ * With GS_SORT_RADIX4_SPLAT_FIRST the two stages interleave (project + splat list | depth passes | sums + emit |
+ * tile-word passes): init_sort_list_ms and radix_sort_ms are the sums of their two halves, and with
+ * record_timings == 2 scatter_* describe the depth passes over the SPLAT list (bytes per splat), scatter_tile_* the
+ * tile-word passes over the elements. */
 typedef struct gs_timings {
     float init_sort_list_ms;
     float radix_sort_ms;
