@@ -496,59 +496,81 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
 // It also does the frame's clears (computeInitSortList's fills, Subrenderer.cpp:42-60): the tile ranges and the
 // per-pass coarse digit totals of the sort -- two fill launches less per frame.
 struct ScanJob { const uint32_t* sums; uint32_t* offsets; SortParams* params; uint32_t capacity; };
-__global__ __launch_bounds__(1024) void k_scan_blocks(const ScanJob job0, const ScanJob job1, uint32_t num_blocks,
+constexpr uint32_t kScanClearWgs = 8;   // workgroups behind the scanning ones: the frame's clears, beside the scan
+__global__ __launch_bounds__(1024) void k_scan_blocks(const ScanJob job0, const ScanJob job1, uint32_t jobs, uint32_t num_blocks,
                                                        uint4* __restrict__ zero_a, uint32_t n16_a,
                                                        uint4* __restrict__ zero_b, uint32_t n16_b,
                                                        uint32_t* __restrict__ next_help_count) {
-    // workgroup 0: the list of elements (+ the clears); workgroup 1, when launched: a second, independent scan
+    if (blockIdx.x >= jobs) {
+        const uint32_t k = blockIdx.x - jobs;
+        if (k == 0u && threadIdx.x == 0 && next_help_count) { next_help_count[0] = 0u; next_help_count[2] = 0u; }   // what the NEXT InitSortList launch adds to
+        for (uint32_t i = k * 1024u + threadIdx.x; i < n16_a; i += kScanClearWgs * 1024u) zero_a[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t i = k * 1024u + threadIdx.x; i < n16_b; i += kScanClearWgs * 1024u) zero_b[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    // workgroup 0: the list of elements; workgroup 1, when asked for: a second, independent scan
     const ScanJob job = blockIdx.x == 0 ? job0 : job1;
     const uint32_t* __restrict__ block_sums = job.sums;
     uint32_t* __restrict__ block_offsets = job.offsets;
     SortParams* params = job.params;
     const uint32_t capacity = job.capacity;
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0 && next_help_count) { next_help_count[0] = 0u; next_help_count[2] = 0u; }   // what the NEXT InitSortList launch adds to
-        for (uint32_t i = threadIdx.x; i < n16_a; i += 1024u) zero_a[i] = make_uint4(0u, 0u, 0u, 0u);
-        for (uint32_t i = threadIdx.x; i < n16_b; i += 1024u) zero_b[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
     __shared__ uint64_t s_wave_tot[16];
-    __shared__ uint64_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t per = (((num_blocks + 1023u) / 1024u) + 3u) & ~3u;
     const uint4* in4 = reinterpret_cast<const uint4*>(block_sums + (size_t)tid * per);
     uint4* out4 = reinterpret_cast<uint4*>(block_offsets + (size_t)tid * per);
+    auto sat = [](uint64_t x) { return (uint32_t)(x > 0xFFFFFFFFull ? 0xFFFFFFFFull : x); };
+    constexpr uint32_t kHeld = 8;            // 16-byte groups a thread keeps in registers: up to 32 K blocks = 8.4 M splats
+    const bool held = per / 4 <= kHeld;
+    uint4 v[kHeld];
     uint64_t sum = 0;
+    if (held) {
+#pragma unroll
+        for (uint32_t i = 0; i < kHeld; ++i) v[i] = i < per / 4 ? in4[i] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (uint32_t i = 0; i < kHeld; ++i) sum += (uint64_t)v[i].x + v[i].y + v[i].z + v[i].w;
+    } else {
 #pragma unroll 4
-    for (uint32_t i = 0; i < per / 4; ++i) {
-        const uint4 v = in4[i];
-        sum += (uint64_t)v.x + v.y + v.z + v.w;
+        for (uint32_t i = 0; i < per / 4; ++i) {
+            const uint4 w = in4[i];
+            sum += (uint64_t)w.x + w.y + w.z + w.w;
+        }
     }
     const uint64_t inc = wave_inclusive_scan64(sum);
     if (lane == 63) s_wave_tot[wave] = inc;
     __syncthreads();
     uint64_t run = inc - sum;
     for (int w = 0; w < wave; ++w) run += s_wave_tot[w];
-    if (tid == 1023) s_carry = run + sum;
-    auto sat = [](uint64_t x) { return (uint32_t)(x > 0xFFFFFFFFull ? 0xFFFFFFFFull : x); };
-#pragma unroll 4
-    for (uint32_t i = 0; i < per / 4; ++i) {
-        const uint4 v = in4[i];
-        uint4 o;
-        o.x = sat(run); run += v.x;
-        o.y = sat(run); run += v.y;
-        o.z = sat(run); run += v.z;
-        o.w = sat(run); run += v.w;
-        out4[i] = o;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const uint64_t counter = s_carry;
+    if (tid == 1023) {
+        const uint64_t counter = run + sum;
         const uint32_t e = counter < capacity ? (uint32_t)counter : capacity; // IndirectSetup.comp:28
         params->counter = counter;
         params->num_elems = e;
         params->num_groups = (e + kSortTile - 1) / kSortTile;
         params->groups_per_seg = (params->num_groups + kSegments - 1) / kSegments;
         params->overflow = counter > capacity ? 1u : 0u;
+    }
+    if (held) {
+#pragma unroll
+        for (uint32_t i = 0; i < kHeld; ++i) {
+            uint4 o;
+            o.x = sat(run); run += v[i].x;
+            o.y = sat(run); run += v[i].y;
+            o.z = sat(run); run += v[i].z;
+            o.w = sat(run); run += v[i].w;
+            if (i < per / 4) out4[i] = o;
+        }
+    } else {
+#pragma unroll 4
+        for (uint32_t i = 0; i < per / 4; ++i) {
+            const uint4 w = in4[i];
+            uint4 o;
+            o.x = sat(run); run += w.x;
+            o.y = sat(run); run += w.y;
+            o.z = sat(run); run += w.z;
+            o.w = sat(run); run += w.w;
+            out4[i] = o;
+        }
     }
 }
 
@@ -718,7 +740,8 @@ void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParam
     const ScanJob elements{sc.block_sums, sc.block_offsets, params, fp.capacity};
     // GS_SORT_RADIX4_SPLAT_FIRST: the emitting splats are scanned beside the elements (a second workgroup)
     const ScanJob splats{sc.block_flags, sc.flag_offsets, sc.aux_params, fp.num_gaussians};
-    hipLaunchKernelGGL(k_scan_blocks, dim3(fp.splat_first ? 2 : 1), dim3(1024), 0, stream, elements, splats, blocks,
+    const uint32_t jobs = fp.splat_first ? 2u : 1u;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(jobs + kScanClearWgs), dim3(1024), 0, stream, elements, splats, jobs, blocks,
                        reinterpret_cast<uint4*>(ranges), n16_ranges, reinterpret_cast<uint4*>(coarse), n16_coarse,
                        sc.help_count + (fp.parity ^ 1u));
 }
@@ -827,7 +850,7 @@ void launch_gather_sorted(const FrameParams& fp, const SplatScratch& sc, const S
     // the offsets of the 256-position blocks of the sorted list (the dispatch record of the elements stays the first
     // scan's: same length, and it knows about an overflow)
     const ScanJob sorted_blocks{sc.sorted_sums, sc.block_offsets, sc.aux_params + 1, fp.capacity};
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, sorted_blocks, sorted_blocks, blocks,
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, sorted_blocks, sorted_blocks, 1u, blocks,
                        (uint4*)nullptr, 0u, (uint4*)nullptr, 0u, (uint32_t*)nullptr);
 }
 
