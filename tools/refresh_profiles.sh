@@ -12,6 +12,7 @@ if [ "${1:-}" = "--install" ]; then
   cp $(find $src/kstats -name p_kernel_stats.csv | head -1) profiles/${r}_bench_configC_kernel_stats.csv
   cp $src/kstats_sf.txt profiles/${r}_bench_configC_splat_first_kernel_stats.txt
   cp $src/pmc_frame.txt profiles/${r}_pmc_frame_traffic_configC.txt
+  python tools/pmc_scatter_json.py > /dev/null   # gpurun_out/pmc_frame/traffic.json -> profiles/r02_pmc_scatter.json
   cp $src/pmc_sq.txt profiles/${r}_pmc_sq_frame_configC.txt
   for c in C D; do cp $src/band_$c.txt profiles/${r}_band_cost_config$c.txt; cp $src/band_${c}_sf.txt profiles/${r}_band_cost_config${c}_splat_first.txt; done
   ls -la profiles | tail -25
@@ -26,7 +27,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/k
   && python tools/kstats.py $(find $out/kstats -name p_kernel_stats.csv | head -1) > $out/kstats.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kstats_sf -o p -- python bench.py --sort splat_first --steps 200 --warmup 20 --no-extras --no-cpu-baseline > $out/kstats_sf_bench.json 2> $out/kstats_sf.err \
   && python tools/kstats.py $(find $out/kstats_sf -name p_kernel_stats.csv | head -1) > $out/kstats_sf.txt
-tools/pmc_frame.sh > $out/pmc_frame.txt 2>&1 && python tools/pmc_scatter_json.py > /dev/null
+tools/pmc_frame.sh > $out/pmc_frame.txt 2>&1 && cp gpurun_out/pmc_frame/traffic.json $out/traffic.json
 tools/pmc_sq.sh > $out/pmc_sq.txt 2>&1
 for c in C D; do
   timeout -k 10 250 python tools/band_cost.py $c > $out/band_$c.txt 2>&1
