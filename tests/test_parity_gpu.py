@@ -813,10 +813,11 @@ def test_randomized_frames(oracle_mod):
     compared with the oracle in full (counter, keys, payload order, ranges, pixels).  Element counts land on both
     sides of every group / wave / batch boundary of the kernels."""
     from vk3dgaussiansplatting_amd import dist as gsdist
-    rng = np.random.default_rng(20240807)
+    # GS_RANDOM_CASES / GS_RANDOM_SEED: a longer or different run of the same generator (one-off soak, not the suite)
+    rng = np.random.default_rng(int(os.environ.get("GS_RANDOM_SEED", "20240807")))
     kernels = [gs.GS_RENDER_KERNEL_AUTO, gs.GS_RENDER_KERNEL_WAVE_1PX, gs.GS_RENDER_KERNEL_WAVE_2PX,
                gs.GS_RENDER_KERNEL_WAVE_4PX, gs.GS_RENDER_KERNEL_WORKGROUP]
-    for case in range(60):
+    for case in range(int(os.environ.get("GS_RANDOM_CASES", "60"))):
         n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 2047, 2048, 2049, 4000, 6000]))
         w, h = int(rng.integers(1, 500)), int(rng.integers(1, 300))
         mu = float(rng.uniform(-4.0, -1.0))
