@@ -35,7 +35,8 @@ WORKLOADS = {"A": "synthetic 100k @ 640x360", "B": "Train-7k shape: 559,263 gaus
              "D": "Garden-30k shape: 5,834,784 gaussians @ 3840x2160",
              "E": "stress: 50,000,000 synthetic gaussians @ 1920x1080",
              "Chard": "Garden-30k shape, clustered / anisotropic / opaque cloud: 5,834,784 gaussians @ 1920x1080"}
-PMC_SCATTER_FILE = os.path.join(ROOT, "profiles", "r02_pmc_scatter.json")
+IC_BYTES = 256 << 20          # Infinity Cache (MI355X_MICROARCH.md): a pass whose buffers fit is served on-die
+DEPTH_SCATTERS = {"k_scatter<4,4,": 3, "k_scatter<4,2,": 1, "k_scatter<2,2,": 3, "k_scatter<2,0,": 1}   # launches per frame
 
 
 def log(*a):
@@ -65,6 +66,9 @@ def parse_args(argv=None):
                          "whose splat density varies over the height of the frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the alternative sorter / frames-in-flight extras")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic; "
+                         "traffic is then null and roofline.frac falls back to the bytes the layout moves")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: the ranks run only the launcher / process-group / strip-gather plumbing on the CPU "
                          "(gloo) with a fill pattern in place of the band render and print the JSON skeleton "
@@ -87,6 +91,53 @@ def launch_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def pmc_traffic(args):
+    """HBM bytes per kernel launch, measured in THIS run: two child processes of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the two do not fit the TCC counter slots
+    together; FETCH_SIZE is doubled for gfx950 -- MI355X_MICROARCH.md, HBM section), a few frames each, started before
+    this process touches the GPU (fresh children, program directly behind `--`).  Returns {kernel name without
+    spaces: {"launches", "read_bytes", "write_bytes"}} or a string saying why there is no measurement."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="gs_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", "3", "--warmup", "1",
+             "--no-extras", "--no-cpu-baseline", "--no-pmc", "--mode", args.mode, "--sort", args.sort,
+             "--render-kernel", args.render_kernel]
+    env = dict(os.environ, TMPDIR="/tmp")
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            t0 = time.time()
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--"]
+                               + child, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    k = per.setdefault(row["Kernel_Name"].split("(")[0].replace("void ", "").replace("gs::", "").replace(" ", ""),
+                                       {"FETCH_SIZE": [], "WRITE_SIZE": []})
+                    k[counter].append(float(row["Counter_Value"]))
+            log(f"[bench] rocprofv3 --pmc {counter}: {time.time() - t0:.1f}s")
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError) as ex:
+        return f"PMC child run failed: {ex!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for k, v in per.items():
+        if v["FETCH_SIZE"] and v["WRITE_SIZE"]:
+            res[k] = {"launches": len(v["FETCH_SIZE"]),
+                      "read_bytes": 2.0 * 1024.0 * sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]),   # KB; x2: gfx950 tallies 128-B requests as 64 B
+                      "write_bytes": 1024.0 * sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])}
+    return res or "no kernels in the counter files"
 
 
 def dry_run(args, world, rank):
@@ -176,6 +227,15 @@ def main():
         args.config = "C" if world == 1 else "D"
     if args.dry_run:
         sys.exit(dry_run(args, world, rank))
+
+    # roofline.traffic: measured by child runs under rocprofv3 --pmc before this process initialises the GPU
+    pmc = "not measured (--no-pmc)" if args.no_pmc else "not measured (one-GPU runs of the radix4 / splat_first sorters only)"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        pmc = "not measured (this process already runs under rocprofv3)"
+    elif world == 1 and not args.no_pmc and not args.rehearse and args.sort != "bucket":
+        pmc = pmc_traffic(args)
+        if isinstance(pmc, str):
+            log(f"[bench] roofline.traffic unavailable: {pmc}")
 
     # stdout carries exactly ONE JSON line: anything a library prints there meanwhile (gloo/RCCL banners)
     # is sent to stderr by pointing fd 1 at fd 2 until the result is ready
@@ -427,7 +487,64 @@ def main():
                         "(<= 1 step per 8-bit channel against the oracle, tests), keys and ranges unchanged; the default and "
                         "the headline stay bit-exact"}
 
-    if not args.no_extras:
+    def x_hard_cloud():
+        # the headline cloud fills the frustum like fog (every tile list about the mean length); this one has the
+        # Garden-30k shape too (same N, E within 0.1 % of README.md:61) but behaves like a capture: clusters, a ground
+        # plane, needles and discs, near-opaque splats -- tile lists from tens to tens of thousands of entries
+        t_g = time.time()
+        aos_h = synth.generate_config("Chard")[0]
+        log(f"[bench] config Chard generated in {time.time() - t_g:.1f}s")
+        rm_h = gs.ResourceManager()
+        rm_h.setGaussians(aos_h)
+        scene_h = gs.Scene(rm_h, aspect_ratio=w / h)
+        scene_h.getCamera().setPosition((0.0, 0.0, 0.0))
+        scene_h.getCamera().setRotation(0.0, 0.0)
+        scene_h.getCamera().recalculate()
+        img = torch.empty((h, w, 4), dtype=torch.uint8, device=device)
+        cur = torch.cuda.current_stream().cuda_stream
+
+        def mk(record, share=None):
+            r = gs.Renderer(w, h, device=local_rank, render_mode=mode, record_timings=record, warmup_frames=0,
+                            sort_algorithm=sort_ids[args.sort],
+                            render_kernel=0 if args.render_kernel == "auto" else int(args.render_kernel))
+            r.init(rm_h)
+            r.initForScene(scene_h, share_with=share)
+            r.setStream(cur)
+            return r
+        r0 = mk(0)
+        k_h = min(args.steps, 200)
+        for _ in range(5):
+            r0.drawDevice(scene_h, img.data_ptr(), sync=False)
+        torch.cuda.synchronize()
+        t_b = time.perf_counter()
+        for _ in range(k_h):
+            r0.drawDevice(scene_h, img.data_ptr(), sync=False)
+        torch.cuda.synchronize()
+        ms_h = (time.perf_counter() - t_b) / k_h * 1e3
+        r1 = mk(1, share=r0)
+        bk = np.zeros(5)
+        k_b = max(5, min(args.steps, 50))
+        for i in range(3 + k_b):
+            r1.drawDevice(scene_h, img.data_ptr(), sync=True)
+            if i >= 3:
+                t_ = r1.timings()
+                bk += [t_.init_sort_list_ms, t_.radix_sort_ms, t_.find_ranges_ms, t_.render_ms, t_.total_ms]
+        e_h = int(r1.timings().num_sort_elements)
+        for r_ in (r1, r0):
+            r_.setStream(None)
+            r_.cleanup()
+        ref_c = REF_MS["C"]
+        return {"workload": WORKLOADS["Chard"], "sort_elements": e_h, "ms_per_step": round(ms_h, 4),
+                "value": round(n / ms_h / 1000.0, 2), "unit": "Msplats/s",
+                "vs_baseline": round(ref_c[1] / ms_h, 3),
+                "buckets_ms": {k_: round(float(v_), 4) for k_, v_ in zip(
+                    ["init_sort_list", "radix_sort", "find_ranges", "render", "total"], bk / k_b)},
+                "note": "same protocol as the headline (one frame slot, image left in HBM); vs_baseline against the same "
+                        "README frame (28.499 ms), which was a real capture"}
+
+    # extras run collectives of their own (Ring.timed): with several ranks one rank failing inside an extra would leave
+    # the others waiting in it, so they are a one-GPU feature
+    if not args.no_extras and world == 1:
         if F != 3:
             extra("frames_in_flight_3", x_three_slots)
         extra("alt_sorter", x_alt_sorter)
@@ -435,6 +552,8 @@ def main():
             extra("splat_first_sorter", x_splat_first)
         if args.mode == "exact":
             extra("fast_render_mode", x_fast_render)
+        if args.config == "C":
+            extra("hard_cloud", x_hard_cloud)
     owner.setStream(None)
     owner.cleanup()
 
@@ -477,66 +596,107 @@ def main():
         e_total = int(sum(float(s[0]) for s in allstats))
         value = n / ms_per_step / 1000.0            # Msplats/s, whole job
         ref = REF_MS.get(args.config) if world == 1 else None
-        # Roofline of the dominant kernel, k_scatter's depth-word passes.  ALGORITHMIC bytes = SURVEY 8(d): 12 B read +
-        # 12 B written per element and launch.  This layout moves fewer (16-bit tile ids, depth words that shrink as
-        # their digits are consumed), so the rate on the bytes really moved is reported beside it, against the 8 TB/s
-        # datasheet peak and against the stream-copy rate measured on this GPU.
-        alg_bytes = 24.0 * e_rank
-        achieved = alg_bytes / (scat * 1e-3) / 1e9 if scat > 0 else 0.0
-        achieved_moved = moved_full * e_rank / (scat * 1e-3) / 1e9 if scat > 0 else 0.0
-        traffic = None
-        try:
-            with open(PMC_SCATTER_FILE) as f:
-                pmc = json.load(f)
-            if pmc["elements"] == e_rank and pmc.get("tile_word_bytes", 4) == int(info.tile_word_bytes):
-                traffic = pmc["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # Roofline of the dominant kernel, k_scatter's depth-word passes (they carry key + payload).  `achieved` / `frac`
+        # describe what HBM sees: the PMC bytes of those launches measured in this run (pmc_traffic) over the mean launch
+        # duration (HIP event pair around every such launch, on its stream), or -- when no PMC measurement could be made
+        # -- the bytes the layout reads + writes.  SURVEY 8(d)'s algorithmic figure (12 B read + 12 B written per element
+        # and launch) is kept beside it; this layout moves fewer bytes than that "packed minimum" (16-bit tile ids, depth
+        # words that shrink as their digits are consumed: 220 E per sort instead of 384 E), so the algorithmic fraction
+        # can exceed 1 and says nothing about HBM utilisation.
+        def rate(nbytes, ms):
+            return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+
+        def pmc_bytes(prefixes):
+            """mean HBM bytes per launch over the kernels whose name starts with one of the prefixes, or None"""
+            if not isinstance(pmc, dict):
+                return None
+            tot = n_l = 0.0
+            for k, v in pmc.items():
+                if any(k.startswith(p_) for p_ in prefixes):
+                    tot += v["launches"] * (v["read_bytes"] + v["write_bytes"])
+                    n_l += v["launches"]
+            return tot / n_l if n_l else None
+
+        moved_launch = moved_full * e_rank
+        traffic = pmc_bytes(tuple(DEPTH_SCATTERS)) if args.sort == "radix4" else None
+        basis_bytes = traffic if traffic else moved_launch
+        achieved = rate(basis_bytes, scat)
+        # the whole sort stage: every Count and Scatter launch of the frame over the RadixSort bucket
+        twb = int(info.tile_word_bytes)
+        count_bytes = (4 * min(passes_full, 4) + 2 * max(passes_full - 4, 0) + twb * passes_tile) * e_rank
+        stage_moved = count_bytes + (moved_full * passes_full + moved_tile * passes_tile) * e_rank
+        stage_traffic = None
+        if isinstance(pmc, dict) and args.sort == "radix4":
+            frames = max(1.0, sum(v["launches"] for k, v in pmc.items() if k.startswith("k_scatter")) / max(passes_full + passes_tile, 1))
+            stage_traffic = sum(v["launches"] * (v["read_bytes"] + v["write_bytes"]) for k, v in pmc.items()
+                                if k.startswith(("k_scatter", "k_count"))) / frames
+        sort_ms = float(buckets[1])
+        stage_bytes = stage_traffic if stage_traffic else stage_moved
         roofline = {
             "bound": "hbm",
             "kernel": "k_scatter, the depth-word passes (radix Scatter moving key + payload, one launch per 4-bit pass)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-            "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2, MI355X_MICROARCH.md) + WRITE_SIZE, "
-                            "separate passes, of this build at this E (profiles/r02_pmc_scatter.json); null when no "
-                            "matching profile is committed",
-            "alg_bytes_per_launch": alg_bytes, "alg_bytes_per_element": 24.0,
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "basis": "pmc" if traffic else "moved",
+            "traffic": round(traffic) if traffic else None,
+            "traffic_note": ("HBM bytes per launch measured in this run: child runs of this command under rocprofv3 --pmc "
+                             "FETCH_SIZE (x2 on gfx950, MI355X_MICROARCH.md) and --pmc WRITE_SIZE, separate passes, mean over "
+                             "the depth-word Scatter launches") if traffic else (pmc if isinstance(pmc, str) else "no depth-word Scatter launches in the counters"),
             "avg_launch_ms": round(scat, 5), "launches_per_frame": passes_full,
-            "moved": {"bytes_per_element": moved_full, "achieved": round(achieved_moved, 1),
-                      "frac_of_peak": round(achieved_moved / HBM_PEAK_GBPS, 4),
-                      "frac_of_measured_copy": round(achieved_moved / copy_gbps, 4) if copy_gbps else None,
-                      "frac_of_copy_at_pass_footprint": round(achieved_moved / copy_fp_gbps, 4) if copy_fp_gbps else None,
-                      "frac_of_guide_copy": round(achieved_moved / HBM_GUIDE_COPY_GBPS, 4)},
+            "moved": {"bytes_per_element": moved_full, "bytes_per_launch": moved_launch,
+                      "achieved": round(rate(moved_launch, scat), 1),
+                      "frac_of_peak": round(rate(moved_launch, scat) / HBM_PEAK_GBPS, 4),
+                      "frac_of_measured_copy": round(rate(moved_launch, scat) / copy_gbps, 4) if copy_gbps else None,
+                      "frac_of_copy_at_pass_footprint": round(rate(moved_launch, scat) / copy_fp_gbps, 4) if copy_fp_gbps else None,
+                      "frac_of_guide_copy": round(rate(moved_launch, scat) / HBM_GUIDE_COPY_GBPS, 4)},
+            "algorithmic": {"bytes_per_element": 24.0, "bytes_per_launch": 24.0 * e_rank,
+                            "achieved": round(rate(24.0 * e_rank, scat), 1),
+                            "frac": round(rate(24.0 * e_rank, scat) / HBM_PEAK_GBPS, 4),
+                            "note": "SURVEY 8(d): 12 B read + 12 B written per element and launch; the layout moves fewer, so "
+                                    "this can exceed 1 -- not an HBM utilisation"},
+            "stage": {"what": "every Count + Scatter launch of the frame over the RadixSort bucket",
+                      "ms": round(sort_ms, 4), "moved_bytes": stage_moved,
+                      "traffic": round(stage_traffic) if stage_traffic else None,
+                      "achieved": round(rate(stage_bytes, sort_ms), 1),
+                      "frac": round(rate(stage_bytes, sort_ms) / HBM_PEAK_GBPS, 4),
+                      "basis": "pmc" if stage_traffic else "moved"},
+            "infinity_cache_resident": bool(moved_launch < IC_BYTES),
+            "infinity_cache_note": f"one depth-word pass reads + writes {moved_launch / 2**20:.0f} MiB against the 256 MiB Infinity "
+                                   "Cache: when it fits, part of the traffic above is served on-die (the PMC counters sit on the "
+                                   "L2's fabric side and include those hits)",
             "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None, "measured_copy_probe": copy_kind,
             "measured_copy_note": "device-to-device copy, 1 GiB per buffer (HBM-resident), best probe shape",
             "measured_copy_at_pass_footprint_GBps": round(copy_fp_gbps, 1) if copy_fp_gbps else None,
             "measured_copy_at_pass_footprint": f"{fp_bytes} bytes per buffer (what one such launch reads), {copy_fp_kind}",
             "guide_copy_GBps": HBM_GUIDE_COPY_GBPS,
-            "note": "achieved/frac: SURVEY 8(d)'s algorithmic 24 B per element over the mean launch duration (HIP event "
-                    "pair around every such launch, on its stream); moved: the bytes this layout really reads + writes "
-                    "per element, over the same duration",
         }
         if args.sort == "splat_first":
             # the depth passes run over the splat list (a quarter of the elements, latency-bound launches): the dominant
-            # HBM kernel of the sort is the tile-word pass, and SURVEY 8(d)'s 24 B per element no longer describes what a
-            # launch has to move (a tile word + a splat index, read and written) -- so `achieved` is the moved bytes here
-            mv = moved_tile * e_rank / (scat_tile * 1e-3) / 1e9 if scat_tile > 0 else 0.0
+            # HBM kernel of the sort is the tile-word pass
+            mv = rate(moved_tile * e_rank, scat_tile)
+            tr = pmc_bytes(("k_scatter<0,0,",))
+            ach = rate(tr, scat_tile) if tr else mv
             roofline = {
                 "bound": "hbm", "kernel": "k_scatter<0, 0, .> (tile-word passes of GS_SORT_RADIX4_SPLAT_FIRST)",
-                "achieved": round(mv, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(mv / HBM_PEAK_GBPS, 4),
-                "traffic": None, "alg_bytes_per_launch": moved_tile * e_rank, "alg_bytes_per_element": moved_tile,
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                "basis": "pmc" if tr else "moved", "traffic": round(tr) if tr else None,
                 "avg_launch_ms": round(scat_tile, 5), "launches_per_frame": passes_tile,
-                "frac_of_measured_copy": round(mv / copy_gbps, 4) if copy_gbps else None,
+                "moved": {"bytes_per_element": moved_tile, "bytes_per_launch": moved_tile * e_rank, "achieved": round(mv, 1),
+                          "frac_of_peak": round(mv / HBM_PEAK_GBPS, 4),
+                          "frac_of_measured_copy": round(mv / copy_gbps, 4) if copy_gbps else None},
                 "measured_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
+                "infinity_cache_resident": bool(moved_tile * e_rank < IC_BYTES),
                 "depth_passes_over_splats": {"avg_launch_ms": round(scat, 5), "launches_per_frame": passes_full,
-                                             "bytes_per_splat": moved_full},
-                "note": "achieved = bytes moved per launch (tile word + splat index, read + written) over the mean launch "
-                        "duration (HIP event pair around every such launch)"}
+                                             "bytes_per_splat": moved_full}}
         elif passes_tile:
-            mv = moved_tile * e_rank / (scat_tile * 1e-3) / 1e9 if scat_tile > 0 else 0.0
+            mv = rate(moved_tile * e_rank, scat_tile)
+            tr = pmc_bytes(("k_scatter<0,0,",))
             roofline["tile_word_passes"] = {
                 "kernel": "k_scatter<0, 0, .> (tile-word passes: depth words not carried)",
                 "avg_launch_ms": round(scat_tile, 5), "launches_per_frame": passes_tile,
+                "traffic": round(tr) if tr else None,
+                "achieved": round(rate(tr, scat_tile) if tr else mv, 1),
+                "frac": round((rate(tr, scat_tile) if tr else mv) / HBM_PEAK_GBPS, 4),
                 "moved": {"bytes_per_element": moved_tile, "achieved": round(mv, 1),
                           "frac_of_peak": round(mv / HBM_PEAK_GBPS, 4),
                           "frac_of_measured_copy": round(mv / copy_gbps, 4) if copy_gbps else None}}
@@ -570,7 +730,8 @@ def main():
         }
         out.update(extras)
         if world > 1:
-            out["rccl_ranks"] = tdist.get_world_size()
+            out["world_size"] = tdist.get_world_size()
+            out["backend"] = tdist.get_backend()     # "nccl" = RCCL over xGMI; "gloo" only under --rehearse
             out["rank_devices"] = [int(s[7]) for s in allstats]
             out["sharded_image_matches_single_gpu"] = sharded_ok
             out["per_rank_total_ms"] = [round(float(s[6]), 4) for s in allstats]

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GS_API_VERSION 1
+#define GS_API_VERSION 2   /* 2: gs_config grew tile_order */
 
 /* status codes */
 #define GS_OK 0
@@ -70,6 +70,10 @@ typedef struct gs_ctx gs_ctx;
 #define GS_RENDER_KERNEL_WAVE_4PX 4u   /* one wave per tile, 4 pixels per lane */
 #define GS_RENDER_KERNEL_WORKGROUP 16u /* one 256-thread workgroup per tile sharing the staged batch (the reference's shape) */
 
+/* Order in which RenderGaussians' tiles are dispatched (same pixels either way). */
+#define GS_TILE_ORDER_LONGEST_FIRST 0u /* by list length, longest first: one small launch behind FindRanges (default) */
+#define GS_TILE_ORDER_RASTER 1u        /* row-major, like the reference's dispatch (Subrenderer.cpp:330-333) */
+
 typedef struct gs_config {
     int32_t device_ordinal;   /* HIP device index */
     uint32_t tile_size;       /* 16; only 16 is supported (TILE_SIZE) */
@@ -84,6 +88,7 @@ typedef struct gs_config {
                                  events; 1 = hipEvents at the reference's 7 timestamp points (Renderer.cpp:557-622);
                                  2 = additionally one event pair around every Scatter launch (roofline measurement) */
     uint32_t render_kernel;   /* GS_RENDER_KERNEL_*: how a tile maps to waves in RenderGaussians; same pixels either way */
+    uint32_t tile_order;      /* GS_TILE_ORDER_* */
 } gs_config;
 
 /* The five buckets of Renderer.cpp:471-475 (ms) + the sort element count ("Elements To Sort"
@@ -158,7 +163,10 @@ void gs_default_config(gs_config* cfg);
 
 /* Renderer::init (Renderer.cpp:688-694) + GpuSort::singleInitResources (RadixSort.cpp:23-142). */
 int gs_create(const gs_config* cfg, gs_ctx** out);
-/* Renderer::cleanup (Renderer.cpp:230-270) + RadixSort::cleanup (RadixSort.cpp:655-674). */
+/* Renderer::cleanup (Renderer.cpp:230-270) + RadixSort::cleanup (RadixSort.cpp:655-674).  Waits for the context's
+ * stream, frees everything the context owns and the context itself, and returns GS_OK -- always: there is no failure
+ * that leaves the handle alive, so it must not be used (not even for gs_last_error) once this has been called.
+ * NULL is accepted.  A scene shared through gs_share_scene lives on while another context holds it. */
 int gs_destroy(gs_ctx* ctx);
 /* Text of the last error on ctx (ctx may be NULL: last gs_create failure). Log::error, Dev/Log.cpp:40-43. */
 const char* gs_last_error(const gs_ctx* ctx);

@@ -81,14 +81,12 @@ public:
         return rc;
     }
 
-    // Renderer::cleanup (Renderer.cpp:230-270).  On failure the handle is kept (nothing leaks silently) and the
-    // status is returned with lastError() set.
+    // Renderer::cleanup (Renderer.cpp:230-270).  gs_destroy always frees the context (gsplat.h), so the handle is
+    // dropped before the call and never touched afterwards.
     int cleanup() {
-        if (!ctx_) return GS_OK;
-        const int rc = gs_destroy(ctx_);
-        if (rc != GS_OK) { error_ = gs_last_error(ctx_); return rc; }
+        gs_ctx* c = ctx_;
         ctx_ = nullptr;
-        return GS_OK;
+        return c ? gs_destroy(c) : GS_OK;
     }
 
     // RECORD_CPU_TIMES figures of the last draw (Renderer.cpp:399-456)

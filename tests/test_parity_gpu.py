@@ -670,6 +670,81 @@ def test_every_render_launch_shape_is_bit_exact(oracle_mod, kernel):
     rf.cleanup()
 
 
+@pytest.mark.parametrize("kernel", [gs.GS_RENDER_KERNEL_WAVE_1PX, gs.GS_RENDER_KERNEL_WAVE_4PX, gs.GS_RENDER_KERNEL_WORKGROUP])
+def test_tile_dispatch_order_does_not_change_pixels(oracle_mod, kernel):
+    """gs_config.tile_order: longest list first (default, k_tile_order behind FindRanges) and raster order render the
+    oracle's frame -- whole frame, a contiguous band and interleaved rows (the order table indexes the OWNED tiles)."""
+    w, h = 333, 190
+    aos = synth.generate(6000, w, h, -3.0, seed=23)
+    aos[:40, 4:7] *= 30.0                                   # a few screen-filling splats: very uneven tile lists
+    sc = make_scene(aos, w, h)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    _, band = oracle_run(oracle_mod, sc, w, h, row_begin=3, row_end=8)
+    for order in (gs.GS_TILE_ORDER_LONGEST_FIRST, gs.GS_TILE_ORDER_RASTER):
+        r = gs.Renderer(w, h, warmup_frames=0, render_kernel=kernel, tile_order=order)
+        r.init(sc.getResourceManager())
+        r.initForScene(sc)
+        assert np.array_equal(r.draw(sc), ref["image"])
+        assert np.array_equal(r.draw(sc), ref["image"])     # second frame: graph replay
+        r.setTileRows(3, 8)
+        assert np.array_equal(r.draw(sc)[48:128], band["image"][48:128])
+        r.setTileRowsInterleaved(1, 3)
+        img = r.draw(sc)
+        for row in range(1, 12, 3):
+            assert np.array_equal(img[row * 16:min(row * 16 + 16, h)], ref["image"][row * 16:min(row * 16 + 16, h)])
+        r.cleanup()
+
+
+def test_zero_determinant_splats(oracle_mod):
+    """RenderGaussians.comp:94-107: a splat whose 2x2 covariance has determinant exactly 0 gets a zero inverse and
+    alpha 0 (it is in its tiles' lists but never blends); the setup runs once per splat in k_project here.  Needles
+    with a huge long axis make cx*cz == cy*cy in fp32 (the +0.3 dilation is absorbed); their stored colour keeps the
+    opacity (InitSortList.comp:126) -- only RenderGaussians' local copy is zeroed."""
+    w, h = 192, 112
+    aos = synth.generate(3000, w, h, -3.0, seed=31)
+    k = 600
+    aos[:k, 4] = 3.0e4                                       # one axis 30000, the others 1e-6: rank-1 covariance ~1e13
+    aos[:k, 5:7] = 1.0e-6
+    aos[:k, 15] = 0.9
+    sc = make_scene(aos, w, h)
+    r = make_renderer(sc, w, h)
+    img = r.draw(sc)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    cov = ref["stage1"]["cov"]
+    det = cov[:, 0] * cov[:, 2] - cov[:, 1] * cov[:, 1]      # fp32, the shader's expression
+    emits = np.zeros(aos.shape[0], bool)
+    emits[ref["id"][:ref["e"]]] = True
+    assert np.count_nonzero((det == 0.0) & emits) > 5, "the scene must contain emitting splats with det == 0"
+    assert_frame_equals_oracle(r, img, ref)
+    r.cleanup()
+
+
+def test_library_before_torch_in_a_fresh_process():
+    """the package itself (not the test harness) keeps the process on one HIP runtime -- loading the library
+    first and importing torch afterwards must still find the GPU, and both must be able to use it."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import vk3dgaussiansplatting_amd as gs\n"
+            "gs._lib.lib()\n"
+            "assert 'torch' not in sys.modules\n"
+            "import numpy as np\n"
+            "from vk3dgaussiansplatting_amd import synth\n"
+            "aos = synth.generate(500, 64, 48, -3.0, seed=3)\n"
+            "rm = gs.ResourceManager(); rm.setGaussians(aos)\n"
+            "sc = gs.Scene(rm, aspect_ratio=64 / 48); sc.getCamera().recalculate()\n"
+            "r = gs.Renderer(64, 48, warmup_frames=0); r.init(rm); r.initForScene(sc)\n"
+            "a = r.draw(sc).copy()\n"
+            "import torch\n"
+            "assert torch.cuda.is_available(), 'torch lost the GPU behind the library'\n"
+            "t = torch.zeros((48, 64, 4), dtype=torch.uint8, device='cuda:0')\n"
+            "r.drawDevice(sc, t.data_ptr(), sync=True)\n"
+            "assert np.array_equal(t.cpu().numpy(), a)\n"
+            "r.cleanup(); print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
 def test_shared_scene_frames_in_flight(oracle_mod, small_cloud):
     """gs_share_scene: three contexts over one uploaded scene, each on its own stream with its own per-frame
     buffers, enqueued back to back without waiting (GfxSettings::FRAMES_IN_FLIGHT = 3): every slot's image is

@@ -26,6 +26,7 @@ GS_RENDER_EXACT = 0
 GS_RENDER_FAST = 1
 GS_RENDER_KERNEL_AUTO, GS_RENDER_KERNEL_WAVE_1PX, GS_RENDER_KERNEL_WAVE_2PX = 0, 1, 2
 GS_RENDER_KERNEL_WAVE_4PX, GS_RENDER_KERNEL_WORKGROUP = 4, 16
+GS_TILE_ORDER_LONGEST_FIRST, GS_TILE_ORDER_RASTER = 0, 1
 GS_SORT_RADIX4 = 0
 GS_SORT_TILE_BUCKET = 1
 GS_SORT_RADIX4_SPLAT_FIRST = 2
@@ -49,6 +50,7 @@ class GsConfig(C.Structure):
         ("render_mode", C.c_uint32),
         ("record_timings", C.c_uint32),
         ("render_kernel", C.c_uint32),
+        ("tile_order", C.c_uint32),
     ]
 
 
@@ -126,6 +128,34 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _one_hip_runtime() -> None:
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so (+ HSA runtime) with
+    the same SONAME as the /opt/rocm copy this library links, and the dynamic loader hands every later request for that
+    SONAME the copy that came first: torch first -> this library runs on torch's runtime (the configuration every GPU
+    test runs in); this library first -> torch later finds the system libamdhip64 beside its own HSA runtime and
+    reports "No HIP GPUs are available".  So, when torch is installed but not imported yet, its libamdhip64 is mapped
+    before ours -- no `import torch`, just the one shared object -- and a later `import torch` (dist.ShardedFrame on
+    a cuda device, bench.py) works in either order.  GS_HIP_RUNTIME=system keeps the /opt/rocm runtime for processes
+    that will never import torch."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("GS_HIP_RUNTIME") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        try:
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+        except OSError as ex:   # a broken wheel must not take the library down with it
+            import warnings
+            warnings.warn(f"could not pre-load {bundled} ({ex}); importing torch after this point may fail to see the GPU")
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -134,6 +164,7 @@ def lib() -> C.CDLL:
         raise GsplatLibraryMissing(
             f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback)")
+    _one_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, u32, f32 = C.c_void_p, C.c_uint32, C.c_float
     ctxp = C.c_void_p

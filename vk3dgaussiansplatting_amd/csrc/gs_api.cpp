@@ -62,6 +62,7 @@ struct gs_ctx {
     bool hi16 = false;   // the frame's sort list stores the compact tile ids as uint16 (at most 65535 owned tiles)
     SortBuffers sort{};
     uint32_t* ranges = nullptr;
+    uint32_t* tile_order = nullptr;   // [tiles] RenderGaussians' dispatch order (GS_TILE_ORDER_LONGEST_FIRST)
     uint8_t* framebuffer = nullptr;
     int sorted_index = 0;       // which ping-pong half holds the sorted list after the last frame
     // The radix passes of a frame (3 launches per pass, parameters fixed once resolution and band are) replayed
@@ -139,7 +140,7 @@ void drop_sort_graph(gs_ctx* c) {
 void free_resolution(gs_ctx* c) {
     drop_sort_graph(c);
     free_sort(c->sort);
-    free_dev(c->ranges); free_dev(c->framebuffer);
+    free_dev(c->ranges); free_dev(c->tile_order); free_dev(c->framebuffer);
     c->capacity = 0; c->width = c->height = 0;
     c->have_frame = false;
 }
@@ -234,6 +235,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     const bool bucket = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET;
     const bool per_pass_events = c->cfg.record_timings >= 2;
     const float tile_share = c->grid_h ? (float)c->rows_owned / (float)c->grid_h : 1.0f;
+    const bool ordered = c->cfg.tile_order == GS_TILE_ORDER_LONGEST_FIRST;
     // one capture-or-replay of a run of radix passes (nothing executes during capture)
     auto radix_passes = [&](hipGraphExec_t& exec, int& result, auto&& launch) -> int {
         if (!per_pass_events && !exec && !c->sort_graph_failed) {
@@ -284,56 +286,61 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
                 launch_emit_sorted(fps, c->scratch, c->sort, presorted, st);
                 const int si = tile_passes(nullptr);
                 launch_find_ranges(fps, c->sort.hi[si], c->sort.params, c->ranges, st);
+                if (ordered) launch_tile_order(fps, c->ranges, c->tile_order, st);
                 return si;
             });
             if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
             c->sorted_index = sorted;
             ranges_done = true;
         } else {
-        launch_splat_list(fps, c->scratch, c->sort, st);
-        if (int r = check_launch(c, "InitSortList")) return r;
-        HIP_TRY(c, hipEventRecord(c->pre_ev[0], st));
-        const int presorted = radix_passes(c->presort_graph, c->presort_result, depth_passes);
-        if (presorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
-        if (int r = check_launch(c, "RadixSort")) return r;
-        HIP_TRY(c, hipEventRecord(c->pre_ev[1], st));
-        launch_gather_sorted(fps, c->scratch, c->sort, presorted, st);
-        launch_emit_sorted(fps, c->scratch, c->sort, presorted, st);
-        if (int r = check_launch(c, "InitSortList")) return r;
-        HIP_TRY(c, hipEventRecord(c->pre_ev[2], st));
-        const int sorted = radix_passes(c->sort_graph, c->sort_graph_result, tile_passes);
-        if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
-        c->sorted_index = sorted;
+            launch_splat_list(fps, c->scratch, c->sort, st);
+            if (int r = check_launch(c, "InitSortList")) return r;
+            HIP_TRY(c, hipEventRecord(c->pre_ev[0], st));
+            const int presorted = radix_passes(c->presort_graph, c->presort_result, depth_passes);
+            if (presorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+            if (int r = check_launch(c, "RadixSort")) return r;
+            HIP_TRY(c, hipEventRecord(c->pre_ev[1], st));
+            launch_gather_sorted(fps, c->scratch, c->sort, presorted, st);
+            launch_emit_sorted(fps, c->scratch, c->sort, presorted, st);
+            if (int r = check_launch(c, "InitSortList")) return r;
+            HIP_TRY(c, hipEventRecord(c->pre_ev[2], st));
+            const int sorted = radix_passes(c->sort_graph, c->sort_graph_result, tile_passes);
+            if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+            c->sorted_index = sorted;
         }
     } else {
-    launch_emit(fp, c->scratch, c->sort, st);
-    if (int r = check_launch(c, "InitSortList")) return r;
-    if (tm) HIP_TRY(c, hipEventRecord(c->ev[2], st));
-    // gpuSort->computeSort (RadixSort.cpp:207-653).  The passes' arguments are fixed once resolution and tile rows are:
-    // captured once, replayed as a hipGraph.  Without timers FindRanges (same property) rides in the same graph.
-    auto all_passes = [&](hipEvent_t* evs) {
-        return launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, evs, bucket ? 32u : 0u, !bucket, c->hi16, tile_share);
-    };
-    if (!tm && !bucket) {
-        const int sorted = radix_passes(c->chain_graph, c->chain_result, [&](hipEvent_t*) {
-            const int si = all_passes(nullptr);
-            launch_find_ranges(fp, c->sort.hi[si], c->sort.params, c->ranges, st);
-            return si;
-        });
-        if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
-        c->sorted_index = sorted;
-        ranges_done = true;
-    } else {
-        const int sorted = radix_passes(c->sort_graph, c->sort_graph_result, all_passes);
-        if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
-        c->sorted_index = sorted;
+        launch_emit(fp, c->scratch, c->sort, st);
+        if (int r = check_launch(c, "InitSortList")) return r;
+        if (tm) HIP_TRY(c, hipEventRecord(c->ev[2], st));
+        // gpuSort->computeSort (RadixSort.cpp:207-653).  The passes' arguments are fixed once resolution and tile rows are:
+        // captured once, replayed as a hipGraph.  Without timers FindRanges (same property) rides in the same graph.
+        auto all_passes = [&](hipEvent_t* evs) {
+            return launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, evs, bucket ? 32u : 0u, !bucket, c->hi16, tile_share);
+        };
+        if (!tm && !bucket) {
+            const int sorted = radix_passes(c->chain_graph, c->chain_result, [&](hipEvent_t*) {
+                const int si = all_passes(nullptr);
+                launch_find_ranges(fp, c->sort.hi[si], c->sort.params, c->ranges, st);
+                if (ordered) launch_tile_order(fp, c->ranges, c->tile_order, st);
+                return si;
+            });
+            if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+            c->sorted_index = sorted;
+            ranges_done = true;
+        } else {
+            const int sorted = radix_passes(c->sort_graph, c->sort_graph_result, all_passes);
+            if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+            c->sorted_index = sorted;
+        }
     }
-    }   // !splat_first
     c->depth_dropped = !bucket;
     if (int r = check_launch(c, "RadixSort")) return r;
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[3], st));
     // computeRanges (Subrenderer.cpp:172-216)
-    if (!ranges_done) launch_find_ranges(fp, c->sort.hi[c->sorted_index], c->sort.params, c->ranges, st);
+    if (!ranges_done) {
+        launch_find_ranges(fp, c->sort.hi[c->sorted_index], c->sort.params, c->ranges, st);
+        if (ordered) launch_tile_order(fp, c->ranges, c->tile_order, st);
+    }
     if (int r = check_launch(c, "FindRanges")) return r;
     if (bucket) {
         // second half of the alternative sorter: per-tile depth sort (needs the ranges)
@@ -346,7 +353,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     }
     if (tm) HIP_TRY(c, hipEventRecord(c->ev[4], st));
     // computeRenderGaussians (Subrenderer.cpp:218-346)
-    launch_render(fp, c->scratch.raster, c->sort.id[c->sorted_index], c->ranges,
+    launch_render(fp, c->scratch.raster, c->sort.id[c->sorted_index], c->ranges, ordered ? c->tile_order : nullptr,
                   out_dev ? out_dev : c->framebuffer, c->cfg.render_mode, c->cfg.render_kernel, st);
     if (int r = check_launch(c, "RenderGaussians")) return r;
     if (tm) { HIP_TRY(c, hipEventRecord(c->ev[5], st)); HIP_TRY(c, hipEventRecord(c->ev[6], st)); }
@@ -388,8 +395,8 @@ int finish_frame(gs_ctx* c) {
             t.init_sort_list_ms = a + d;
             t.radix_sort_ms = b + e;
         } else {
-        HIP_TRY(c, hipEventElapsedTime(&t.init_sort_list_ms, c->ev[1], c->ev[2]));
-        HIP_TRY(c, hipEventElapsedTime(&t.radix_sort_ms, c->ev[2], c->ev[3]));
+            HIP_TRY(c, hipEventElapsedTime(&t.init_sort_list_ms, c->ev[1], c->ev[2]));
+            HIP_TRY(c, hipEventElapsedTime(&t.radix_sort_ms, c->ev[2], c->ev[3]));
         }
         HIP_TRY(c, hipEventElapsedTime(&t.find_ranges_ms, c->ev[3], c->ev[4]));
         HIP_TRY(c, hipEventElapsedTime(&t.render_ms, c->ev[4], c->ev[5]));
@@ -476,6 +483,7 @@ void gs_default_config(gs_config* cfg) {
     cfg->render_mode = GS_RENDER_EXACT;
     cfg->record_timings = 0;        // RECORD_GPU_TIMES is commented out in the reference (GfxSettings.h:7)
     cfg->render_kernel = GS_RENDER_KERNEL_AUTO;
+    cfg->tile_order = GS_TILE_ORDER_LONGEST_FIRST;
 }
 
 int gs_create(const gs_config* cfg_in, gs_ctx** out) {
@@ -490,6 +498,7 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
         cfg.render_kernel != GS_RENDER_KERNEL_WAVE_2PX && cfg.render_kernel != GS_RENDER_KERNEL_WAVE_4PX &&
         cfg.render_kernel != GS_RENDER_KERNEL_WORKGROUP)
         return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown render_kernel");
+    if (cfg.tile_order > GS_TILE_ORDER_RASTER) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown tile_order");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -716,6 +725,7 @@ int gs_set_resolution(gs_ctx* c, uint32_t width, uint32_t height) {
     if (rc != GS_OK) { free_resolution(c); return rc; }
     // any failure from here on leaves the context without a resolution (capacity 0), never half set up
     hipError_t e = hipMalloc((void**)&c->ranges, ((size_t)gw * gh * 2 * sizeof(uint32_t) + 15) & ~(size_t)15);   // cleared 16 bytes at a time
+    if (e == hipSuccess) e = hipMalloc((void**)&c->tile_order, (size_t)gw * gh * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&c->framebuffer, (size_t)width * height * 4);
     if (e == hipSuccess) e = hipMemset(c->ranges, 0, (size_t)gw * gh * 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(c->framebuffer, 0, (size_t)width * height * 4);
@@ -911,11 +921,20 @@ int gs_debug_read(gs_ctx* c, int which, void* dst, size_t bytes) {
             if (bytes > need) return fail(c, GS_ERR_INVALID, "gs_debug_read: size exceeds buffer");
             std::vector<SplatRaster> host(c->n);
             HIP_TRY(c, hipMemcpy(host.data(), c->scratch.raster, (size_t)c->n * sizeof(SplatRaster), hipMemcpyDeviceToHost));
+            // color.a as the reference stores it (InitSortList.comp:126) is the opacity itself; the record's copy is
+            // already zeroed where the 2x2 determinant vanishes (RenderGaussians.comp:104), so it comes from the scene
+            std::vector<float> opacity;
+            std::vector<uint32_t> touched;
+            if (which == GS_BUF_COLOR) {
+                opacity.resize(c->n); touched.resize(c->n);
+                HIP_TRY(c, hipMemcpy(opacity.data(), c->scene.opacity, (size_t)c->n * sizeof(float), hipMemcpyDeviceToHost));
+                HIP_TRY(c, hipMemcpy(touched.data(), c->scratch.tiles_touched, (size_t)c->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            }
             std::vector<float> outv((size_t)c->n * 4);
             for (uint32_t i = 0; i < c->n; ++i) {
                 const SplatRaster& r = host[i];
                 float* o = &outv[(size_t)i * 4];
-                if (which == GS_BUF_COLOR) { o[0] = r.r; o[1] = r.g; o[2] = r.b; o[3] = r.a; }
+                if (which == GS_BUF_COLOR) { o[0] = r.r; o[1] = r.g; o[2] = r.b; o[3] = touched[i] ? opacity[i] : 0.0f; }
                 else { o[0] = r.cx; o[1] = r.cy; o[2] = r.cz; o[3] = 0.0f; }
             }
             std::memcpy(dst, outv.data(), bytes);

@@ -72,14 +72,17 @@ struct SortParams {
     uint32_t pad[2];
 };
 
-// What RenderGaussians needs per splat, written once by the project kernel (the reference keeps
-// color/covariance in the 336-byte record and recomputes the screen position per tile,
-// RenderGaussians.comp:88-107; the expressions and operand order are the same).  48 B, 16-aligned.
+// What RenderGaussians needs per splat, written once by the project kernel: the reference keeps color / covariance in
+// the 336-byte record and redoes the screen position and the 2x2 inverse once per (tile, splat),
+// RenderGaussians.comp:88-107; here that setup runs once per emitting splat -- same expressions, same operand order,
+// so the same floats.  48 B, 16-aligned; RenderGaussians reads the first 36 bytes, the covariance rides along for
+// gs_debug_read(GS_BUF_COV) at no extra traffic (the record is written in whole cache lines either way).
 struct alignas(16) SplatRaster {
-    float sx, sy;        // getScreenSpacePosition(...).xy
-    float cx, cy, cz;    // GaussianData.covariance.xyz (raw, +0.3 dilation applied)
-    float r, g, b, a;    // GaussianData.color
-    float pad[3];
+    float sx, sy;        // getScreenSpacePosition(...).xy                       RenderGaussians.comp:89-90
+    float ix, iy, iz;    // gCovInv = (cz, -cy, cx) * (1 / det), 0 when det == 0  :94-107 (emitting splats only)
+    float r, g, b;       // GaussianData.color.rgb                                :92
+    float a;             // GaussianData.color.a, 0 when det == 0                 :92, :104
+    float cx, cy, cz;    // GaussianData.covariance.xyz (raw, +0.3 dilation applied): every non-culled splat
 };
 static_assert(sizeof(SplatRaster) == 48, "SplatRaster must be 48 bytes");
 
@@ -185,9 +188,12 @@ void launch_tile_sort(const FrameParams& fp, const uint32_t* ranges, uint32_t* l
                       hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 void launch_find_ranges(const FrameParams& fp, const uint32_t* sorted_tile, const SortParams* params,
                         uint32_t* ranges, hipStream_t stream);
+// order[k] = the k-th tile RenderGaussians dispatches, as an index among the context's own tiles, longest list first
+void launch_tile_order(const FrameParams& fp, const uint32_t* ranges, uint32_t* order, hipStream_t stream);
+// order == nullptr: raster order
 void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
-                   const uint32_t* ranges, uint8_t* rgba, uint32_t render_mode, uint32_t render_kernel,
-                   hipStream_t stream);
+                   const uint32_t* ranges, const uint32_t* order, uint8_t* rgba, uint32_t render_mode,
+                   uint32_t render_kernel, hipStream_t stream);
 void launch_aos_to_soa(const float* chunk, uint32_t first, uint32_t count, uint32_t n,
                        const SceneBuffers& s, hipStream_t stream);
 void launch_block_bounds(uint32_t n, const SceneBuffers& s, hipStream_t stream);

@@ -349,9 +349,9 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
 
                 // A context that owns a tile-row band can often tell from the position alone that a splat cannot
                 // reach the band: radius = ceil(3 sqrt(lambda_max(Sigma'))) and lambda_max(Sigma') <=
-                // |J|_F^2 |W|_F^2 lambda_max(Sigma) + 0.3, with lambda_max(Sigma) <= sig2 from the upload and J, W as in
-                // getCovarianceMatrix (Common.glsl:49-69).  Widened by 2 % + 2 px and two whole tile rows; a NaN or
-                // infinity anywhere makes the comparison false, i.e. the splat takes the normal path.
+                // |J|_2^2 |W|_2^2 lambda_max(Sigma) + 0.3 (spectral norms, radius_bound above), with lambda_max(Sigma) <=
+                // sig2 from the upload and J, W as in getCovarianceMatrix (Common.glsl:49-69).  Widened by 2 % + 2 px; a
+                // NaN or infinity anywhere makes the comparison false, i.e. the splat takes the normal path.
                 if (band) {
                     const float hgt = (float)fp.height;
                     const float tfx = fp.tan_fov_y * (float)fp.width / hgt;
@@ -402,9 +402,23 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
                 // that emits no element here (off-screen inside the 1.3 NDC cull margin, or outside this
                 // context's tile-row band) the 192-byte SH read and the colour evaluation are skipped:
                 // unobservable in keys, ranges and pixels (SURVEY "F" list).
-                rec0 = make_float4(sx, sy, cov[0], cov[1]);
-                rec1.x = cov[2];
+                rec0 = make_float4(sx, sy, 0.0f, 0.0f);
+                rec2 = make_float4(0.0f, cov[0], cov[1], cov[2]);
                 if (count != 0u) {
+                    // RenderGaussians.comp:94-107, once per splat instead of once per (tile, splat): the inverse of
+                    // the 2x2 covariance (IEEE reciprocal, then three products) and the zero-determinant rule
+                    float opacity = scene.opacity[g];
+                    float inv_x = 0.0f, inv_y = 0.0f, inv_z = 0.0f;
+                    if (det != 0.0f) {
+                        const float det_inv = 1.0f / det;                  // :99
+                        inv_x = cov[2] * det_inv;                          // :100
+                        inv_y = -cov[1] * det_inv;
+                        inv_z = cov[0] * det_inv;
+                    } else {
+                        opacity = 0.0f;                                    // :104
+                    }
+                    rec0.z = inv_x; rec0.w = inv_y;
+                    rec2.x = opacity;
                     // colour, InitSortList.comp:124-126 + Common.glsl:141-170
                     const float ddx = px - fp.cam_pos[0], ddy = py - fp.cam_pos[1], ddz = pz - fp.cam_pos[2];
                     const float len = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
@@ -435,8 +449,7 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
                         res[c] = res[c] + 0.5f;
                         res[c] = maxf(res[c], 0.0f);
                     }
-                    rec1 = make_float4(cov[2], res[0], res[1], res[2]);
-                    rec2 = make_float4(scene.opacity[g], 0.0f, 0.0f, 0.0f);
+                    rec1 = make_float4(inv_z, res[0], res[1], res[2]);
                     sc.depth_key[g] = depth_key;
                     sc.extents[g] = make_uint2((uint32_t)min_x | ((uint32_t)k0 << 16),
                                                (uint32_t)max_x | ((uint32_t)k1 << 16));

@@ -134,7 +134,7 @@ __device__ __forceinline__ Fetched fetch_splat(const SplatRaster* __restrict__ r
 }
 
 // True when no pixel of the rectangle [x0, x0 + 15] x [y0, y0 + rows_m1] can reach the exponent fthr for the
-// conic (ix, iy, iz) centred at (sx, sy); the caller guarantees a positive determinant.  See stage_splat.
+// conic (ix, iy, iz) centred at (sx, sy).  See stage_splat.
 __device__ __forceinline__ bool rect_unreachable(float sx, float sy, float ix, float iy, float iz, float fthr,
                                                  float x0, float y0, float rows_m1) {
     const float u0 = sx - (x0 + 15.0f), u1 = sx - x0;                               // u range (u0 <= u1)
@@ -160,44 +160,32 @@ __device__ __forceinline__ bool rect_unreachable(float sx, float sy, float ix, f
     return reject;
 }
 
-// RenderGaussians.comp:86-108, the per-splat setup one lane does while a batch is staged: screen position,
-// inverse 2x2 covariance, colour, plus two things the shader does not have -- the exponent below which
-// alpha < 1/255 is certain, and an exact rejection of splats that cannot touch the pixel rectangle
-// [tile_x0, tile_x0 + 15] x [tile_y0, tile_y0 + rows_m1].  Returns false when the splat can be dropped.
-__device__ __forceinline__ bool stage_splat(const Fetched& nxt, float tile_x0, float tile_y0, float rows_m1,
-                                            float4& r0, float4& r1, float4& r2) {
+// What is left of RenderGaussians.comp:86-108 per list entry now that k_project has done the per-splat setup (screen
+// position, inverse 2x2 covariance, zero-determinant rule: SplatRaster): two things the shader does not have -- the
+// exponent below which alpha < 1/255 is certain, and an exact rejection of splats that cannot touch the pixel
+// rectangle [tile_x0, tile_x0 + 15] x [tile_y0, tile_y0 + rows_m1].  Returns false when the splat can be dropped;
+// fthr goes to the slot beside alpha (nxt.c.y).
+__device__ __forceinline__ bool stage_splat(Fetched& nxt, float tile_x0, float tile_y0, float rows_m1) {
     bool keep = false;
     if (nxt.valid) {
         const float sx = nxt.a.x, sy = nxt.a.y;
-        const float cx = nxt.a.z, cy = nxt.a.w, cz = nxt.b.x;
-        float alpha0 = nxt.c.x;
-        const float det = cx * cz - cy * cy;                       // :96
-        float ix = 0.0f, iy = 0.0f, iz = 0.0f;
-        if (det != 0.0f) {
-            const float det_inv = 1.0f / det;                      // :99
-            ix = cz * det_inv;                                     // :100
-            iy = -cy * det_inv;
-            iz = cx * det_inv;
-        } else {
-            alpha0 = 0.0f;                                         // :104
-        }
+        const float ix = nxt.a.z, iy = nxt.a.w, iz = nxt.b.x;
+        const float alpha0 = nxt.c.x;
         // Skip threshold: alpha = a*exp(f) < 1/255 (the `continue` of :127) is certain once
         // f < ln(1/(255 a)) - margin; the margin (0.01) dwarfs the errors of the fast log and of
         // the pinned exp (<= 2e-6 relative), so the test below never changes a result.  a <= 0 or
         // NaN gives +inf / NaN, i.e. "always skip" / "never skip", both exact.
-        const float fthr = __logf(1.0f / (255.0f * alpha0)) - 0.01f;
-        r0 = make_float4(sx, sy, ix, iy);
-        r1 = make_float4(iz, nxt.b.y, nxt.b.z, nxt.b.w);
-        r2 = make_float4(alpha0, fthr, 0.f, 0.f);
+        const float fthr = -__logf(255.0f * alpha0) - 0.01f;
+        nxt.c.y = fthr;
         // Whole-rectangle rejection (the reference assigns tiles by a 3-sigma bounding box, so many list
         // entries touch no pixel of the tile).  With u = sx - px, v = py - sy the shader's exponent is
-        // f = -q/2, q(u,v) = ix u^2 + 2 iy u v + iz v^2 (positive definite for a valid covariance).
-        // Over the pixel rectangle q is minimal either at the centre (inside: keep) or on one
-        // of the four edges, where it is a 1-D parabola with a closed-form clamped minimiser.  If
-        // -q_min/2, widened by a generous bound on the fp32 error of the per-pixel f, is below the
-        // skip threshold, every pixel would `continue` (:127): dropping the splat is unobservable.
-        const bool reject = det > 0.0f && rect_unreachable(sx, sy, ix, iy, iz, fthr, tile_x0, tile_y0, rows_m1);
-        keep = !reject;
+        // f = -q/2, q(u,v) = ix u^2 + 2 iy u v + iz v^2.  Over the pixel rectangle q is minimal either at the
+        // centre (inside: keep) or on one of the four edges -- for a definite form and for an indefinite one
+        // alike (no interior minimum then) -- where it is a 1-D parabola, convex because ix, iz > 0, with a
+        // closed-form clamped minimiser.  If -q_min/2, widened by a generous bound on the fp32 error of the
+        // per-pixel f, is below the skip threshold, every pixel would `continue` (:127): dropping the splat is
+        // unobservable.
+        keep = !rect_unreachable(sx, sy, ix, iy, iz, fthr, tile_x0, tile_y0, rows_m1);
     }
     return keep;
 }
@@ -212,6 +200,7 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
                                                 const SplatRaster* __restrict__ raster,
                                                 const uint32_t* __restrict__ sorted_id,
                                                 const uint32_t* __restrict__ ranges,
+                                                const uint32_t* __restrict__ order,
                                                 uint32_t* __restrict__ rgba, uint4* __restrict__ stats = nullptr) {
     // LDS image of the current batch: {sx, sy, inv.x, inv.y}, {inv.z, r, g, b}, {a, skip threshold, -, -}
     __shared__ float4 s_batch[64][3];
@@ -221,7 +210,7 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
     constexpr int LPR = 64 / ROWS;         // lanes per row
     static_assert(LPR * PX == kTile, "lane layout");
     const int lane = threadIdx.x;
-    const uint32_t tile_in_band = blockIdx.x / WPT;
+    const uint32_t tile_in_band = order ? order[blockIdx.x / WPT] : blockIdx.x / WPT;   // longest lists first (k_tile_order)
     const uint32_t sub = blockIdx.x % WPT;
     const uint32_t krow = tile_in_band / fp.grid_w;                    // index among this context's tile rows
     const uint32_t ty = fp.first_row + krow * fp.row_stride;
@@ -250,16 +239,15 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
     const uint64_t st_t0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
     Fetched nxt = fetch_splat(raster, sorted_id, start + lane, end);
     for (uint32_t i = start; i < end; i += 64) {                       // :81
-        // :86-108 per-splat setup, one splat per lane
-        float4 r0, r1, r2;
-        const bool keep = stage_splat(nxt, tile_x0, tile_y0, (float)(ROWS - 1), r0, r1, r2);
+        // :86-108, one list entry per lane (the per-splat setup itself is k_project's)
+        const bool keep = stage_splat(nxt, tile_x0, tile_y0, (float)(ROWS - 1));
         const uint64_t kmask = __ballot(keep);
         const uint32_t n = (uint32_t)__popcll(kmask);
         if (keep) {
             const uint32_t slot = mbcnt(kmask);                        // order-preserving compaction
-            s_batch[slot][0] = r0;
-            s_batch[slot][1] = r1;
-            s_batch[slot][2] = r2;
+            s_batch[slot][0] = nxt.a;
+            s_batch[slot][1] = nxt.b;
+            s_batch[slot][2] = nxt.c;
         }
         __syncthreads();                                               // :109 (single wave)
         nxt = fetch_splat(raster, sorted_id, i + 64 + lane, end);      // prefetch next batch
@@ -421,28 +409,56 @@ __device__ __forceinline__ uint32_t strip_mask(float sy, float ix, float iy, flo
     return m;
 }
 
+// RenderGaussians.comp:127-142 for one pixel and one list entry whose alpha is known: the `continue` on alpha < 1/255,
+// the colour add, add-then-test transmittance.  `need` = the pixel is live and the exponent passed the f tests.
+template <bool EXACT>
+__device__ __forceinline__ void blend_entry(bool need, float alpha, float cr, float cg, float cb, float& col0, float& col1,
+                                            float& col2, float& T, bool& done) {
+    const bool act = need && !(alpha < 1.0f / 255.0f);                 // :127
+    const float wgt = T * alpha;                                       // :131
+    if constexpr (EXACT) {
+        col0 = act ? col0 + wgt * cr : col0;
+        col1 = act ? col1 + wgt * cg : col1;
+        col2 = act ? col2 + wgt * cb : col2;
+    } else {
+        const float w0 = act ? wgt : 0.0f;
+        col0 = __builtin_fmaf(w0, cr, col0);
+        col1 = __builtin_fmaf(w0, cg, col1);
+        col2 = __builtin_fmaf(w0, cb, col2);
+    }
+    const float next_t = T * (1.0f - alpha);                           // :133
+    const bool fin = act && next_t < 0.0001f;                          // :136-140, colour already added
+    done = done || fin;
+    T = (act && !fin) ? next_t : T;                                    // :142
+}
+
 // One 256-thread workgroup per tile, one pixel per lane -- the reference's own shape (RenderGaussians.comp:
 // local_size 16x16, 256-splat shared batch) with wave-level scheduling on top.  Per batch of 256 list entries: thread
-// t fetches entry t (prefetched one batch ahead), sets it up ONCE for the tile (RenderGaussians.comp:86-108) and
-// stores it at slot t together with the mask of 4-row strips it can reach (0 = dropped: it provably touches no pixel
-// of the tile).  After ONE barrier each wave turns the masks into four 64-bit scalar bit sets -- ballot of "entry
-// reaches my strip" -- and walks only the set bits, in list order: a splat three pixels across costs the one wave it
-// lies in a visit, not all four.  A wave whose 64 pixels are all done stops blending but keeps staging; the workgroup
-// leaves the list when all four are done.
+// t fetches entry t (prefetched one batch ahead), tests it ONCE for the tile and stores it at slot t together with
+// the mask of 4-row strips it can reach (0 = dropped: it provably touches no pixel of the tile).  After ONE barrier
+// each wave turns the masks into four 64-bit scalar bit sets -- ballot of "entry reaches my strip" -- and walks only
+// the set bits, in list order: a splat three pixels across costs the one wave it lies in a visit, not all four.
+// The walk takes TWO entries per step: their exponents, the pinned exp and alpha are evaluated side by side in the
+// two halves of packed fp32 instructions (v_pk_mul / v_pk_add / v_pk_fma are IEEE per component, so each half goes
+// through exactly the scalar operation sequence of :119-124), then the two blends run one after the other in list
+// order (:127-142 is a chain through T).  A wave whose 64 pixels are all done stops blending but keeps staging; the
+// workgroup leaves the list when all four are done.
 template <bool EXACT>
 __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
                                                     const SplatRaster* __restrict__ raster,
                                                     const uint32_t* __restrict__ sorted_id,
                                                     const uint32_t* __restrict__ ranges,
+                                                    const uint32_t* __restrict__ order,
                                                     uint32_t* __restrict__ rgba) {
     __shared__ float4 s_batch[256][3];
     __shared__ uint32_t s_mask[256];
     __shared__ uint32_t s_done;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t krow = blockIdx.x / fp.grid_w;                      // index among this context's tile rows
+    const uint32_t tile_in_band = order ? order[blockIdx.x] : blockIdx.x;   // longest lists first (k_tile_order)
+    const uint32_t krow = tile_in_band / fp.grid_w;                    // index among this context's tile rows
     const uint32_t ty = fp.first_row + krow * fp.row_stride;
-    const uint32_t tx = blockIdx.x % fp.grid_w;
+    const uint32_t tx = tile_in_band % fp.grid_w;
     const uint32_t tile_index = ty * fp.grid_w + tx;                   // :74-76
     const uint32_t start = ranges[tile_index * 2 + 0];                 // :77
     const uint32_t end = ranges[tile_index * 2 + 1];
@@ -460,19 +476,18 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
 
     Fetched nxt = fetch_splat(raster, sorted_id, start + tid, end);
     for (uint32_t i = start; i < end; i += 256) {                      // :81
-        float4 r0, r1, r2;
         uint32_t mask = 0u;
-        if (stage_splat(nxt, tile_x0, tile_y0, 15.0f, r0, r1, r2)) {
+        if (stage_splat(nxt, tile_x0, tile_y0, 15.0f)) {
             // the bound on the rounding of the per-pixel exponent that stage_splat's rectangle test uses, over the tile
-            const float far_x = fmaxf(fabsf(r0.x - tile_x0), fabsf(r0.x - (tile_x0 + 15.0f)));
-            const float far_y = fmaxf(fabsf(r0.y - tile_y0), fabsf(r0.y - (tile_y0 + 15.0f)));
-            const float mag = fabsf(r0.z) * far_x * far_x + fabsf(r1.x) * far_y * far_y + 2.0f * fabsf(r0.w) * far_x * far_y;
-            mask = strip_mask(r0.y, r0.z, r0.w, r1.x, r2.y, 0.01f + 8e-6f * mag, tile_y0);
+            const float far_x = fmaxf(fabsf(nxt.a.x - tile_x0), fabsf(nxt.a.x - (tile_x0 + 15.0f)));
+            const float far_y = fmaxf(fabsf(nxt.a.y - tile_y0), fabsf(nxt.a.y - (tile_y0 + 15.0f)));
+            const float mag = fabsf(nxt.a.z) * far_x * far_x + fabsf(nxt.b.x) * far_y * far_y + 2.0f * fabsf(nxt.a.w) * far_x * far_y;
+            mask = strip_mask(nxt.a.y, nxt.a.z, nxt.a.w, nxt.b.x, nxt.c.y, 0.01f + 8e-6f * mag, tile_y0);
         }
         if (mask) {
-            s_batch[tid][0] = r0;
-            s_batch[tid][1] = r1;
-            s_batch[tid][2] = r2;
+            s_batch[tid][0] = nxt.a;
+            s_batch[tid][1] = nxt.b;
+            *reinterpret_cast<float2*>(&s_batch[tid][2]) = make_float2(nxt.c.x, nxt.c.y);
         }
         s_mask[tid] = mask;
         __syncthreads();                                               // :109; s_done of the previous batch settled
@@ -483,44 +498,38 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
 #pragma unroll 1
             for (int k = 0; k < 4 && !wave_done; ++k) {
                 uint64_t m = __ballot((s_mask[k * 64 + lane] >> wave) & 1u);   // entries of this chunk that reach my rows
-                while (m) {                                            // :112, list order
-                    const int j = k * 64 + __builtin_ctzll(m);
+                while (m) {                                            // :112, list order, two entries per step
+                    const int ja = k * 64 + __builtin_ctzll(m);
                     m &= m - 1;
-                    const float4 g0 = s_batch[j][0];
-                    const float4 g1 = s_batch[j][1];
-                    const float2 g2 = *reinterpret_cast<const float2*>(&s_batch[j][2]);
-                    const float ga = g2.x, fthr = g2.y;
-                    float ey = g0.y - fpy;                             // :119
-                    ey = -ey;                                          // :120
-                    const float ex = g0.x - fpx;
-                    float f;
+                    const bool two = m != 0ull;                        // wave-uniform
+                    const int jb = two ? k * 64 + __builtin_ctzll(m) : ja;
+                    m &= m - 1;                                        // 0 stays 0
+                    const float4 a0 = s_batch[ja][0], a1 = s_batch[ja][1];
+                    const float2 a2 = *reinterpret_cast<const float2*>(&s_batch[ja][2]);
+                    const float4 b0 = s_batch[jb][0], b1 = s_batch[jb][1];
+                    const float2 b2 = *reinterpret_cast<const float2*>(&s_batch[jb][2]);
+                    const v2f ex = (v2f){a0.x, b0.x} - (v2f){fpx, fpx};          // :119
+                    const v2f ey = -((v2f){a0.y, b0.y} - (v2f){fpy, fpy});       // :119-120
+                    const v2f ixv = {a0.z, b0.z}, iyv = {a0.w, b0.w}, izv = {a1.x, b1.x};
+                    v2f f;
                     if constexpr (EXACT) {
-                        f = -0.5f * (g0.z * ex * ex + g1.x * ey * ey) - g0.w * ex * ey;   // :123
+                        f = (v2f){-0.5f, -0.5f} * (ixv * ex * ex + izv * ey * ey) - iyv * ex * ey;   // :123
                     } else {
-                        const float q = __builtin_fmaf(g0.z * ex, ex, g1.x * ey * ey);
-                        f = __builtin_fmaf(-0.5f, q, -(g0.w * ey * ex));
+                        const v2f q = __builtin_elementwise_fma(ixv * ex, ex, izv * ey * ey);
+                        f = __builtin_elementwise_fma((v2f){-0.5f, -0.5f}, q, -(iyv * ey * ex));
                     }
-                    const bool need = !done && !(f > 0.0f) && !(f < fthr);
-                    if (!__any(need)) continue;                        // nobody in these rows can pass :127
-                    float alpha;
-                    if constexpr (EXACT) alpha = ga * exp_pinned(f);   // :124
-                    else alpha = ga * __builtin_amdgcn_exp2f(f * 0x1.715476p+0f);
-                    const bool act = need && !(alpha < 1.0f / 255.0f); // :127
-                    const float wgt = T * alpha;                       // :131
+                    const bool live_a = !(f.x > 0.0f) && !(f.x < a2.y);
+                    const bool live_b = two && !(f.y > 0.0f) && !(f.y < b2.y);
+                    if (!__any(!done && (live_a || live_b))) continue; // nobody in these rows can pass :127
+                    v2f alpha;
                     if constexpr (EXACT) {
-                        col0 = act ? col0 + wgt * g1.y : col0;
-                        col1 = act ? col1 + wgt * g1.z : col1;
-                        col2 = act ? col2 + wgt * g1.w : col2;
+                        alpha = (v2f){a2.x, b2.x} * exp_pinned2(f);    // :124
                     } else {
-                        const float w0 = act ? wgt : 0.0f;
-                        col0 = __builtin_fmaf(w0, g1.y, col0);
-                        col1 = __builtin_fmaf(w0, g1.z, col1);
-                        col2 = __builtin_fmaf(w0, g1.w, col2);
+                        const v2f t = f * (v2f){0x1.715476p+0f, 0x1.715476p+0f};
+                        alpha = (v2f){a2.x, b2.x} * (v2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
                     }
-                    const float next_t = T * (1.0f - alpha);           // :133
-                    const bool fin = act && next_t < 0.0001f;          // :136-140, colour already added
-                    done = done || fin;
-                    T = (act && !fin) ? next_t : T;                    // :142
+                    blend_entry<EXACT>(!done && live_a, alpha.x, a1.y, a1.z, a1.w, col0, col1, col2, T, done);
+                    blend_entry<EXACT>(!done && live_b, alpha.y, b1.y, b1.z, b1.w, col0, col1, col2, T, done);
                     if (__all(done)) {                                 // this wave's rows are finished
                         wave_done = true;
                         if (lane == 0) atomicAdd(&s_done, 1u);
@@ -564,29 +573,64 @@ void launch_find_ranges(const FrameParams& fp, const uint32_t* sorted_tile, cons
     hipLaunchKernelGGL(k_find_ranges, dim3(blocks), dim3(256), 0, stream, sorted_tile, params, ranges, fp.hi16, map);
 }
 
+// Dispatch order of RenderGaussians' tiles: longest list first.  Workgroups are handed out in grid order and a tile's
+// time grows with its list, so on a capture-like scene (a few tiles with tens of thousands of entries, most with
+// hundreds) raster order leaves the heaviest tiles wherever they happen to lie and the launch ends on them; sorted by
+// list length the tail is made of the shortest tiles.  One workgroup: counting sort of the owned tiles into 32
+// classes by bits(end - start), longest class first, any order inside a class (every order gives the same pixels).
+__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order,
+                                                      uint32_t tiles, TileMap map) {
+    __shared__ uint32_t s_count[33], s_cursor[33];
+    if (threadIdx.x < 33) { s_count[threadIdx.x] = 0u; s_cursor[threadIdx.x] = 0u; }
+    __syncthreads();
+    auto tile_class = [&](uint32_t c) {
+        const uint2 r = reinterpret_cast<const uint2*>(ranges)[global_tile(map, c)];
+        const uint32_t len = r.y > r.x ? r.y - r.x : 0u;
+        return len ? 32u - (uint32_t)__builtin_clz(len) : 0u;     // bits(len): 0 for an empty tile, else 1 .. 32
+    };
+    for (uint32_t c = threadIdx.x; c < tiles; c += 1024u) atomicAdd(&s_count[tile_class(c)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {   // first position of every class, longest class first
+        uint32_t run = 0u;
+        for (int b = 32; b >= 0; --b) { const uint32_t n = s_count[b]; s_count[b] = run; run += n; }
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < tiles; c += 1024u) {
+        const uint32_t b = tile_class(c);
+        order[s_count[b] + atomicAdd(&s_cursor[b], 1u)] = c;
+    }
+}
+
+void launch_tile_order(const FrameParams& fp, const uint32_t* ranges, uint32_t* order, hipStream_t stream) {
+    const uint32_t tiles = fp.rows_owned * fp.grid_w;
+    if (tiles == 0) return;
+    const TileMap map{fp.grid_w, fp.first_row, fp.row_stride};
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, ranges, order, tiles, map);
+}
+
 void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
                          const uint32_t* ranges, uint8_t* rgba, uint4* stats, hipStream_t stream) {
     const uint32_t tiles = fp.rows_owned * fp.grid_w;
     if (tiles == 0) return;
     hipLaunchKernelGGL((k_render<true, 4, true>), dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
-                       ranges, reinterpret_cast<uint32_t*>(rgba), stats);
+                       ranges, (const uint32_t*)nullptr, reinterpret_cast<uint32_t*>(rgba), stats);
 }
 
 void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
-                   const uint32_t* ranges, uint8_t* rgba, uint32_t render_mode, uint32_t render_kernel,
-                   hipStream_t stream) {
+                   const uint32_t* ranges, const uint32_t* order, uint8_t* rgba, uint32_t render_mode,
+                   uint32_t render_kernel, hipStream_t stream) {
     const uint32_t tiles = fp.rows_owned * fp.grid_w;
     if (tiles == 0) return;
     uint32_t* out = reinterpret_cast<uint32_t*>(rgba);
     const uint32_t px = render_kernel != 0u ? render_kernel : tiles < 1500u ? 1u : tiles < 20000u ? 16u : 2u;
 #define GS_LAUNCH_RENDER(EXACT, PX)                                                                   \
     hipLaunchKernelGGL((k_render<EXACT, PX, false>), dim3(tiles * (4 / PX)), dim3(64), 0, stream, fp, \
-                       raster, sorted_id, ranges, out, (uint4*)nullptr)
+                       raster, sorted_id, ranges, order, out, (uint4*)nullptr)
     if (px == 16) {   // workgroup-per-tile kernel
         if (render_mode == 0u)
-            hipLaunchKernelGGL((k_render_wg<true>), dim3(tiles), dim3(256), 0, stream, fp, raster, sorted_id, ranges, out);
+            hipLaunchKernelGGL((k_render_wg<true>), dim3(tiles), dim3(256), 0, stream, fp, raster, sorted_id, ranges, order, out);
         else
-            hipLaunchKernelGGL((k_render_wg<false>), dim3(tiles), dim3(256), 0, stream, fp, raster, sorted_id, ranges, out);
+            hipLaunchKernelGGL((k_render_wg<false>), dim3(tiles), dim3(256), 0, stream, fp, raster, sorted_id, ranges, order, out);
     } else if (render_mode == 0u) {
         if (px == 1) GS_LAUNCH_RENDER(true, 1);
         else if (px == 2) GS_LAUNCH_RENDER(true, 2);

@@ -3,25 +3,23 @@
 //
 // Reference pipeline per 4-bit pass (RadixSort.cpp:309-642): five dependent dispatches
 //   Count -> Reduce -> Scan -> ScanAdd -> Scatter, 64 keys per workgroup, 16-byte uvec4 elements.
-// Here the same five stages run in THREE launches per pass over 2048-key tiles ("groups"):
-//   k_count    Count  : per-group digit histogram -> table[bin][group]  (RadixSortCount.comp:40-91);
-//                       reads only the 4-byte key half the digit lives in (keys are SoA).
-//              Reduce : each of the 1024 persistent workgroups owns a CONTIGUOUS run of groups (one
-//                       reduce segment) and stores the run's 16 digit totals to seg_sum[bin][segment]
-//                       with plain stores (RadixSortReduce.comp:34-72; device atomics here cost
-//                       ~15 us per pass on MI355X, measured).
-//   (k_scan)   Scan   : no launch of its own any more -- see k_scatter; was: one workgroup, exclusive scan of the 16 x 1024 segment totals in bin-major
-//                       order, in place (RadixSortScan.comp:29-71).
-//   k_scatter  ScanAdd: prologue -- exclusive prefix of the group's counts inside its segment,
-//                       read from the L2-resident table, plus the segment base
-//                       (RadixSortScanAdd.comp:34-66);
-//              Scatter: wave64 match-mask ranking (stable), LDS-staged local sort, run-wise
-//                       coalesced stores (RadixSortScatter.comp:58-171).
-// Count is persistent (1024 workgroups, each walking the groups of its segment and prefetching the next group's
-// keys); Scatter launches one workgroup per group (five resident per CU).  Inside a frame the words are narrower
-// than the reference's: 16-bit band-relative tile ids when they fit, and depth words that shrink as their digits are
-// consumed (see k_scatter); the stand-alone sorter (gs_sort_host) always moves three 32-bit words.
-// Output is bit-identical to a stable sort by the low num_sort_bits of the key.
+// Here the same five stages run in TWO launches per pass over 2048-key tiles ("groups"):
+//   k_count    Count  : per-group digit histogram, one WAVE per group (RadixSortCount.comp:40-91); reads only the
+//                       word the digit lives in (keys are SoA; 2 bytes per key once that word is 16 bits wide).
+//              Reduce : workgroup s (512 threads, kSegments = 512 of them) owns reduce segment s = K consecutive
+//                       groups; their 16 digit totals go to seg_sum[bin][segment] with plain stores and, one level
+//                       up, into 16 x 64 coarse totals with one agent-scope atomic add per digit
+//                       (RadixSortReduce.comp:34-72, two levels).
+//              ScanAdd, segment-local part: the table gets, per group and digit, the keys of that digit in the EARLIER
+//                       groups of the segment (RadixSortScanAdd.comp:34-66).
+//   k_scatter  Scan   : prologue -- every workgroup scans the coarse totals itself (DPP row scans) and adds the
+//                       segment totals and the table entry ahead of its group (RadixSortScan.comp:29-71 and the rest
+//                       of ScanAdd); there is no Scan launch.
+//              Scatter: one 256-thread workgroup per group (7-8 resident per CU): wave64 match-mask ranking (stable),
+//                       LDS-staged local sort, run-wise coalesced stores (RadixSortScatter.comp:58-171).
+// Inside a frame the words are narrower than the reference's: 16-bit compact tile ids when they fit, and depth words
+// that shrink as their digits are consumed (see k_scatter); the stand-alone sorter (gs_sort_host) always moves three
+// 32-bit words.  Output is bit-identical to a stable sort by the low num_sort_bits of the key.
 // Launch grids are fixed; the device-side element count (SortParams, the IndirectSetup record)
 // bounds every loop -- no host read-back inside a frame.
 #include "gs_device_utils.h"
@@ -207,13 +205,6 @@ __global__ __launch_bounds__(kCountThreads) void k_count(const SortParams* __res
 //              consecutive global indices (RadixSortScatter.comp:153-168): run-wise coalesced stores
 // The group count (not the list capacity) bounds the work: surplus workgroups leave at once.
 // ---------------------------------------------------------------------------------------------
-#ifndef GS_SCATTER_ABLATE
-#define GS_SCATTER_ABLATE 0     // timing-only builds (tools/build_variants.sh), never shipped.  bit 0: stores go to the
-                                // group's own range (no scatter pattern); bit 1: no global stores; bit 2: no ranking
-#endif
-#ifndef GS_RANK_XNOR
-#define GS_RANK_XNOR 1
-#endif
 #ifndef GS_SCATTER_MINWAVES_KEY
 #define GS_SCATTER_MINWAVES_KEY 5    // resident workgroups per CU asked of the compiler: passes that carry 12 or more bytes
 #endif
@@ -314,7 +305,6 @@ __device__ __forceinline__ void scatter_group(
         const bool ok = FULL || base + r * 64 < e;
         const uint32_t kw = use_hi ? hi[r] : lo[r];
         const uint32_t dg = digit_of(kw, sh);
-#if GS_RANK_XNOR
         // per digit bit b: S = all ones where the lane's bit is set (one signed bit-field extract), the ballot of the
         // bit, and XNOR(ballot, S) = the lanes that agree with this lane on bit b; AND over the four bits
         uint32_t m_lo = 0xFFFFFFFFu, m_hi = 0xFFFFFFFFu;
@@ -327,15 +317,6 @@ __device__ __forceinline__ void scatter_group(
             m_hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)sbit);
         }
         uint64_t mask = ((uint64_t)m_hi << 32) | m_lo;
-#else
-        uint64_t mask = FULL ? ~0ull : __ballot(ok);
-#pragma unroll
-        for (int b = 0; b < kRadixBits; ++b) {
-            const bool bit = (dg >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            mask &= bit ? bal : ~bal;
-        }
-#endif
         if (!FULL) mask = ok ? mask : 0ull;
         const uint32_t in_round = mbcnt(mask);
         const uint32_t n_round = (uint32_t)__popcll(mask);
@@ -347,9 +328,6 @@ __device__ __forceinline__ void scatter_group(
         const int dest = leader ? (int)dg : 63;
         const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)n_round);
         cntreg += lane < kBins ? recv : 0u;
-#if GS_SCATTER_ABLATE & 4
-        rank[r] = (uint32_t)(wave * R + r) * 64u + lane;   // linear position
-#endif
     }
     if (lane < kBins) s_wcnt[lane * kSortWaves + wave] = cntreg;
     __syncthreads();
@@ -373,11 +351,7 @@ __device__ __forceinline__ void scatter_group(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t dg = digit_of(use_hi ? hi[r] : lo[r], sh);
-#if GS_SCATTER_ABLATE & 4
-        const uint32_t p = rank[r];
-#else
         const uint32_t p = (uint32_t)__shfl((int)wbase, (int)dg, 64) + rank[r];
-#endif
         if (FULL || base + r * 64 < e) {
             if constexpr (LO_IN == 0) s_slot[p] = make_uint2(id[r], hi[r]);
             else if constexpr (LO_IN == 2 && HI16) s_slot[p] = make_uint2(id[r], lo[r] | (hi[r] << 16));
@@ -397,21 +371,13 @@ __device__ __forceinline__ void scatter_group(
         else if constexpr (LO_IN == 2 && HI16) { l = sl.y & 0xFFFFu; h = sl.y >> 16; }
         else { l = sl.y; h = s_third[p]; }
         const uint32_t d = digit_of(use_hi ? h : l, sh);
-#if GS_SCATTER_ABLATE & 5
-        const uint32_t o = tile_base + p + (d & 0u);
-#else
         const uint32_t o = (uint32_t)__shfl((int)gofs, (int)d, 64) + p;
-#endif
         if (FULL || p < valid) {
-#if GS_SCATTER_ABLATE & 2
-            if (l == 0x12345678u && h == 0x9abcdef0u) out_lo[o] = l;   // keeps the pipeline alive, ~never taken
-#else
             if constexpr (LO_OUT == 4) out_lo[o] = l;
             else if constexpr (LO_OUT == 2) reinterpret_cast<uint16_t*>(out_lo)[o] = (uint16_t)(LO_IN == 4 ? l >> 16 : l);
             if constexpr (HI16) reinterpret_cast<uint16_t*>(out_hi)[o] = (uint16_t)h;
             else out_hi[o] = h;
             out_id[o] = sl.x;
-#endif
         }
     }
 }

@@ -253,7 +253,8 @@ class _Context:
     """Owns one gs_ctx."""
 
     def __init__(self, device: int = 0, render_mode: int = _lib.GS_RENDER_EXACT, record_timings=True,
-                 sort_algorithm: int = _lib.GS_SORT_RADIX4, render_kernel: int = _lib.GS_RENDER_KERNEL_AUTO):
+                 sort_algorithm: int = _lib.GS_SORT_RADIX4, render_kernel: int = _lib.GS_RENDER_KERNEL_AUTO,
+                 tile_order: int = _lib.GS_TILE_ORDER_LONGEST_FIRST):
         L = _lib.lib()
         cfg = GsConfig()
         L.gs_default_config(C.byref(cfg))
@@ -261,6 +262,7 @@ class _Context:
         cfg.render_mode = render_mode
         cfg.sort_algorithm = sort_algorithm
         cfg.render_kernel = render_kernel
+        cfg.tile_order = tile_order
         cfg.record_timings = int(record_timings)   # 0 off, 1 buckets, 2 buckets + per-Scatter events
         self.cfg = cfg
         self.handle = C.c_void_p()
@@ -275,11 +277,8 @@ class _Context:
 
     def close(self):
         if self.handle:
-            L = _lib.lib()
-            rc = L.gs_destroy(self.handle)
-            if rc != 0:     # e.g. other contexts still share this one's scene: the handle stays valid
-                raise GsplatError(rc, L.gs_last_error(self.handle).decode())
-            self.handle = C.c_void_p()
+            handle, self.handle = self.handle, C.c_void_p()   # gs_destroy always frees the context: never touch it again
+            _lib.lib().gs_destroy(handle)
 
     def __del__(self):
         try:
@@ -357,9 +356,11 @@ class Renderer:
     def __init__(self, width: int = 1280, height: int = 720, device: int = 0,
                  render_mode: int = _lib.GS_RENDER_EXACT, record_timings: bool = True,
                  warmup_frames: int | None = None, sort_algorithm: int = _lib.GS_SORT_RADIX4,
-                 render_kernel: int = _lib.GS_RENDER_KERNEL_AUTO):
+                 render_kernel: int = _lib.GS_RENDER_KERNEL_AUTO,
+                 tile_order: int = _lib.GS_TILE_ORDER_LONGEST_FIRST):
         self.width, self.height = int(width), int(height)   # swapchain extent (Engine.cpp:35)
         self._render_kernel = render_kernel
+        self._tile_order = tile_order
         self._device, self._render_mode, self._record = device, render_mode, record_timings
         self._sort_algorithm = sort_algorithm   # GPU_SORT_ALGORITHM, Renderer.h:33
         self._ctx: _Context | None = None
@@ -378,7 +379,7 @@ class Renderer:
     def init(self, resourceManager: ResourceManager):
         self.resourceManager = resourceManager
         self._ctx = _Context(self._device, self._render_mode, self._record, self._sort_algorithm,
-                             self._render_kernel)
+                             self._render_kernel, self._tile_order)
 
     # -- Renderer.cpp:696-710
     def getNumTiles(self) -> int:
