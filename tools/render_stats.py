@@ -17,7 +17,7 @@ sc = gs.Scene(rm, aspect_ratio=w / h); cam = sc.getCamera(); cam.setPosition((0,
 r = gs.Renderer(w, h, warmup_frames=0); r.init(rm); r.initForScene(sc)
 r.drawDevice(sc)
 info = r.sceneInfo(); T = info.tiles_x * info.tiles_y
-out = np.zeros((T, 4), np.uint32)
+out = np.zeros((T, 8), np.uint32)
 L = _lib.lib(); L.gs_debug_render_stats.argtypes = [C.c_void_p] * 5
 p = lambda a: a.ctypes.data_as(C.c_void_p)
 rc = L.gs_debug_render_stats(r._ctx.handle, p(cam.getViewMatrix()), p(cam.getProjectionMatrix()), p(cam.getPosition()), p(out))

@@ -725,7 +725,7 @@ int gs_set_resolution(gs_ctx* c, uint32_t width, uint32_t height) {
     if (rc != GS_OK) { free_resolution(c); return rc; }
     // any failure from here on leaves the context without a resolution (capacity 0), never half set up
     hipError_t e = hipMalloc((void**)&c->ranges, ((size_t)gw * gh * 2 * sizeof(uint32_t) + 15) & ~(size_t)15);   // cleared 16 bytes at a time
-    if (e == hipSuccess) e = hipMalloc((void**)&c->tile_order, (size_t)gw * gh * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->tile_order, (size_t)gw * gh * 2 * sizeof(uint32_t));   // table + k_tile_order's scratch
     if (e == hipSuccess) e = hipMalloc((void**)&c->framebuffer, (size_t)width * height * 4);
     if (e == hipSuccess) e = hipMemset(c->ranges, 0, (size_t)gw * gh * 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(c->framebuffer, 0, (size_t)width * height * 4);
@@ -1064,17 +1064,17 @@ int gs_sort_bench(gs_ctx* c, uint32_t n, uint32_t num_tiles, uint32_t iters, uin
 }
 
 // Tuning only (not declared in gsplat.h): re-runs RenderGaussians of the last frame with per-tile
-// counters; out = uint32[tiles][4] {list length, splats visited, splats needing exp, clock ticks}.
+// counters; out = uint32[tiles][8] {list length, splats visited, splats needing exp, clock ticks, entries staged, 0, 0, 0}.
 int gs_debug_render_stats(gs_ctx* c, const float* view, const float* proj, const float* cam_pos, uint32_t* out) {
     if (!c || !out || !c->have_frame) return GS_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     const FrameParams fp = make_frame_params(c, view, proj, cam_pos, 0);
     const size_t tiles = (size_t)c->grid_w * c->grid_h;
     uint4* d = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d, tiles * sizeof(uint4)));
-    HIP_TRY(c, hipMemsetAsync(d, 0, tiles * sizeof(uint4), c->stream));
+    HIP_TRY(c, hipMalloc((void**)&d, tiles * 2 * sizeof(uint4)));
+    HIP_TRY(c, hipMemsetAsync(d, 0, tiles * 2 * sizeof(uint4), c->stream));
     launch_render_stats(fp, c->scratch.raster, c->sort.id[c->sorted_index], c->ranges, c->framebuffer, d, c->stream);
-    hipError_t e = hipMemcpyAsync(out, d, tiles * sizeof(uint4), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipMemcpyAsync(out, d, tiles * 2 * sizeof(uint4), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_debug_render_stats: ") + hipGetErrorString(e));

@@ -7,11 +7,12 @@
 // k_render / k_render_wg: RenderGaussians.comp:56-152 in two launch shapes (gs_config.render_kernel; table of
 //   measurements above launch_render).  k_render<PX>: independent wave64s, PX horizontally adjacent pixels per
 //   lane (PX = 4: one wave per 16x16 tile), no workgroup barriers, one 16-byte RGBA8 store per lane.
-//   k_render_wg: one 256-thread workgroup per tile, one pixel per lane (the shader's own shape), the four waves
-//   staging each 256-entry batch together.  Both gather the batch through the sorted id list from the 48-byte
-//   SplatRaster records, prefetch one batch ahead of the blend loop, drop while staging the splats that provably
-//   touch no pixel of the rectangle (conservative, unobservable), and use wave votes for the early-outs the
-//   reference lacks (its `done` only zeroes `limit`, :111).
+//   k_render_wg: one 256-thread workgroup per tile, one pixel per lane (the shader's own shape), its four waves
+//   each walking the list on their own for their four pixel rows.  Both gather the batch through the sorted id list
+//   from the 48-byte SplatRaster records (screen position, inverse covariance, colour: set up once per splat by
+//   k_project), prefetch one batch ahead of the blend loop, drop while staging the splats that provably touch no
+//   pixel of the rectangle (conservative, unobservable), and use wave votes for the early-outs the reference lacks
+//   (its `done` only zeroes `limit`, :111).  k_tile_order: the order in which the tiles are dispatched.
 // GS_RENDER_EXACT evaluates every expression in the reference's order without contraction and with
 // the pinned exp of oracle/gs_oracle.h => pixels bit-identical to the CPU oracle.
 // GS_RENDER_FAST uses fused multiply-adds and the hardware exp2 (what a GLSL compiler is free to
@@ -191,7 +192,8 @@ __device__ __forceinline__ bool stage_splat(Fetched& nxt, float tile_x0, float t
 }
 
 // STATS is a tuning-only instantiation (gs_debug_render_stats): per tile {list length, splats
-// visited, splats with any pixel needing exp, clock ticks}.  The product launches STATS = false.
+// visited, splats with any pixel needing exp, clock ticks | entries staged before the tile was done, -, -, -}.
+// The product launches STATS = false.
 // PX = pixels per lane: 4 -> one wave per tile (16 rows x 4 lanes), 2 -> two waves per tile (each
 // 8 rows x 8 lanes), 1 -> four waves per tile (each 4 rows x 16 lanes).  Waves of one tile are
 // independent workgroups: each gathers, culls (against its own pixel rectangle) and blends on its own.
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
         done[k] = !(px0 + k < fp.width && py < fp.height);             // never stored (:147)
     }
 
-    uint32_t st_visited = 0, st_need = 0;
+    uint32_t st_visited = 0, st_need = 0, st_walked = 0;   // STATS: entries visited / needing an exp / staged before the tile was done
     const uint64_t st_t0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
     Fetched nxt = fetch_splat(raster, sorted_id, start + lane, end);
     for (uint32_t i = start; i < end; i += 64) {                       // :81
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
         const bool keep = stage_splat(nxt, tile_x0, tile_y0, (float)(ROWS - 1));
         const uint64_t kmask = __ballot(keep);
         const uint32_t n = (uint32_t)__popcll(kmask);
+        if (STATS) st_walked = (i + 64u < end ? i + 64u : end) - start;
         if (keep) {
             const uint32_t slot = mbcnt(kmask);                        // order-preserving compaction
             s_batch[slot][0] = nxt.a;
@@ -361,8 +364,10 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
         __syncthreads();                                               // :84
     }
 finish:
-    if (STATS && lane == 0)
-        stats[tile_index] = make_uint4(end - start, st_visited, st_need, (uint32_t)(__builtin_amdgcn_s_memtime() - st_t0));
+    if (STATS && lane == 0) {
+        stats[tile_index * 2] = make_uint4(end - start, st_visited, st_need, (uint32_t)(__builtin_amdgcn_s_memtime() - st_t0));
+        stats[tile_index * 2 + 1] = make_uint4(st_walked, 0u, 0u, 0u);
+    }
     // :147-151 clamp + RGBA8 UNORM store, A = 255
     uint32_t packed[PX];
 #pragma unroll
@@ -391,24 +396,6 @@ finish:
     }
 }
 
-// Rows of the tile (0..15, relative to tile_y0) that the splat can reach at all: where the exponent can come up to
-// the skip threshold, f >= fthr - tol, i.e. q(u, v) <= Q' = 2 (tol - fthr).  For the conic M = [[ix, iy], [iy, iz]]
-// the ellipse q <= Q' spans |v| <= sqrt(Q' ix / det M).  Returned as a 4-bit mask of the 4-row strips the four waves
-// of k_render_wg blend (bit w = rows 4 w .. 4 w + 3).  Conservative (0.01 % + 0.05 px wider); anything odd -> all.
-__device__ __forceinline__ uint32_t strip_mask(float sy, float ix, float iy, float iz, float fthr, float tol, float tile_y0) {
-    const float detm = ix * iz - iy * iy;
-    const float qq = 2.0f * (tol - fthr);
-    if (!(detm > 0.0f) || !(ix > 0.0f) || !(qq == qq)) return 0xFu;
-    if (qq < 0.0f) return 0u;                                     // the threshold is out of reach everywhere
-    const float vmax = __builtin_amdgcn_sqrtf(qq * ix * __builtin_amdgcn_rcpf(detm)) * 1.0001f + 0.05f;   // 1-ulp ops, inside the margin
-    if (!(vmax == vmax) || vmax > 1.0e6f) return 0xFu;
-    const float lo = sy - vmax - tile_y0, hi = sy + vmax - tile_y0;   // rows relative to the tile, as reals
-    uint32_t m = 0u;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) m |= (hi >= (float)(4 * w) && lo <= (float)(4 * w + 3)) ? (1u << w) : 0u;
-    return m;
-}
-
 // RenderGaussians.comp:127-142 for one pixel and one list entry whose alpha is known: the `continue` on alpha < 1/255,
 // the colour add, add-then-test transmittance.  `need` = the pixel is live and the exponent passed the f tests.
 template <bool EXACT>
@@ -432,27 +419,55 @@ __device__ __forceinline__ void blend_entry(bool need, float alpha, float cr, fl
     T = (act && !fin) ? next_t : T;                                    // :142
 }
 
-// One 256-thread workgroup per tile, one pixel per lane -- the reference's own shape (RenderGaussians.comp:
-// local_size 16x16, 256-splat shared batch) with wave-level scheduling on top.  Per batch of 256 list entries: thread
-// t fetches entry t (prefetched one batch ahead), tests it ONCE for the tile and stores it at slot t together with
-// the mask of 4-row strips it can reach (0 = dropped: it provably touches no pixel of the tile).  After ONE barrier
-// each wave turns the masks into four 64-bit scalar bit sets -- ballot of "entry reaches my strip" -- and walks only
-// the set bits, in list order: a splat three pixels across costs the one wave it lies in a visit, not all four.
-// The walk takes TWO entries per step: their exponents, the pinned exp and alpha are evaluated side by side in the
-// two halves of packed fp32 instructions (v_pk_mul / v_pk_add / v_pk_fma are IEEE per component, so each half goes
-// through exactly the scalar operation sequence of :119-124), then the two blends run one after the other in list
-// order (:127-142 is a chain through T).  A wave whose 64 pixels are all done stops blending but keeps staging; the
-// workgroup leaves the list when all four are done.
+// Two list entries (slots ja, jb of the staged batch; jb == ja and two == false for a single one) against one pixel per
+// lane: their exponents, the pinned exp and alpha are evaluated side by side in the two halves of packed fp32
+// instructions (v_pk_mul / v_pk_add / v_pk_fma are IEEE per component, so each half goes through exactly the scalar
+// operation sequence of RenderGaussians.comp:119-124), then the two blends run one after the other in list order
+// (:127-142 is a chain through T).  `two` is wave-uniform.
 template <bool EXACT>
-__global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
-                                                    const SplatRaster* __restrict__ raster,
-                                                    const uint32_t* __restrict__ sorted_id,
-                                                    const uint32_t* __restrict__ ranges,
-                                                    const uint32_t* __restrict__ order,
-                                                    uint32_t* __restrict__ rgba) {
-    __shared__ float4 s_batch[256][3];
-    __shared__ uint32_t s_mask[256];
-    __shared__ uint32_t s_done;
+__device__ __forceinline__ void blend_pair(const float4 (*batch)[3], int ja, int jb, bool two, float fpx, float fpy,
+                                           float& col0, float& col1, float& col2, float& T, bool& done) {
+    const float4 a0 = batch[ja][0], a1 = batch[ja][1];
+    const float2 a2 = *reinterpret_cast<const float2*>(&batch[ja][2]);
+    const float4 b0 = batch[jb][0], b1 = batch[jb][1];
+    const float2 b2 = *reinterpret_cast<const float2*>(&batch[jb][2]);
+    const v2f ex = (v2f){a0.x, b0.x} - (v2f){fpx, fpx};                          // :119
+    const v2f ey = -((v2f){a0.y, b0.y} - (v2f){fpy, fpy});                       // :119-120
+    const v2f ixv = {a0.z, b0.z}, iyv = {a0.w, b0.w}, izv = {a1.x, b1.x};
+    v2f f;
+    if constexpr (EXACT) {
+        f = (v2f){-0.5f, -0.5f} * (ixv * ex * ex + izv * ey * ey) - iyv * ex * ey;   // :123
+    } else {
+        const v2f q = __builtin_elementwise_fma(ixv * ex, ex, izv * ey * ey);
+        f = __builtin_elementwise_fma((v2f){-0.5f, -0.5f}, q, -(iyv * ey * ex));
+    }
+    const bool live_a = !(f.x > 0.0f) && !(f.x < a2.y);
+    const bool live_b = two && !(f.y > 0.0f) && !(f.y < b2.y);
+    if (!__any(!done && (live_a || live_b))) return;                   // nobody in these rows can pass :127
+    v2f alpha;
+    if constexpr (EXACT) {
+        alpha = (v2f){a2.x, b2.x} * exp_pinned2(f);                    // :124
+    } else {
+        const v2f t = f * (v2f){0x1.715476p+0f, 0x1.715476p+0f};
+        alpha = (v2f){a2.x, b2.x} * (v2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    }
+    blend_entry<EXACT>(!done && live_a, alpha.x, a1.y, a1.z, a1.w, col0, col1, col2, T, done);
+    blend_entry<EXACT>(!done && live_b, alpha.y, b1.y, b1.z, b1.w, col0, col1, col2, T, done);
+}
+
+// One 256-thread workgroup per tile, one pixel per lane -- the reference's own launch shape (RenderGaussians.comp:
+// local_size 16x16) -- but its four waves share nothing except the launch: wave w owns the pixel rows 4 w .. 4 w + 3 of
+// the tile and walks the tile's list on its own in batches of 64 entries -- its own gather (prefetched one batch ahead),
+// the exact rectangle test against its own 16 x 4 pixels, order-preserving compaction into its quarter of the LDS
+// buffer, a dense blend loop over the survivors two entries per step (blend_pair) -- and leaves as soon as its 64
+// pixels are done.  No workgroup barrier anywhere: a wave never waits for the wave with the most visits in a batch,
+// which is what the shared 256-entry batch of the shader (and of this kernel until round 3) costs on long lists
+// (profiles/r03_render_variants.txt: sharing the first 1, 2, 3, 4 or all batches loses 3 / 7 / 12 / 18 / 27 % on the
+// capture-like cloud and 15 - 22 % on the uniform one, although every entry is then gathered four times).
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp, const SplatRaster* __restrict__ raster, const uint32_t* __restrict__ sorted_id,
+                 const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ order, uint32_t* __restrict__ rgba) {
+    __shared__ float4 s_batch[256][3];     // {sx, sy, inv.x, inv.y}, {inv.z, r, g, b}, {a, skip threshold, -, -}; 64 slots per wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tile_in_band = order ? order[blockIdx.x] : blockIdx.x;   // longest lists first (k_tile_order)
@@ -465,80 +480,41 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
     const uint32_t py = ty * kTile + (uint32_t)wave * 4u + (uint32_t)(lane >> 4);
     const uint32_t px = tx * kTile + (uint32_t)(lane & 15);
     const float fpx = (float)px, fpy = (float)py;                      // integer pixel coords (R1)
-    const float tile_x0 = (float)(tx * kTile), tile_y0 = (float)(ty * kTile);
+    const float tile_x0 = (float)(tx * kTile), wave_y0 = (float)(ty * kTile + (uint32_t)wave * 4u);
 
     float col0 = 0.0f, col1 = 0.0f, col2 = 0.0f, T = 1.0f;
     bool done = !(px < fp.width && py < fp.height);                    // never stored (:147)
-    bool wave_done = __all(done);
-    if (tid == 0) s_done = 0u;
-    __syncthreads();
-    if (wave_done && lane == 0) atomicAdd(&s_done, 1u);
-
-    Fetched nxt = fetch_splat(raster, sorted_id, start + tid, end);
-    for (uint32_t i = start; i < end; i += 256) {                      // :81
-        uint32_t mask = 0u;
-        if (stage_splat(nxt, tile_x0, tile_y0, 15.0f)) {
-            // the bound on the rounding of the per-pixel exponent that stage_splat's rectangle test uses, over the tile
-            const float far_x = fmaxf(fabsf(nxt.a.x - tile_x0), fabsf(nxt.a.x - (tile_x0 + 15.0f)));
-            const float far_y = fmaxf(fabsf(nxt.a.y - tile_y0), fabsf(nxt.a.y - (tile_y0 + 15.0f)));
-            const float mag = fabsf(nxt.a.z) * far_x * far_x + fabsf(nxt.b.x) * far_y * far_y + 2.0f * fabsf(nxt.a.w) * far_x * far_y;
-            mask = strip_mask(nxt.a.y, nxt.a.z, nxt.a.w, nxt.b.x, nxt.c.y, 0.01f + 8e-6f * mag, tile_y0);
-        }
-        if (mask) {
-            s_batch[tid][0] = nxt.a;
-            s_batch[tid][1] = nxt.b;
-            *reinterpret_cast<float2*>(&s_batch[tid][2]) = make_float2(nxt.c.x, nxt.c.y);
-        }
-        s_mask[tid] = mask;
-        __syncthreads();                                               // :109; s_done of the previous batch settled
-        if (s_done == 4u) break;                                       // every pixel of the tile is finished
-        nxt = fetch_splat(raster, sorted_id, i + 256 + tid, end);      // prefetch next batch
-
-        if (!wave_done) {
-#pragma unroll 1
-            for (int k = 0; k < 4 && !wave_done; ++k) {
-                uint64_t m = __ballot((s_mask[k * 64 + lane] >> wave) & 1u);   // entries of this chunk that reach my rows
-                while (m) {                                            // :112, list order, two entries per step
-                    const int ja = k * 64 + __builtin_ctzll(m);
-                    m &= m - 1;
-                    const bool two = m != 0ull;                        // wave-uniform
-                    const int jb = two ? k * 64 + __builtin_ctzll(m) : ja;
-                    m &= m - 1;                                        // 0 stays 0
-                    const float4 a0 = s_batch[ja][0], a1 = s_batch[ja][1];
-                    const float2 a2 = *reinterpret_cast<const float2*>(&s_batch[ja][2]);
-                    const float4 b0 = s_batch[jb][0], b1 = s_batch[jb][1];
-                    const float2 b2 = *reinterpret_cast<const float2*>(&s_batch[jb][2]);
-                    const v2f ex = (v2f){a0.x, b0.x} - (v2f){fpx, fpx};          // :119
-                    const v2f ey = -((v2f){a0.y, b0.y} - (v2f){fpy, fpy});       // :119-120
-                    const v2f ixv = {a0.z, b0.z}, iyv = {a0.w, b0.w}, izv = {a1.x, b1.x};
-                    v2f f;
-                    if constexpr (EXACT) {
-                        f = (v2f){-0.5f, -0.5f} * (ixv * ex * ex + izv * ey * ey) - iyv * ex * ey;   // :123
-                    } else {
-                        const v2f q = __builtin_elementwise_fma(ixv * ex, ex, izv * ey * ey);
-                        f = __builtin_elementwise_fma((v2f){-0.5f, -0.5f}, q, -(iyv * ey * ex));
-                    }
-                    const bool live_a = !(f.x > 0.0f) && !(f.x < a2.y);
-                    const bool live_b = two && !(f.y > 0.0f) && !(f.y < b2.y);
-                    if (!__any(!done && (live_a || live_b))) continue; // nobody in these rows can pass :127
-                    v2f alpha;
-                    if constexpr (EXACT) {
-                        alpha = (v2f){a2.x, b2.x} * exp_pinned2(f);    // :124
-                    } else {
-                        const v2f t = f * (v2f){0x1.715476p+0f, 0x1.715476p+0f};
-                        alpha = (v2f){a2.x, b2.x} * (v2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-                    }
-                    blend_entry<EXACT>(!done && live_a, alpha.x, a1.y, a1.z, a1.w, col0, col1, col2, T, done);
-                    blend_entry<EXACT>(!done && live_b, alpha.y, b1.y, b1.z, b1.w, col0, col1, col2, T, done);
-                    if (__all(done)) {                                 // this wave's rows are finished
-                        wave_done = true;
-                        if (lane == 0) atomicAdd(&s_done, 1u);
-                        break;
-                    }
-                }
+    if (!__all(done)) {
+        float4 (*wbatch)[3] = s_batch + wave * 64;                     // this wave's quarter of the buffer
+        Fetched nxt = fetch_splat(raster, sorted_id, start + lane, end);
+        for (uint32_t i = start; i < end; i += 64) {                   // :81
+            const bool keep = stage_splat(nxt, tile_x0, wave_y0, 3.0f);
+            const uint64_t kmask = __ballot(keep);
+            const int n = (int)__popcll(kmask);
+            if (keep) {
+                const uint32_t slot = mbcnt(kmask);                    // order-preserving compaction
+                wbatch[slot][0] = nxt.a;
+                wbatch[slot][1] = nxt.b;
+                *reinterpret_cast<float2*>(&wbatch[slot][2]) = make_float2(nxt.c.x, nxt.c.y);
             }
+            // one wave writes and reads these slots and the DS operations of a wave execute in order: no barrier
+            // instruction, only fences that keep the compiler from moving the reads below above the writes (:109)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            nxt = fetch_splat(raster, sorted_id, i + 64 + lane, end);  // prefetch next batch
+            bool finished = false;
+#pragma unroll 1
+            for (int j = 0; j < n; j += 2) {                           // :112, two entries per step
+                const bool two = j + 1 < n;
+                blend_pair<EXACT>(wbatch, j, two ? j + 1 : j, two, fpx, fpy, col0, col1, col2, T, done);
+                if (__all(done)) { finished = true; break; }           // this wave's rows are finished
+            }
+            if (finished) break;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // ... nor the next batch's writes above these reads (:84)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __syncthreads();                                               // :84
     }
     // :147-151 clamp + RGBA8 UNORM store, A = 255
     if (px < fp.width && py < fp.height) {
@@ -551,19 +527,17 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
     }
 }
 
-// Launch shape (gs_config.render_kernel; every shape gives the same pixels).  AUTO picks by the number of tiles
-// to render, from these measurements on MI355X (exact mode, ms; 1 / 2 / 4 px per lane with independent waves,
-// then the shared-batch workgroup):
-//    920 tiles (config A)                 0.056 / 0.075 / 0.126 / 0.064
-//   1080 tiles (C, 1/8 row band)          0.068 / 0.095 / 0.148 / 0.080
-//   2040 tiles (C, 1/4 band)              0.085 / 0.103 / 0.159 / 0.087
-//   3600 tiles (config B)                 0.102 / 0.104 / 0.125 / 0.102
-//   4080 tiles (C, lower / upper half)    0.249, 0.133 / 0.285, 0.143 / 0.179, 0.191 / 0.142, 0.145
-//   8160 tiles (config C)                 0.348 / 0.371 / 0.282 / 0.243
-//  32400 tiles (config D)                 0.709 / 0.620 / 0.670 / 0.695
-// Few tiles cannot fill 1024 SIMDs with one wave each, so they get four independent waves; in the middle the
-// workgroup kernel wins because a tile is staged once and its longest dependent chain is a quarter as long; with
-// very many tiles every shape is throughput-bound and the ones that do the least per-splat work lead.
+// Launch shape (gs_config.render_kernel; every shape gives the same pixels).  AUTO picks by the number of tiles to
+// render, from these measurements on MI355X (round 3, exact mode, ms, longest-first order; 1 / 2 / 4 px per lane with
+// independent one-wave workgroups, then the workgroup per tile; tools/render_probe.py, profiles/r03_render_variants.txt):
+//    920 tiles (config A)                 0.051 / 0.072 /  --   / 0.041
+//   3600 tiles (config B)                 0.099 / 0.102 /  --   / 0.086
+//   8160 tiles (config C, uniform)        0.320 / 0.346 / 0.278 / 0.193
+//   8160 tiles (config C-hard, capture)   0.622 / 0.793 / 1.523 / 0.577
+//  32400 tiles (config D)                 0.647 / 0.574 /  --   / 0.589
+// The workgroup per tile wins or ties everywhere: one launch slot per tile instead of two or four, and its blend loop
+// takes two entries per step.  Only a 4K frame's 32 k tiles come out 2-7 % ahead with two pixels per lane (half as many
+// gathers and rectangle tests per tile).
 void launch_find_ranges(const FrameParams& fp, const uint32_t* sorted_tile, const SortParams* params,
                         uint32_t* ranges, hipStream_t stream) {
     uint32_t blocks = (fp.capacity / 4u + 255u) / 256u;
@@ -576,28 +550,77 @@ void launch_find_ranges(const FrameParams& fp, const uint32_t* sorted_tile, cons
 // Dispatch order of RenderGaussians' tiles: longest list first.  Workgroups are handed out in grid order and a tile's
 // time grows with its list, so on a capture-like scene (a few tiles with tens of thousands of entries, most with
 // hundreds) raster order leaves the heaviest tiles wherever they happen to lie and the launch ends on them; sorted by
-// list length the tail is made of the shortest tiles.  One workgroup: counting sort of the owned tiles into 32
-// classes by bits(end - start), longest class first, any order inside a class (every order gives the same pixels).
+// list length the tail is made of the shortest tiles.  One workgroup: the owned tiles binned into 33 classes by
+// bits(end - start), longest class first, any order inside a class (every order gives the same pixels).
+// The LDS counters are fed per wave and class -- the lanes of a class elect a leader that adds their number -- not per
+// tile (1024 threads on three or four addresses took 50 us at 4K).
+__device__ __forceinline__ uint32_t class_slot(uint32_t cls, bool active, uint32_t* counters) {
+    // For an active lane: the value of counters[cls] before this wave's lanes of that class, plus the lane's rank among
+    // them.  The lanes of one class find each other with one ballot per class bit (as the radix Scatter finds equal
+    // digits); the first lane of every class adds their number -- all classes of the wave in ONE atomic instruction.
+    uint64_t same = __ballot(active);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const bool bit = (cls >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        same &= bit ? bal : ~bal;
+    }
+    const uint32_t rank = mbcnt(same);
+    uint32_t base = 0u;
+    if (active && rank == 0u) base = atomicAdd(&counters[cls], (uint32_t)__popcll(same));
+    base = (uint32_t)__shfl((int)base, active ? __builtin_ctzll(same) : 0, 64);   // from the class leader (every lane takes part)
+    return base + rank;
+}
+
+constexpr int kOrderRounds = 8;     // tiles a thread has in flight at once: 8192 tiles per sweep of the workgroup
 __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order,
-                                                      uint32_t tiles, TileMap map) {
-    __shared__ uint32_t s_count[33], s_cursor[33];
-    if (threadIdx.x < 33) { s_count[threadIdx.x] = 0u; s_cursor[threadIdx.x] = 0u; }
+                                                      uint32_t* __restrict__ scratch, uint32_t tiles, TileMap map) {
+    __shared__ uint32_t s_count[33];
+    if (threadIdx.x < 33) s_count[threadIdx.x] = 0u;
     __syncthreads();
-    auto tile_class = [&](uint32_t c) {
-        const uint2 r = reinterpret_cast<const uint2*>(ranges)[global_tile(map, c)];
-        const uint32_t len = r.y > r.x ? r.y - r.x : 0u;
-        return len ? 32u - (uint32_t)__builtin_clz(len) : 0u;     // bits(len): 0 for an empty tile, else 1 .. 32
-    };
-    for (uint32_t c = threadIdx.x; c < tiles; c += 1024u) atomicAdd(&s_count[tile_class(c)], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) {   // first position of every class, longest class first
-        uint32_t run = 0u;
-        for (int b = 32; b >= 0; --b) { const uint32_t n = s_count[b]; s_count[b] = run; run += n; }
+    // Class of every tile and its slot inside the class (arrival order: what the class counter held when the tile's
+    // wave added its lanes), packed into scratch[c] -- written and read back by the same thread.  The ranges of
+    // kOrderRounds tiles per thread are loaded up front: the kernel is one workgroup and all latency.
+    for (uint32_t c0 = 0; c0 < tiles; c0 += (uint32_t)kOrderRounds * 1024u) {
+        uint2 r[kOrderRounds];
+#pragma unroll
+        for (int k = 0; k < kOrderRounds; ++k) {
+            const uint32_t c = c0 + (uint32_t)k * 1024u + threadIdx.x;
+            r[k] = c < tiles ? reinterpret_cast<const uint2*>(ranges)[global_tile(map, c)] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < kOrderRounds; ++k) {
+            const uint32_t c = c0 + (uint32_t)k * 1024u + threadIdx.x;
+            if (c0 + (uint32_t)k * 1024u >= tiles) break;              // uniform: whole waves vote in every round
+            const bool active = c < tiles;
+            const uint32_t len = r[k].y > r[k].x ? r[k].y - r[k].x : 0u;
+            const uint32_t cls = len ? 32u - (uint32_t)__builtin_clz(len) : 0u;   // bits(len): 0 for an empty tile, else 1 .. 32
+            const uint32_t slot = class_slot(cls, active, s_count);
+            if (active) scratch[c] = cls | (slot << 6);
+        }
     }
     __syncthreads();
-    for (uint32_t c = threadIdx.x; c < tiles; c += 1024u) {
-        const uint32_t b = tile_class(c);
-        order[s_count[b] + atomicAdd(&s_cursor[b], 1u)] = c;
+    // first position of every class, longest class first: an inclusive DPP scan over the reversed counters (wave 0)
+    uint32_t base = 0u;
+    if (threadIdx.x < 64) {
+        const uint32_t n = threadIdx.x < 33 ? s_count[32 - threadIdx.x] : 0u;
+        base = wave_inclusive_scan(n) - n;
+    }
+    __syncthreads();
+    if (threadIdx.x < 33) s_count[32 - threadIdx.x] = base;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < tiles; c0 += (uint32_t)kOrderRounds * 1024u) {
+        uint32_t v[kOrderRounds];
+#pragma unroll
+        for (int k = 0; k < kOrderRounds; ++k) {
+            const uint32_t c = c0 + (uint32_t)k * 1024u + threadIdx.x;
+            v[k] = c < tiles ? scratch[c] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kOrderRounds; ++k) {
+            const uint32_t c = c0 + (uint32_t)k * 1024u + threadIdx.x;
+            if (c < tiles) order[s_count[v[k] & 63u] + (v[k] >> 6)] = c;
+        }
     }
 }
 
@@ -605,7 +628,8 @@ void launch_tile_order(const FrameParams& fp, const uint32_t* ranges, uint32_t* 
     const uint32_t tiles = fp.rows_owned * fp.grid_w;
     if (tiles == 0) return;
     const TileMap map{fp.grid_w, fp.first_row, fp.row_stride};
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, ranges, order, tiles, map);
+    // order[0 .. tiles) is the table, order[grid_w * grid_h ...) the kernel's scratch (gs_set_resolution allocates both)
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, ranges, order, order + (size_t)fp.grid_w * fp.grid_h, tiles, map);
 }
 
 void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
@@ -622,7 +646,7 @@ void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint3
     const uint32_t tiles = fp.rows_owned * fp.grid_w;
     if (tiles == 0) return;
     uint32_t* out = reinterpret_cast<uint32_t*>(rgba);
-    const uint32_t px = render_kernel != 0u ? render_kernel : tiles < 1500u ? 1u : tiles < 20000u ? 16u : 2u;
+    const uint32_t px = render_kernel != 0u ? render_kernel : tiles < 20000u ? 16u : 2u;
 #define GS_LAUNCH_RENDER(EXACT, PX)                                                                   \
     hipLaunchKernelGGL((k_render<EXACT, PX, false>), dim3(tiles * (4 / PX)), dim3(64), 0, stream, fp, \
                        raster, sorted_id, ranges, order, out, (uint4*)nullptr)
