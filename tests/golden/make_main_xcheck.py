@@ -1,0 +1,90 @@
+"""Generates tests/golden/ref_main_small.npz and ref_main_dense.npz: what the main() bodies of the reference's
+InitSortList.comp, FindRanges.comp and RenderGaussians.comp -- their own text, compiled as C++ over the reference's
+vendored glm by oracle/ref_main_xcheck.cpp, authoring container only -- produce for two scenes:
+
+  small : the 600 splats of small_scene.npz under its camera, SH modes 0, 1, 2
+  dense : 2,500 large, mostly opaque splats under a rotated camera at 200 x 120 (ragged tile grid: 13 x 8 with a
+          half-filled last row and column), so that pixels saturate, the `nextT < 0.0001` break and the alpha / f
+          `continue`s all fire, and tile lists run over several 256-entry batches
+
+A CROSS-CHECK of the restatements against the shader text, not a pin of GLSL arithmetic (header of
+oracle/ref_main_xcheck.cpp).
+
+    make -C oracle ref && python tests/golden/make_main_xcheck.py
+"""
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+EXE = os.path.join(ROOT, "oracle", "_ref", "ref_main_xcheck")
+
+
+def run(aos, view, proj, cam_pos, w, h, sh_mode):
+    n = aos.shape[0]
+    tiles = ((w + 15) // 16) * ((h + 15) // 16)
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<4I", n, w, h, sh_mode))
+            f.write(np.asarray(view, "<f4").tobytes() + np.asarray(proj, "<f4").tobytes() + np.asarray(cam_pos, "<f4").tobytes())
+            f.write(np.ascontiguousarray(aos, "<f4").tobytes())
+        subprocess.run([EXE, fin, fout], check=True)
+        raw = open(fout, "rb").read()
+    counter, capacity = struct.unpack_from("<2I", raw, 0)
+    e = min(counter, capacity)
+    off = 8
+    out = {"counter": np.uint32(counter), "capacity": np.uint32(capacity)}
+    for name, dtype, shape in (("color", "<f4", (n, 4)), ("cov", "<f4", (n, 4)), ("list", "<u4", (e, 3)), ("sorted", "<u4", (e, 3)),
+                               ("ranges", "<u4", (tiles, 2)), ("image_f32", "<f4", (h, w, 4)), ("rgba", "u1", (h, w, 4))):
+        cnt = int(np.prod(shape))
+        out[name] = np.frombuffer(raw, dtype, cnt, off).reshape(shape).copy()
+        off += cnt * np.dtype(dtype).itemsize
+    assert off == len(raw)
+    return out
+
+
+def dense_inputs():
+    """Records stored in the fixture, so it does not depend on numpy's generators."""
+    sys.path.insert(0, ROOT)
+    import oracle
+    from vk3dgaussiansplatting_amd import synth
+    w, h = 200, 120
+    aos = synth.generate(2500, w, h, -0.9, seed=77)
+    rng = np.random.default_rng(5)
+    aos[:, 15] = rng.choice(np.float32([0.999, 0.95, 0.7, 0.3, 0.02, 0.003]), aos.shape[0], p=[0.3, 0.25, 0.2, 0.15, 0.05, 0.05])
+    aos[::9, 4:7] *= np.float32(0.05)                # and some small ones
+    pos = np.array([0.3, -0.1, -1.5], np.float32)
+    view, proj = oracle.camera_matrices(pos, 0.15, -0.08, w / h)    # only a matrix generator here (itself pinned by glm)
+    return aos, view, proj, pos, w, h
+
+
+if __name__ == "__main__":
+    if not os.path.exists(EXE):
+        sys.exit("build oracle/_ref/ref_main_xcheck first (make -C oracle ref; needs /root/reference)")
+    g = np.load(os.path.join(GOLDEN, "small_scene.npz"))
+    keep = {}
+    for mode in (0, 1, 2):
+        o = run(g["aos"], g["view"], g["proj"], g["cam_pos"], int(g["width"]), int(g["height"]), mode)
+        if mode == 0:
+            keep.update({k: o[k] for k in ("counter", "capacity", "cov", "list", "sorted", "ranges")})
+        keep[f"color_mode{mode}"] = o["color"]
+        keep[f"rgba_mode{mode}"] = o["rgba"]
+    path = os.path.join(GOLDEN, "ref_main_small.npz")
+    np.savez_compressed(path, **keep)
+    print("wrote", path, os.path.getsize(path), "bytes; E =", int(keep["counter"]))
+    aos, view, proj, pos, w, h = dense_inputs()
+    o = run(aos, view, proj, pos, w, h, 0)
+    lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
+    print("dense: E =", int(o["counter"]), "tile lists", int(lens.min()), "..", int(lens.max()),
+          "saturated pixels (any channel 255):", int((o["rgba"][..., :3] == 255).any(axis=2).sum()),
+          "black pixels:", int((o["rgba"][..., :3] == 0).all(axis=2).sum()))
+    del o["image_f32"]
+    path = os.path.join(GOLDEN, "ref_main_dense.npz")
+    np.savez_compressed(path, aos=aos, view=view, proj=proj, cam_pos=pos, width=np.uint32(w), height=np.uint32(h), **o)
+    print("wrote", path, os.path.getsize(path), "bytes")

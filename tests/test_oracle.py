@@ -91,6 +91,65 @@ def test_common_glsl_cross_check(oracle_mod, which):
     assert np.all(np.abs(a - b) <= 4 * np.spacing(np.abs(x["viewpos_in"]).max(axis=1, keepdims=True)).astype(np.float64))
 
 
+def _main_xcheck_inputs(which):
+    x = np.load(os.path.join(GOLDEN, f"ref_main_{which}.npz"))
+    g = np.load(os.path.join(GOLDEN, "small_scene.npz")) if which == "small" else x
+    return g, x
+
+
+@pytest.mark.parametrize("which", ["small", "dense"])
+def test_shader_main_bodies_cross_check(oracle_mod, which):
+    """CROSS-CHECK, not a pin: tests/golden/ref_main_*.npz is what the main() bodies of the reference's own
+    InitSortList.comp (:82-151), FindRanges.comp (:42-71) and RenderGaussians.comp (:56-152) produce when their text
+    is compiled as C++ over the reference's vendored glm (oracle/ref_main_xcheck.cpp: invocations in ascending order,
+    256 host threads + a barrier per RenderGaussians workgroup) -- the element counter, the list as emitted (tile,
+    depth key, splat, in order), the stored colour and covariance of every splat, the tile ranges out of FindRanges run
+    over the list capacity with its 0xFFFFFFFF tail, and the frame.  The oracle must agree bit for bit: that rules out a
+    shared misreading of the cull predicates (:94, :100), the emit loop (:130-150), the range writes (:48-70), the batch
+    loop, the zero-determinant rule (:94-107), the two `continue` conditions (:127) and add-then-test transmittance
+    (:131-142).  Where the reference is mounted the committed dump is regenerated and compared first."""
+    from conftest import ROOT
+    g, x = _main_xcheck_inputs(which)
+    w, h = int(g["width"]), int(g["height"])
+    modes = (0, 1, 2) if which == "small" else (0,)
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_main_xcheck")
+    if os.path.isdir("/root/reference/vkGaussianSplatting") and os.path.exists(exe):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("make_main_xcheck", os.path.join(GOLDEN, "make_main_xcheck.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        for mode in modes:
+            fresh = mod.run(g["aos"], g["view"], g["proj"], g["cam_pos"], w, h, mode)
+            names = {"color": f"color_mode{mode}", "rgba": f"rgba_mode{mode}"} if which == "small" else {}
+            for k in ("counter", "cov", "list", "sorted", "ranges", "color", "rgba"):
+                if which == "small" and mode and k not in names:
+                    continue
+                assert np.asarray(fresh[k]).tobytes() == np.asarray(x[names.get(k, k)]).tobytes(), (k, mode)
+        if which == "dense":
+            assert mod.dense_inputs()[0].tobytes() == g["aos"].tobytes()
+    for mode in modes:
+        p = oracle_mod.make_params(w, h, g["view"], g["proj"], g["cam_pos"], sh_mode=mode)
+        r = oracle_mod.full_pipeline(p, g["aos"])
+        e, s1 = r["e"], r["stage1"]
+        col = x[f"color_mode{mode}"] if which == "small" else x["color"]
+        img = x[f"rgba_mode{mode}"] if which == "small" else x["rgba"]
+        assert np.array_equal(s1["color"].view(np.uint32), col.view(np.uint32))
+        assert np.array_equal(r["image"], img)
+        if mode == 0:
+            assert s1["counter"] == int(x["counter"]) and s1["capacity"] == int(x["capacity"]) and e > 2000
+            assert np.array_equal(np.stack([s1["tile"][:e], s1["depth"][:e], s1["id"][:e]], axis=1), x["list"])
+            assert np.array_equal(np.stack([r["tile"][:e], r["depth"][:e], r["id"][:e]], axis=1), x["sorted"])
+            assert np.array_equal(s1["cov"].view(np.uint32), x["cov"].view(np.uint32))
+            assert np.array_equal(r["ranges"], x["ranges"])
+            # the oracle's literal FindRanges (capacity-long list with the sentinel tail, as the shader is dispatched)
+            padded = np.full(int(s1["capacity"]), 0xFFFFFFFF, np.uint32)
+            padded[:e] = r["tile"][:e]
+            assert np.array_equal(oracle_mod.find_ranges(padded, padded.size, r["ranges"].shape[0], literal=True), x["ranges"])
+    if which == "dense":
+        lens = x["ranges"][:, 1].astype(np.int64) - x["ranges"][:, 0]
+        assert lens.max() > 256, "the dense scene must need more than one 256-entry batch"
+
+
 def test_camera_matrices_match_reference_glm(oracle_mod, ref_golden):
     """view/proj bit-identical to glm::lookAt / glm::perspective run from /root/reference (Camera.cpp:7-48)."""
     for cam in ref_golden["cameras"]:

@@ -572,7 +572,7 @@ __device__ __forceinline__ uint32_t class_slot(uint32_t cls, bool active, uint32
     return base + rank;
 }
 
-constexpr int kOrderRounds = 8;     // tiles a thread has in flight at once: 8192 tiles per sweep of the workgroup
+constexpr int kOrderRounds = 32;    // tiles a thread has in flight at once: 32768 tiles (a 4K frame) per sweep of the workgroup
 __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order,
                                                       uint32_t* __restrict__ scratch, uint32_t tiles, TileMap map) {
     __shared__ uint32_t s_count[33];
