@@ -73,6 +73,9 @@ def parse_args(argv=None):
                     help="no GPU work: the ranks run only the launcher / process-group / strip-gather plumbing on the CPU "
                          "(gloo) with a fill pattern in place of the band render and print the JSON skeleton "
                          "(tests/test_bench_launcher.py)")
+    ap.add_argument("--rank-timeout", type=int, default=900,
+                    help="N > 1: seconds after which a launch that has not finished is killed (exit code 4); inside a rank "
+                         "every collective has a 180 s limit of its own")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: every rank uses cuda:0 and the strip gather goes "
                          "through gloo on the host (RCCL needs one GPU per rank)")
@@ -81,7 +84,10 @@ def parse_args(argv=None):
 
 def launch_ranks(args):
     """--gpus N outside a torch.distributed launch: start the N ranks ourselves.  This parent never imports torch or
-    touches HIP; the ranks are fresh child processes (never an exec of a process that has initialised the GPU)."""
+    touches HIP; the ranks are fresh child processes (never an exec of a process that has initialised the GPU).  The
+    launch gets a wall-clock limit: a rank that hangs in a collective must not take the whole run with it -- the ranks
+    run in a process group of their own, which is what gets killed."""
+    import signal
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -90,7 +96,17 @@ def launch_ranks(args):
     log(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=args.rank_timeout)
+    except subprocess.TimeoutExpired:
+        log(f"[bench] ERROR: the ranks did not finish within {args.rank_timeout} s (a rank hung?): killing process group {proc.pid}")
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        return 4
 
 
 def pmc_traffic(args):
@@ -256,11 +272,24 @@ def main():
     tdist = None
     if world > 1:
         import torch.distributed as tdist
+        import datetime
+        limit = datetime.timedelta(seconds=180)          # a collective that takes longer is a hang: fail, do not wait for ever
         if args.rehearse:
-            tdist.init_process_group(backend="gloo")
+            tdist.init_process_group(backend="gloo", timeout=limit)
         else:
-            tdist.init_process_group(backend="nccl", device_id=device)
+            tdist.init_process_group(backend="nccl", device_id=device, timeout=limit)
         assert tdist.get_world_size() == world
+        # first-real-run self-checks (no N-GPU box is reachable while this is written): the strips must travel over
+        # RCCL, and every rank must sit on a card of its own
+        backend = tdist.get_backend()
+        if not args.rehearse and backend != "nccl":
+            log(f"[bench] ERROR: process group backend is {backend!r}, expected 'nccl' (RCCL)")
+            sys.exit(3)
+        ids = [None] * world
+        tdist.all_gather_object(ids, (local_rank, torch.cuda.get_device_properties(device).name))
+        if not args.rehearse and len({i[0] for i in ids}) != world:
+            log(f"[bench] ERROR: ranks share devices: {ids}")
+            sys.exit(3)
     # one explicit HIP stream for the frame kernels AND the strip gather (torch orders RCCL after it)
     torch.cuda.set_stream(torch.cuda.Stream(device=device))
 
@@ -372,7 +401,7 @@ def main():
 
     # N > 1: the assembled frame must equal what one GPU renders alone (checked once, untimed); the single-GPU
     # render of the same frame is also timed (a few frames), so the line carries its own strong-scaling reference
-    sharded_ok, one_gpu_ms = None, None
+    sharded_ok, one_gpu_ms, gather_ms = None, None, None
     if world > 1:
         with torch.cuda.stream(ring.streams[0]):
             ring.sf.wait(0)
@@ -393,6 +422,16 @@ def main():
             rf.cleanup()
             sharded_ok = bool(torch.equal(ring.sf.assemble(strips).to(full.device), full))
             log(f"[bench] sharded frame equals the single-GPU frame: {sharded_ok}; one GPU alone: {one_gpu_ms:.3f} ms")
+        ring.barrier()
+        # the collective alone: the strips are already rendered, 20 gathers back to back, slowest rank
+        t_g = time.perf_counter()
+        for _ in range(20):
+            with torch.cuda.stream(ring.streams[0]):
+                ring.sf.gather(0)
+        torch.cuda.synchronize()
+        g_ms = torch.tensor([(time.perf_counter() - t_g) / 20 * 1e3], dtype=torch.float64, device="cpu" if args.rehearse else device)
+        tdist.all_reduce(g_ms, op=tdist.ReduceOp.MAX)
+        gather_ms = float(g_ms.item())
         ring.barrier()
 
     ms_per_step = ring.timed(args.steps, args.warmup)
@@ -737,16 +776,23 @@ def main():
             out["per_rank_total_ms"] = [round(float(s[6]), 4) for s in allstats]
             out["per_rank_buckets_ms"] = [[round(float(x), 4) for x in s[2:6]] for s in allstats]
             out["per_rank_sort_elements"] = [int(s[0]) for s in allstats]
+            out["sort_elements_imbalance_max_over_mean"] = round(max(float(s[0]) for s in allstats) / max(1.0, e_total / world), 3)
+            out["gather_ms"] = round(gather_ms, 4) if gather_ms is not None else None
+            out["gather_note"] = "one gather of the RGBA8 strips to rank 0 alone (strips already rendered), mean of 20, slowest rank"
             out["one_gpu_same_frame_ms"] = round(one_gpu_ms, 4) if one_gpu_ms else None
             out["speedup_vs_one_gpu_same_frame"] = round(one_gpu_ms / ms_per_step, 3) if one_gpu_ms else None
         if world == 1 and not args.no_cpu_baseline:
             import oracle
             out["cpu_baseline"] = cpu_baseline(aos, cfg, oracle)
+        if world > 1 and sharded_ok is False:
+            out["error"] = "the frame assembled from the ranks' strips differs from the frame one GPU renders alone"
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         tdist.barrier()
         tdist.destroy_process_group()
+        if rank == 0 and sharded_ok is False:
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -155,6 +155,34 @@ def test_ply_conversion(tmp_path, fmt):
     assert np.allclose(got[:, ~exact], want[:, ~exact], rtol=2e-7, atol=0)
 
 
+def test_ply_streaming_conversion_many_rows_and_partial_output(tmp_path):
+    """The two-sweep converter (positions -> Morton order, then every row straight into its slot) on a file of several
+    read chunks (70 k rows x 248 B = 17 MB; the chunk is 16 MB) with many equal Morton codes (positions on a coarse
+    lattice: the stable order decides): the count alone (no output), the whole array, and only the first records of
+    the Morton order -- which must be exactly the head of the whole array."""
+    import ctypes as C
+    from vk3dgaussiansplatting_amd import synth
+    rng = np.random.default_rng(9)
+    n = 70_000
+    table = rng.normal(size=(n, len(PLY_PROPS))).astype(np.float32)
+    table[:, :3] = rng.integers(-6, 7, size=(n, 3)).astype(np.float32)          # 13^3 lattice points: ties everywhere
+    path = str(tmp_path / "big.ply")
+    _write_ply(path, table)
+    L = _lib.lib()
+    cnt = C.c_uint32()
+    assert L.gs_convert_ply(os.fsencode(path), None, 0, C.byref(cnt)) == 0 and cnt.value == n
+    full = np.zeros((n, 84), np.float32)
+    assert L.gs_convert_ply(os.fsencode(path), full.ctypes.data_as(C.c_void_p), n, C.byref(cnt)) == 0
+    want = _expected_records(table)
+    order = np.argsort(synth.morton_codes(want[:, 0:3]), kind="stable")
+    exact = np.ones(84, bool)
+    exact[[4, 5, 6, 15]] = False
+    assert np.array_equal(full[:, exact], want[order][:, exact])
+    head = np.full((1000 + 8, 84), -7.0, np.float32)
+    assert L.gs_convert_ply(os.fsencode(path), head.ctypes.data_as(C.c_void_p), 1000, C.byref(cnt)) == 0 and cnt.value == n
+    assert np.array_equal(head[:1000], full[:1000]) and np.all(head[1000:] == -7.0)      # nothing beyond max_records is touched
+
+
 def test_ply_missing_file_and_bad_header(tmp_path, capsys):
     rm = gs.ResourceManager()
     rm.loadGaussians(str(tmp_path / "nope.ply"))        # Log::error + return, list unchanged

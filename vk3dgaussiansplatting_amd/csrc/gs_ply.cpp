@@ -54,131 +54,187 @@ uint32_t f2u(float v) {   // glm::uvec3(vec3): truncation; out-of-range pinned t
     return (uint32_t)v;
 }
 
-int convert(const char* path, std::vector<float>& records, uint32_t& n_out, std::string& err) {
-    std::ifstream in(path, std::ios::binary);
-    if (!in) { err = std::string("File cannot be found: ") + (path ? path : "(null)"); return GS_ERR_IO; } // ResourceManager.cpp:169-173
+// What a .ply's first element looks like and where its rows start.
+struct PlyHeader {
+    std::string format;
+    size_t count = 0, row_bytes = 0;
+    std::vector<Prop> props;
+    std::vector<size_t> offs;          // byte offset of every property inside a binary row
+    int col[59];                       // property index of the 59 values the loader reads, in the order of kNames()
+    bool ascii = false, big = false;
+    std::streampos data_pos;
+};
+
+// the 59 named properties of ResourceManager.cpp:186-221
+std::vector<std::string> value_names() {
+    std::vector<std::string> names = {"x", "y", "z", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1",
+                                      "rot_2", "rot_3", "opacity", "f_dc_0", "f_dc_1", "f_dc_2"};
+    for (int i = 0; i < 45; ++i) names.push_back("f_rest_" + std::to_string(i));
+    return names;
+}
+
+int read_header(std::ifstream& in, PlyHeader& h, std::string& err) {
     std::string line;
     if (!std::getline(in, line) || line.substr(0, 3) != "ply") { err = "not a ply file"; return GS_ERR_FORMAT; }
-    std::string format;
-    size_t count = 0;
     bool in_first = false, seen_first = false, header_done = false;
-    std::vector<Prop> props;
     while (std::getline(in, line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
         std::istringstream ss(line);
         std::string tok;
         ss >> tok;
-        if (tok == "format") { ss >> format; }
+        if (tok == "format") { ss >> h.format; }
         else if (tok == "element") {
             std::string name; size_t cnt = 0;
             ss >> name >> cnt;
-            if (!seen_first) { seen_first = true; in_first = true; count = cnt; }   // names[0], ResourceManager.cpp:178-179
+            if (!seen_first) { seen_first = true; in_first = true; h.count = cnt; }   // names[0], ResourceManager.cpp:178-179
             else in_first = false;
         } else if (tok == "property" && in_first) {
             Prop p; std::string t; ss >> t;
             if (t == "list") { err = "list property in the gaussian element is not supported"; return GS_ERR_FORMAT; }
             p.type = t; ss >> p.name; p.size = type_size(t); p.is_list = false;
             if (p.size == 0) { err = "unknown property type " + t; return GS_ERR_FORMAT; }
-            props.push_back(p);
+            h.props.push_back(p);
         } else if (tok == "end_header") { header_done = true; break; }
     }
     if (!header_done || !seen_first) { err = "ply header incomplete"; return GS_ERR_FORMAT; }
-    const bool ascii = format == "ascii";
-    const bool big = format == "binary_big_endian";
-    if (!ascii && !big && format != "binary_little_endian") { err = "unsupported ply format " + format; return GS_ERR_FORMAT; }
-    if (count > 0x7FFFFFFFull) { err = "too many gaussians"; return GS_ERR_FORMAT; }
-
-    // the 62 named properties of ResourceManager.cpp:186-221
-    std::vector<std::string> names = {"x", "y", "z", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1",
-                                      "rot_2", "rot_3", "opacity", "f_dc_0", "f_dc_1", "f_dc_2"};
-    for (int i = 0; i < 45; ++i) names.push_back("f_rest_" + std::to_string(i));
-    std::vector<int> col(names.size(), -1);
-    size_t row_bytes = 0;
-    std::vector<size_t> offs(props.size());
-    for (size_t i = 0; i < props.size(); ++i) { offs[i] = row_bytes; row_bytes += props[i].size; }
+    h.ascii = h.format == "ascii";
+    h.big = h.format == "binary_big_endian";
+    if (!h.ascii && !h.big && h.format != "binary_little_endian") { err = "unsupported ply format " + h.format; return GS_ERR_FORMAT; }
+    if (h.count > 0x7FFFFFFFull) { err = "too many gaussians"; return GS_ERR_FORMAT; }
+    const std::vector<std::string> names = value_names();
+    h.offs.resize(h.props.size());
+    for (size_t i = 0; i < h.props.size(); ++i) { h.offs[i] = h.row_bytes; h.row_bytes += h.props[i].size; }
     for (size_t k = 0; k < names.size(); ++k) {
-        for (size_t i = 0; i < props.size(); ++i)
-            if (props[i].name == names[k]) { col[k] = (int)i; break; }
-        if (col[k] < 0) { err = "ply is missing property " + names[k]; return GS_ERR_FORMAT; }
-        if (!is_f32(props[col[k]].type) && !is_f64(props[col[k]].type)) {
+        h.col[k] = -1;
+        for (size_t i = 0; i < h.props.size(); ++i)
+            if (h.props[i].name == names[k]) { h.col[k] = (int)i; break; }
+        if (h.col[k] < 0) { err = "ply is missing property " + names[k]; return GS_ERR_FORMAT; }
+        if (!is_f32(h.props[h.col[k]].type) && !is_f64(h.props[h.col[k]].type)) {
             err = "property " + names[k] + " is not a float"; return GS_ERR_FORMAT;   // hasPropertyType<float>, ResourceManager.h:67
         }
     }
-
-    const size_t n = count;
     // The header's element count is untrusted: before anything of that size is allocated, a binary file must really
     // hold count rows (an ascii row needs at least two bytes per property).
-    {
-        const std::streampos data_pos = in.tellg();
-        in.seekg(0, std::ios::end);
-        const std::streampos end_pos = in.tellg();
-        in.seekg(data_pos);
-        const uint64_t remaining = end_pos > data_pos ? (uint64_t)(end_pos - data_pos) : 0ull;
-        const uint64_t need = (uint64_t)n * (ascii ? 2ull * props.size() : (uint64_t)row_bytes);
-        if (!in || need > remaining) { err = "ply data truncated: the header announces more rows than the file holds"; return GS_ERR_FORMAT; }
-    }
-    std::vector<std::vector<float>> v(names.size(), std::vector<float>(n));
-    if (ascii) {
-        std::vector<double> row(props.size());
-        for (size_t i = 0; i < n; ++i) {
-            for (size_t p = 0; p < props.size(); ++p)
-                if (!(in >> row[p])) { err = "ply data truncated"; return GS_ERR_FORMAT; }
-            for (size_t k = 0; k < names.size(); ++k) v[k][i] = (float)row[col[k]];
-        }
-    } else {
-        std::vector<unsigned char> buf(row_bytes);
-        for (size_t i = 0; i < n; ++i) {
-            if (!in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)row_bytes)) { err = "ply data truncated"; return GS_ERR_FORMAT; }
-            for (size_t k = 0; k < names.size(); ++k) {
-                const Prop& p = props[col[k]];
-                unsigned char tmp[8];
-                std::memcpy(tmp, buf.data() + offs[col[k]], p.size);
-                if (big) std::reverse(tmp, tmp + p.size);
-                if (p.size == 4) { float f; std::memcpy(&f, tmp, 4); v[k][i] = f; }
-                else { double d; std::memcpy(&d, tmp, 8); v[k][i] = (float)d; }
-            }
-        }
-    }
+    h.data_pos = in.tellg();
+    in.seekg(0, std::ios::end);
+    const std::streampos end_pos = in.tellg();
+    in.seekg(h.data_pos);
+    const uint64_t remaining = end_pos > h.data_pos ? (uint64_t)(end_pos - h.data_pos) : 0ull;
+    const uint64_t need = (uint64_t)h.count * (h.ascii ? 2ull * h.props.size() : (uint64_t)h.row_bytes);
+    if (!in || need > remaining) { err = "ply data truncated: the header announces more rows than the file holds"; return GS_ERR_FORMAT; }
+    return GS_OK;
+}
 
-    // ResourceManager.cpp:223-282
-    std::vector<float> rec(n * 84, 0.0f);
+// Walks the rows of the first element once, front to back, in chunks of a few MB (a Garden-size file is 1.4 GB):
+// fn(row index, the first `want` of the 59 values).
+template <typename Fn>
+int for_each_row(std::ifstream& in, const PlyHeader& h, int want, std::string& err, Fn&& fn) {
+    in.clear();
+    in.seekg(h.data_pos);
+    float val[59];
+    if (h.ascii) {
+        std::vector<double> row(h.props.size());
+        for (size_t i = 0; i < h.count; ++i) {
+            for (size_t p = 0; p < h.props.size(); ++p)
+                if (!(in >> row[p])) { err = "ply data truncated"; return GS_ERR_FORMAT; }
+            for (int k = 0; k < want; ++k) val[k] = (float)row[h.col[k]];
+            fn(i, val);
+        }
+        return GS_OK;
+    }
+    const size_t chunk_rows = std::max<size_t>(1, (16u << 20) / h.row_bytes);
+    std::vector<unsigned char> buf(chunk_rows * h.row_bytes);
+    for (size_t i0 = 0; i0 < h.count; i0 += chunk_rows) {
+        const size_t rows = std::min(chunk_rows, h.count - i0);
+        if (!in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)(rows * h.row_bytes))) { err = "ply data truncated"; return GS_ERR_FORMAT; }
+        for (size_t r = 0; r < rows; ++r) {
+            const unsigned char* row = buf.data() + r * h.row_bytes;
+            for (int k = 0; k < want; ++k) {
+                const Prop& p = h.props[h.col[k]];
+                unsigned char tmp[8];
+                std::memcpy(tmp, row + h.offs[h.col[k]], p.size);
+                if (h.big) std::reverse(tmp, tmp + p.size);
+                if (p.size == 4) { float f; std::memcpy(&f, tmp, 4); val[k] = f; }
+                else { double d; std::memcpy(&d, tmp, 8); val[k] = (float)d; }
+            }
+            fn(i0 + r, val);
+        }
+    }
+    return GS_OK;
+}
+
+// ResourceManager.cpp:229-273 for one row: v = the 59 values in value_names() order, g = the 84-float record
+inline void convert_row(const float* v, float* g) {
+    g[0] = v[0] * -1.0f; g[1] = v[1] * -1.0f; g[2] = v[2]; g[3] = 0.0f;                        // :231-236
+    g[4] = std::exp(v[3]); g[5] = std::exp(v[4]); g[6] = std::exp(v[5]); g[7] = 0.0f;          // :237-242
+    float r[4] = {v[6], v[7], v[8], v[9]};                                                      // :244-249
+    const float t0 = r[0] * r[0], t1 = r[1] * r[1], t2 = r[2] * r[2], t3 = r[3] * r[3];
+    const float inv = 1.0f / std::sqrt((t0 + t1) + (t2 + t3));                                 // glm::normalize(vec4), :250
+    for (int a = 0; a < 4; ++a) r[a] = r[a] * inv;
+    g[8] = -r[2]; g[9] = -r[3]; g[10] = r[0]; g[11] = -r[1];                                   // :251-256
+    g[12] = v[11]; g[13] = v[12]; g[14] = v[13];
+    g[15] = 1.0f / (1.0f + std::exp(-v[10]));                                                  // :259-264
+    for (int c = 0; c < 15; ++c) {                                                             // :265-273
+        g[16 + c * 4 + 0] = v[14 + c + 15 * 0];
+        g[16 + c * 4 + 1] = v[14 + c + 15 * 1];
+        g[16 + c * 4 + 2] = v[14 + c + 15 * 2];
+        g[16 + c * 4 + 3] = 0.0f;
+    }
+    for (int k = 76; k < 84; ++k) g[k] = 0.0f;                                                  // color, covariance: scratch
+}
+
+// Two sweeps over the file, nothing but the output held at full size (a Garden-30k .ply is 1.45 GB, its record array
+// 1.96 GB; the first version kept 59 column vectors and two record arrays: 5.3 GB).
+//   sweep 1: positions only -> bounds, Morton codes (ResourceManager.cpp:225-226, 275-297), the stable order;
+//   sweep 2: every row converted (:229-273) straight into its slot of the caller's array.
+// records_out == nullptr: only the count.  At most max_records records (the first ones of the Morton order) are written.
+int convert(const char* path, float* records_out, size_t max_records, uint32_t& n_out, std::string& err,
+            std::vector<float>* grow = nullptr) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) { err = std::string("File cannot be found: ") + (path ? path : "(null)"); return GS_ERR_IO; } // ResourceManager.cpp:169-173
+    PlyHeader h;
+    if (int rc = read_header(in, h, err)) return rc;
+    const size_t n = h.count;
+    n_out = (uint32_t)n;
+    if (grow) { grow->assign(n * 84, 0.0f); records_out = grow->data(); max_records = n; }
+    if (!records_out || n == 0) return GS_OK;
+
+    // sweep 1 (ResourceManager.cpp:223-227, 231-236, 275-281)
+    std::vector<float> pos(n * 3);
     float min_pos[3], max_pos[3];
     for (int a = 0; a < 3; ++a) { min_pos[a] = std::numeric_limits<float>::max(); max_pos[a] = std::numeric_limits<float>::min(); } // :225-226 (min() = smallest positive, as written)
-    for (size_t i = 0; i < n; ++i) {
-        float* g = &rec[i * 84];
-        g[0] = v[0][i] * -1.0f; g[1] = v[1][i] * -1.0f; g[2] = v[2][i]; g[3] = 0.0f;          // :231-236
-        g[4] = std::exp(v[3][i]); g[5] = std::exp(v[4][i]); g[6] = std::exp(v[5][i]); g[7] = 0.0f; // :237-242
-        float r[4] = {v[6][i], v[7][i], v[8][i], v[9][i]};                                       // :244-249
-        const float t0 = r[0] * r[0], t1 = r[1] * r[1], t2 = r[2] * r[2], t3 = r[3] * r[3];
-        const float inv = 1.0f / std::sqrt((t0 + t1) + (t2 + t3));                              // glm::normalize(vec4), :250
-        for (int a = 0; a < 4; ++a) r[a] = r[a] * inv;
-        g[8] = -r[2]; g[9] = -r[3]; g[10] = r[0]; g[11] = -r[1];                                // :251-256
-        g[12] = v[11][i]; g[13] = v[12][i]; g[14] = v[13][i];
-        g[15] = 1.0f / (1.0f + std::exp(-v[10][i]));                                            // :259-264
-        for (int c = 0; c < 15; ++c) {                                                          // :265-273
-            g[16 + c * 4 + 0] = v[14 + c + 15 * 0][i];
-            g[16 + c * 4 + 1] = v[14 + c + 15 * 1][i];
-            g[16 + c * 4 + 2] = v[14 + c + 15 * 2][i];
-            g[16 + c * 4 + 3] = 0.0f;
-        }
-        for (int a = 0; a < 3; ++a) { max_pos[a] = std::max(max_pos[a], g[a]); min_pos[a] = std::min(min_pos[a], g[a]); } // :275-281
-    }
-    // :283-297 Z-order sort for cache coherence
+    if (int rc = for_each_row(in, h, 3, err, [&](size_t i, const float* v) {
+            const float g[3] = {v[0] * -1.0f, v[1] * -1.0f, v[2]};
+            for (int a = 0; a < 3; ++a) { pos[i * 3 + a] = g[a]; max_pos[a] = std::max(max_pos[a], g[a]); min_pos[a] = std::min(min_pos[a], g[a]); }
+        })) return rc;
+    // :283-297 Z-order sort for cache coherence: stable, on precomputed codes (three counting passes over the 30-bit code)
     const float delta[3] = {max_pos[0] - min_pos[0], max_pos[1] - min_pos[1], max_pos[2] - min_pos[2]};
-    std::vector<uint32_t> code(n);
+    std::vector<uint32_t> code(n), order(n), tmp(n);
     for (size_t i = 0; i < n; ++i) {
-        const float* g = &rec[i * 84];
         uint32_t q[3];
-        for (int a = 0; a < 3; ++a) q[a] = f2u((g[a] - min_pos[a]) / delta[a] * 1023.0f);
+        for (int a = 0; a < 3; ++a) q[a] = f2u((pos[i * 3 + a] - min_pos[a]) / delta[a] * 1023.0f);
         code[i] = (morton_part_by2(q[2]) << 2) + (morton_part_by2(q[1]) << 1) + morton_part_by2(q[0]);
     }
-    std::vector<uint32_t> order(n);
+    { std::vector<float>().swap(pos); }
     std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
-    records.resize(n * 84);
-    for (size_t i = 0; i < n; ++i) std::memcpy(&records[i * 84], &rec[(size_t)order[i] * 84], 84 * sizeof(float));
-    n_out = (uint32_t)n;
-    return GS_OK;
+    for (int shift = 0; shift < 32; shift += 11) {                       // f2u saturates, so a code may use all 32 bits
+        std::vector<size_t> cnt((size_t)1 << 11, 0);
+        for (size_t i = 0; i < n; ++i) ++cnt[(code[order[i]] >> shift) & 2047u];
+        size_t run = 0;
+        for (size_t b = 0; b < cnt.size(); ++b) { const size_t c = cnt[b]; cnt[b] = run; run += c; }
+        for (size_t i = 0; i < n; ++i) tmp[cnt[(code[order[i]] >> shift) & 2047u]++] = order[i];
+        order.swap(tmp);
+    }
+    // order[k] = row that comes k-th; dest[row] = where it goes (tmp reused)
+    std::vector<uint32_t>& dest = tmp;
+    for (size_t k = 0; k < n; ++k) dest[order[k]] = (uint32_t)k;
+    { std::vector<uint32_t>().swap(order); std::vector<uint32_t>().swap(code); }
+
+    // sweep 2
+    return for_each_row(in, h, 59, err, [&](size_t i, const float* v) {
+        const size_t d = dest[i];
+        if (d < max_records) convert_row(v, records_out + d * 84);
+    });
 }
 
 } // namespace
@@ -186,9 +242,9 @@ int convert(const char* path, std::vector<float>& records, uint32_t& n_out, std:
 extern "C" {
 
 // nothing may leave an extern "C" function as an exception (std::bad_alloc / length_error on a hostile header)
-static int convert_noexcept(const char* path, std::vector<float>& rec, uint32_t& n) {
+static int convert_noexcept(const char* path, float* out, size_t max_records, uint32_t& n, std::vector<float>* grow) {
     try {
-        return convert(path, rec, n, g_ply_error);
+        return convert(path, out, max_records, n, g_ply_error, grow);
     } catch (const std::exception& ex) {
         g_ply_error = std::string("ply conversion failed: ") + ex.what();
         return GS_ERR_FORMAT;
@@ -200,15 +256,10 @@ static int convert_noexcept(const char* path, std::vector<float>& rec, uint32_t&
 
 int gs_convert_ply(const char* path, void* aos336_out, uint32_t max_records, uint32_t* n_out) {
     if (!path || !n_out) return GS_ERR_INVALID;
-    std::vector<float> rec;
     uint32_t n = 0;
-    int rc = convert_noexcept(path, rec, n);
+    const int rc = convert_noexcept(path, static_cast<float*>(aos336_out), aos336_out ? max_records : 0, n, nullptr);
     if (rc != GS_OK) return rc;
     *n_out = n;
-    if (aos336_out) {
-        const uint32_t m = n < max_records ? n : max_records;
-        if (m) std::memcpy(aos336_out, rec.data(), (size_t)m * GS_GAUSSIAN_RECORD_BYTES);
-    }
     return GS_OK;
 }
 
@@ -217,7 +268,7 @@ int gs_load_ply(gs_ctx* ctx, const char* path) {
     if (!ctx || !path) return GS_ERR_INVALID;
     std::vector<float> rec;
     uint32_t n = 0;
-    int rc = convert_noexcept(path, rec, n);
+    int rc = convert_noexcept(path, nullptr, 0, n, &rec);
     if (rc != GS_OK) return rc;   // message retrievable with gs_ply_last_error()
     if (n == 0) return GS_ERR_FORMAT;
     return gs_upload_gaussians(ctx, rec.data(), n);
