@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of every kernel of a config-C frame (separate --pmc passes).
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run this on the GPU box}"
 out=gpurun_out/pmc_frame; mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras ${EXTRA_ARGS} > $out/$c.txt 2>&1 || { echo FAILED $c; tail -5 $out/$c.txt; exit 1; }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ issue/wait counters of every kernel of a config-C frame ("VALU busy from rocprof" for
 # RenderGaussians).  One --pmc pass with the 8 SQ slots + GRBM, kernel trace only.
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run this on the GPU box}"
 out=gpurun_out/pmc_sq; mkdir -p $out
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE \
     --kernel-trace --output-format csv -d $out/sq -o p -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras ${EXTRA_ARGS} > $out/sq.txt 2>&1 || { echo FAILED; tail -5 $out/sq.txt; exit 1; }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/sort_probe.py for the default build and every build_variants/lib_*.so; one JSON line each into gpurun_out/probe.txt
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?run this on the GPU box}"
 mkdir -p gpurun_out
 : > gpurun_out/probe.txt
 for lib in "" build_variants/lib_*.so; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # k_scatter durations inside a config-C frame for every build_variants/lib_*.so (and the default build)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run this on the GPU box}"
 for lib in "" build_variants/lib_*.so; do
   name=$(basename "${lib:-default}" .so)
   GS_LIB_OVERRIDE=${lib:+$PWD/$lib} timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sv/$name -o p -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --frames-in-flight 1 > gpurun_out/sv_$name.json 2>/dev/null
