@@ -1081,6 +1081,66 @@ int gs_debug_render_stats(gs_ctx* c, const float* view, const float* proj, const
     return GS_OK;
 }
 
+// Tuning only (not declared in gsplat.h): microseconds per dependent step of `workgroups` x 256 threads that each move
+// bytes_per_wg bytes written by another workgroup in the step before -- persistent = 0: one kernel launch per step (a
+// hipGraph replay of `steps` launches, as the frame replays its radix passes); persistent = 1: ONE launch with a
+// device-wide counter barrier (release / acquire at agent scope) between the steps.  timed_out = 1 when the persistent
+// grid was not wholly resident and a bounded spin gave up (the number is then meaningless).
+int gs_sync_probe(gs_ctx* c, int persistent, uint32_t workgroups, uint32_t steps, uint32_t bytes_per_wg, uint32_t iters,
+                  float* us_per_step, uint32_t* timed_out) {
+    if (!c || !us_per_step || !timed_out || workgroups == 0 || steps == 0 || iters == 0) return GS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t per_wg = bytes_per_wg / 16u;
+    const size_t bytes = std::max<size_t>(16, (size_t)workgroups * per_wg * 16);
+    void *a = nullptr, *b = nullptr;
+    uint32_t* flags = nullptr;             // [0] barrier counter, [1] timed out
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipMalloc(&a, bytes);
+    if (e == hipSuccess) e = hipMalloc(&b, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&flags, 8);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 1, bytes, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b, 2, bytes, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(flags, 0, 8, c->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess && !persistent) {
+        hipGraph_t graph = nullptr;
+        e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
+        if (e == hipSuccess) {
+            for (uint32_t s = 0; s < steps; ++s) launch_probe_step((s & 1u) ? b : a, (s & 1u) ? a : b, workgroups, per_wg, s, c->stream);
+            e = hipStreamEndCapture(c->stream, &graph);
+        }
+        if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+    }
+    float ms = 0.0f;
+    uint32_t host_flags[2] = {0u, 0u};
+    for (uint32_t it = 0; it < iters + 2u && e == hipSuccess; ++it) {          // two warm-up rounds
+        if (it == 2u) e = hipEventRecord(e0, c->stream);
+        if (persistent) {
+            if (e == hipSuccess) e = hipMemsetAsync(flags, 0, 4, c->stream);   // the counter; the flag stays
+            launch_probe_persistent(a, b, workgroups, per_wg, steps, flags, flags + 1, c->stream);
+        } else if (e == hipSuccess) {
+            e = hipGraphLaunch(exec, c->stream);
+        }
+    }
+    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess && persistent) e = hipMemcpy(host_flags, flags, 8, hipMemcpyDeviceToHost);
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (flags) (void)hipFree(flags);
+    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_sync_probe: ") + hipGetErrorString(e));
+    *us_per_step = ms * 1000.0f / (float)iters / (float)steps;
+    *timed_out = host_flags[1];
+    return GS_OK;
+}
+
 int gs_membench(gs_ctx* c, int kind, size_t bytes, uint32_t blocks, uint32_t iters, float* gbps, float* ms_out) {
     if (!c || !gbps || bytes < 16 || iters == 0 || kind < 0 || kind > 12) return GS_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));

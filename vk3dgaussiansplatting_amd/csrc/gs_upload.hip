@@ -206,4 +206,59 @@ void launch_stream_probe(int kind, const void* src, void* dst, size_t bytes, uin
     }
 }
 
+// ---- hand-off probe (tuning only, gs_sync_probe): what does it cost to hand a small list from one radix stage to the
+//      next -- a kernel boundary per stage, or one persistent launch with a device-wide barrier per stage?  One step =
+//      every workgroup reads `dwords` 16-byte words of ITS slice of `a` written in the previous step by ANOTHER
+//      workgroup (the neighbour: a real cross-workgroup dependency, like a pass reading what the previous pass
+//      scattered) and writes its slice of `b`; a and b swap every step.
+__device__ __forceinline__ void probe_step(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t wg, uint32_t wgs,
+                                           uint32_t per_wg, uint32_t step) {
+    const uint32_t from = (wg + 1u) % wgs;                 // the neighbour's slice
+    for (uint32_t i = threadIdx.x; i < per_wg; i += blockDim.x) {
+        uint4 v = src[(size_t)from * per_wg + i];
+        v.x += step; v.y ^= wg;
+        dst[(size_t)wg * per_wg + i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_probe_step(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t per_wg, uint32_t step) {
+    probe_step(src, dst, blockIdx.x, gridDim.x, per_wg, step);
+}
+
+// One launch, `steps` steps, a counter barrier between them: every storing wave drains its stores, the workgroup meets,
+// one lane releases (agent scope: the XCD's L2 writes its dirty lines back), arrives, polls the counter with relaxed
+// agent-scope loads and a sleep, acquires (this CU's L1 is invalidated), the workgroup meets again.  Every spin is
+// bounded: a grid that is not wholly resident gives up, flags it and still terminates.
+__global__ __launch_bounds__(256) void k_probe_persistent(uint4* __restrict__ a, uint4* __restrict__ b, uint32_t per_wg, uint32_t steps,
+                                                          uint32_t* __restrict__ counter, uint32_t* __restrict__ timed_out) {
+    uint4* src = a;
+    uint4* dst = b;
+    for (uint32_t s = 0; s < steps; ++s) {
+        probe_step(src, dst, blockIdx.x, gridDim.x, per_wg, s);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t want = (s + 1u) * gridDim.x;
+            uint32_t budget = 400000u;
+            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && --budget) __builtin_amdgcn_s_sleep(2);
+            if (budget == 0u) *timed_out = 1u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        uint4* t = src; src = dst; dst = t;
+    }
+}
+
+void launch_probe_step(const void* src, void* dst, uint32_t workgroups, uint32_t per_wg, uint32_t step, hipStream_t stream) {
+    hipLaunchKernelGGL(k_probe_step, dim3(workgroups), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, per_wg, step);
+}
+void launch_probe_persistent(void* a, void* b, uint32_t workgroups, uint32_t per_wg, uint32_t steps, uint32_t* counter,
+                             uint32_t* timed_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_probe_persistent, dim3(workgroups), dim3(256), 0, stream, (uint4*)a, (uint4*)b, per_wg, steps, counter, timed_out);
+}
+
 } // namespace gs
