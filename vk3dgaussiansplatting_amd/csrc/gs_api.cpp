@@ -1141,6 +1141,35 @@ int gs_sync_probe(gs_ctx* c, int persistent, uint32_t workgroups, uint32_t steps
     return GS_OK;
 }
 
+// Tuning only: microseconds of one launch of `workgroups` workgroups that each issue `lines` 16-lane atomic adds (add = 1) or plain
+// stores (add = 0) to rows of a rows x 16 counter table; stride_num / stride_den workgroups share a starting row.
+int gs_atomic_probe(gs_ctx* c, uint32_t workgroups, uint32_t lines, uint32_t rows, uint32_t stride_num, uint32_t stride_den, uint32_t add,
+                    uint32_t iters, float* us_per_launch) {
+    if (!c || !us_per_launch || !workgroups || !rows || !stride_den || !iters) return GS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t* table = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void**)&table, (size_t)rows * 64);
+    if (e == hipSuccess) e = hipMemsetAsync(table, 0, (size_t)rows * 64, c->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) {
+        for (int w = 0; w < 3; ++w) launch_probe_atomics(table, rows, workgroups, lines, stride_num, stride_den, add, c->stream);
+        e = hipEventRecord(e0, c->stream);
+        for (uint32_t i = 0; i < iters; ++i) launch_probe_atomics(table, rows, workgroups, lines, stride_num, stride_den, add, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (table) (void)hipFree(table);
+    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_atomic_probe: ") + hipGetErrorString(e));
+    *us_per_launch = ms * 1000.0f / (float)iters;
+    return GS_OK;
+}
+
 int gs_membench(gs_ctx* c, int kind, size_t bytes, uint32_t blocks, uint32_t iters, float* gbps, float* ms_out) {
     if (!c || !gbps || bytes < 16 || iters == 0 || kind < 0 || kind > 12) return GS_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));

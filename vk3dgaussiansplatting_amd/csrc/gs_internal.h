@@ -200,6 +200,8 @@ void launch_block_bounds(uint32_t n, const SceneBuffers& s, hipStream_t stream);
 void launch_stream_probe(int kind, const void* src, void* dst, size_t bytes, uint32_t blocks, hipStream_t stream);
 // tuning only (gs_sync_probe)
 void launch_probe_step(const void* src, void* dst, uint32_t workgroups, uint32_t per_wg, uint32_t step, hipStream_t stream);
+void launch_probe_atomics(uint32_t* table, uint32_t rows, uint32_t workgroups, uint32_t lines, uint32_t stride_num, uint32_t stride_den,
+                          uint32_t add, hipStream_t stream);
 void launch_probe_persistent(void* a, void* b, uint32_t workgroups, uint32_t per_wg, uint32_t steps, uint32_t* counter,
                              uint32_t* timed_out, hipStream_t stream);
 void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,

@@ -253,6 +253,26 @@ __global__ __launch_bounds__(256) void k_probe_persistent(uint4* __restrict__ a,
     }
 }
 
+// ---- atomic-rate probe (tuning only, gs_atomic_probe): could a radix Scatter feed the NEXT pass's per-group digit counts with
+//      global atomics instead of a Count launch?  Workgroup w issues `lines` wave instructions of 16 active lanes, each a
+//      non-returning agent-scope add to the 16 consecutive counters of row (w * stride_num / stride_den + k) % rows: with
+//      stride 1/16 sixteen neighbouring workgroups meet on a row, as neighbouring source groups of a pass meet on a destination group.
+__global__ __launch_bounds__(256) void k_probe_atomics(uint32_t* __restrict__ table, uint32_t rows, uint32_t lines, uint32_t stride_num,
+                                                       uint32_t stride_den, uint32_t add) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane >= 16u) return;
+    const uint32_t first = (uint32_t)(((uint64_t)blockIdx.x * stride_num) / stride_den);
+    for (uint32_t k = wave; k < lines; k += 4u) {
+        const uint32_t row = (first + k * 97u) % rows;      // the 16 digits of a group land in 16 runs, i.e. rows far apart
+        if (add) (void)__hip_atomic_fetch_add(&table[(size_t)row * 16u + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else table[(size_t)row * 16u + lane] = k;            // the same addresses with plain stores, for reference
+    }
+}
+void launch_probe_atomics(uint32_t* table, uint32_t rows, uint32_t workgroups, uint32_t lines, uint32_t stride_num, uint32_t stride_den,
+                          uint32_t add, hipStream_t stream) {
+    hipLaunchKernelGGL(k_probe_atomics, dim3(workgroups), dim3(256), 0, stream, table, rows, lines, stride_num, stride_den, add);
+}
+
 void launch_probe_step(const void* src, void* dst, uint32_t workgroups, uint32_t per_wg, uint32_t step, hipStream_t stream) {
     hipLaunchKernelGGL(k_probe_step, dim3(workgroups), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, per_wg, step);
 }
