@@ -132,8 +132,21 @@ def pmc_traffic(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             t0 = time.time()
-            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--"]
-                               + child, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            # a process group of its own: if the profiler gets stuck, the group (rocprofv3 AND the bench child under it) is
+            # killed -- ~10 s each normally; never let a stuck profiler cost the run its line
+            proc = subprocess.Popen([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--"] + child,
+                                    cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _, err = proc.communicate(timeout=90)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.communicate()
+                return f"rocprofv3 --pmc {counter} did not finish within 90 s"
+            r = subprocess.CompletedProcess(proc.args, proc.returncode, None, err)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
