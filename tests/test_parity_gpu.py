@@ -33,8 +33,9 @@ def make_scene(aos, w, h, pos=(0.0, 0.0, 0.0), yaw=0.0, pitch=0.0, sh_mode=0):
 ALL_SORTS = (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET, gs.GS_SORT_RADIX4_SPLAT_FIRST)
 
 
-def make_renderer(sc, w, h, mode=gs.GS_RENDER_EXACT, sort=gs.GS_SORT_RADIX4, kernel=gs.GS_RENDER_KERNEL_AUTO):
-    r = gs.Renderer(w, h, render_mode=mode, warmup_frames=0, sort_algorithm=sort, render_kernel=kernel)
+def make_renderer(sc, w, h, mode=gs.GS_RENDER_EXACT, sort=gs.GS_SORT_RADIX4, kernel=gs.GS_RENDER_KERNEL_AUTO,
+                  order=gs.GS_TILE_ORDER_LONGEST_FIRST):
+    r = gs.Renderer(w, h, render_mode=mode, warmup_frames=0, sort_algorithm=sort, render_kernel=kernel, tile_order=order)
     r.init(sc.getResourceManager())
     r.initForScene(sc)
     return r
@@ -978,7 +979,7 @@ def test_band_exceeding_the_launch_estimate(oracle_mod):
 
 def test_randomized_frames(oracle_mod):
     """Sixty seeded random set-ups -- cloud size (1 .. 6000), footprint scale, resolution (ragged tiles included),
-    camera pose, SH mode, sorter, render launch shape, whole frame / contiguous band / interleaved rows -- each
+    camera pose, SH mode, sorter, render launch shape, tile order, whole frame / contiguous band / interleaved rows -- each
     compared with the oracle in full (counter, keys, payload order, ranges, pixels).  Element counts land on both
     sides of every group / wave / batch boundary of the kernels."""
     from vk3dgaussiansplatting_amd import dist as gsdist
@@ -997,10 +998,11 @@ def test_randomized_frames(oracle_mod):
         sort = ALL_SORTS[int(rng.choice(3, p=[0.45, 0.2, 0.35]))]
         kernel = kernels[int(rng.integers(0, len(kernels)))]
         sc = make_scene(aos, w, h, pos=pos, yaw=yaw, pitch=pitch, sh_mode=sh_mode)
-        r = make_renderer(sc, w, h, sort=sort, kernel=kernel)
+        order = gs.GS_TILE_ORDER_RASTER if case % 4 == 3 else gs.GS_TILE_ORDER_LONGEST_FIRST
+        r = make_renderer(sc, w, h, sort=sort, kernel=kernel, order=order)
         gh = r.sceneInfo().tiles_y
         share = rng.random()
-        what = f"case {case}: n={n} {w}x{h} mu={mu:.2f} sh={sh_mode} sort={sort} kernel={kernel}"
+        what = f"case {case}: n={n} {w}x{h} mu={mu:.2f} sh={sh_mode} sort={sort} kernel={kernel} order={order}"
         if share < 0.5 or gh < 2:
             img = r.draw(sc)
             _, ref = oracle_run(oracle_mod, sc, w, h)
