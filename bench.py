@@ -153,8 +153,15 @@ def pmc_traffic(args):
             with open(files[0]) as f:
                 for row in csv.DictReader(f):
                     k = per.setdefault(row["Kernel_Name"].split("(")[0].replace("void ", "").replace("gs::", "").replace(" ", ""),
-                                       {"FETCH_SIZE": [], "WRITE_SIZE": []})
+                                       {"FETCH_SIZE": [], "WRITE_SIZE": [], "us": []})
                     k[counter].append(float(row["Counter_Value"]))
+            # the same run's kernel trace: begin -> end of every launch (what rocprofv3 --stats averages)
+            for tf in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+                with open(tf) as f:
+                    for row in csv.DictReader(f):
+                        k = per.get(row["Kernel_Name"].split("(")[0].replace("void ", "").replace("gs::", "").replace(" ", ""))
+                        if k is not None:
+                            k["us"].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1000.0)
             log(f"[bench] rocprofv3 --pmc {counter}: {time.time() - t0:.1f}s")
     except (OSError, subprocess.SubprocessError, KeyError, ValueError) as ex:
         return f"PMC child run failed: {ex!r}"
@@ -165,7 +172,8 @@ def pmc_traffic(args):
         if v["FETCH_SIZE"] and v["WRITE_SIZE"]:
             res[k] = {"launches": len(v["FETCH_SIZE"]),
                       "read_bytes": 2.0 * 1024.0 * sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]),   # KB; x2: gfx950 tallies 128-B requests as 64 B
-                      "write_bytes": 1024.0 * sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])}
+                      "write_bytes": 1024.0 * sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]),
+                      "trace_us": sum(v["us"]) / len(v["us"]) if v["us"] else None}
     return res or "no kernels in the counter files"
 
 
@@ -669,8 +677,20 @@ def main():
                     n_l += v["launches"]
             return tot / n_l if n_l else None
 
+        def pmc_trace_us(prefixes):
+            """mean kernel-trace duration (us) of those launches in the PMC child runs, or None"""
+            if not isinstance(pmc, dict):
+                return None
+            tot = n_l = 0.0
+            for k, v in pmc.items():
+                if any(k.startswith(p_) for p_ in prefixes) and v.get("trace_us"):
+                    tot += v["launches"] * v["trace_us"]
+                    n_l += v["launches"]
+            return tot / n_l if n_l else None
+
         moved_launch = moved_full * e_rank
         traffic = pmc_bytes(tuple(DEPTH_SCATTERS)) if args.sort == "radix4" else None
+        trace_us = pmc_trace_us(tuple(DEPTH_SCATTERS)) if traffic else None
         basis_bytes = traffic if traffic else moved_launch
         achieved = rate(basis_bytes, scat)
         # the whole sort stage: every Count and Scatter launch of the frame over the RadixSort bucket
@@ -695,6 +715,11 @@ def main():
                              "FETCH_SIZE (x2 on gfx950, MI355X_MICROARCH.md) and --pmc WRITE_SIZE, separate passes, mean over "
                              "the depth-word Scatter launches") if traffic else (pmc if isinstance(pmc, str) else "no depth-word Scatter launches in the counters"),
             "avg_launch_ms": round(scat, 5), "launches_per_frame": passes_full,
+            "avg_launch_note": "HIP event pair around every such launch on its stream: includes the launch boundary, so `frac` is the "
+                               "conservative figure; `kernel_trace` restates it on rocprofv3's begin -> end duration of the same "
+                               "launches (measured in the PMC child runs, i.e. with counters on: ~1 us longer than --stats alone)",
+            "kernel_trace": ({"avg_launch_ms": round(trace_us * 1e-3, 5), "achieved": round(rate(traffic, trace_us * 1e-3), 1),
+                              "frac": round(rate(traffic, trace_us * 1e-3) / HBM_PEAK_GBPS, 4)} if trace_us else None),
             "moved": {"bytes_per_element": moved_full, "bytes_per_launch": moved_launch,
                       "achieved": round(rate(moved_launch, scat), 1),
                       "frac_of_peak": round(rate(moved_launch, scat) / HBM_PEAK_GBPS, 4),
