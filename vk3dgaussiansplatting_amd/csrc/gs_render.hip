@@ -465,8 +465,12 @@ __device__ __forceinline__ void blend_pair(const float4 (*batch)[3], int ja, int
 // (profiles/r03_render_variants.txt: sharing the first 1, 2, 3, 4 or all batches loses 3 / 7 / 12 / 18 / 27 % on the
 // capture-like cloud and 15 - 22 % on the uniform one, although every entry is then gathered four times).
 template <bool EXACT>
-__global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp, const SplatRaster* __restrict__ raster, const uint32_t* __restrict__ sorted_id,
-                 const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ order, uint32_t* __restrict__ rgba) {
+__global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
+                                                    const SplatRaster* __restrict__ raster,
+                                                    const uint32_t* __restrict__ sorted_id,
+                                                    const uint32_t* __restrict__ ranges,
+                                                    const uint32_t* __restrict__ order,
+                                                    uint32_t* __restrict__ rgba) {
     __shared__ float4 s_batch[256][3];     // {sx, sy, inv.x, inv.y}, {inv.z, r, g, b}, {a, skip threshold, -, -}; 64 slots per wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
