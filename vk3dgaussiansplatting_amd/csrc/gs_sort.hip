@@ -15,7 +15,7 @@
 //   k_scatter  Scan   : prologue -- every workgroup scans the coarse totals itself (DPP row scans) and adds the
 //                       segment totals and the table entry ahead of its group (RadixSortScan.comp:29-71 and the rest
 //                       of ScanAdd); there is no Scan launch.
-//              Scatter: one 256-thread workgroup per group (7-8 resident per CU): wave64 match-mask ranking (stable),
+//              Scatter: one 256-thread workgroup per group (5-6 resident per CU): wave64 match-mask ranking (stable),
 //                       LDS-staged local sort, run-wise coalesced stores (RadixSortScatter.comp:58-171).
 // Inside a frame the words are narrower than the reference's: 16-bit compact tile ids when they fit, and depth words
 // that shrink as their digits are consumed (see k_scatter); the stand-alone sorter (gs_sort_host) always moves three
