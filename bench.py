@@ -52,7 +52,7 @@ def parse_args(argv=None):
                     help="default: C (the headline shape) on one GPU, D (the 4K frame BASELINE.json names for the "
                          "tile-row shard) on several")
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
-    ap.add_argument("--sort", default="radix4", choices=["radix4", "bucket", "splat_first"],
+    ap.add_argument("--sort", default="radix4", choices=["radix4", "bucket", "splat_first", "radix8", "radix8_splat_first"],
                     help="radix4 = the contractual nine-stage sort (default); bucket = GS_SORT_TILE_BUCKET; "
                          "splat_first = GS_SORT_RADIX4_SPLAT_FIRST (the same twelve 4-bit passes, the depth ones before "
                          "the splats are replicated into tiles)")
@@ -329,7 +329,8 @@ def main():
     cam.setRotation(0.0, 0.0)
     cam.recalculate()
     mode = gs.GS_RENDER_EXACT if args.mode == "exact" else gs.GS_RENDER_FAST
-    sort_ids = {"radix4": gs.GS_SORT_RADIX4, "bucket": gs.GS_SORT_TILE_BUCKET, "splat_first": gs.GS_SORT_RADIX4_SPLAT_FIRST}
+    sort_ids = {"radix4": gs.GS_SORT_RADIX4, "bucket": gs.GS_SORT_TILE_BUCKET, "splat_first": gs.GS_SORT_RADIX4_SPLAT_FIRST,
+                "radix8": gs.GS_SORT_RADIX8, "radix8_splat_first": gs.GS_SORT_RADIX8_SPLAT_FIRST}
     interleaved = args.rows == "interleaved" and world > 1
 
     def make(record, sort=None, share=None, render_mode=None):

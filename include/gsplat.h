@@ -54,6 +54,9 @@ extern "C" {
                                      tiles; InitSortList's emit then walks the splats in depth order and the four
                                      tile-word passes -- stable -- finish the order by (tile, depth).  Moves a third of
                                      the bytes.  Not the default: the default keeps the reference's stage order. */
+#define GS_SORT_RADIX8 3u       /* the A/B slot for an 8-bit-digit variant: the same stable LSD sort over all key bits with
+                                   half the passes (Count, Scan, Scatter per pass; csrc/gs_sort8.hip), identical output */
+#define GS_SORT_RADIX8_SPLAT_FIRST 4u /* GS_SORT_RADIX4_SPLAT_FIRST's stage order with the 8-bit passes */
 
 /* render arithmetic */
 #define GS_RENDER_EXACT 0u      /* bit-identical to the CPU oracle (no contraction, pinned exp) */

@@ -30,7 +30,8 @@ def make_scene(aos, w, h, pos=(0.0, 0.0, 0.0), yaw=0.0, pitch=0.0, sh_mode=0):
     return sc
 
 
-ALL_SORTS = (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET, gs.GS_SORT_RADIX4_SPLAT_FIRST)
+ALL_SORTS = (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET, gs.GS_SORT_RADIX4_SPLAT_FIRST, gs.GS_SORT_RADIX8,
+             gs.GS_SORT_RADIX8_SPLAT_FIRST)
 
 
 def make_renderer(sc, w, h, mode=gs.GS_RENDER_EXACT, sort=gs.GS_SORT_RADIX4, kernel=gs.GS_RENDER_KERNEL_AUTO,
@@ -303,9 +304,11 @@ def test_tile_row_bands_reproduce_full_frame(oracle_mod, small_cloud):
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 4095, 4096, 4097, 100_003, 1_500_000])
 @pytest.mark.parametrize("bits", [44, 48])
-def test_radix_sort_matches_stable_sort(n, bits):
+@pytest.mark.parametrize("sorter", [gs.RadixSort, gs.RadixSort8])
+def test_radix_sort_matches_stable_sort(n, bits, sorter):
     """GpuSort seam on caller arrays: ragged sizes around the 64-lane and 4096-key tile edges,
-    heavy ties (payload order must be preserved)."""
+    heavy ties (payload order must be preserved).  Tile words carry bits above the sorted ones when bits < 48 is
+    paired with a wider draw (the 8-bit variant's last pass must mask them)."""
     rng = np.random.default_rng(n * 131 + bits)
     tile = rng.integers(0, 1 << (bits - 32), n, dtype=np.uint32)
     depth = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
@@ -313,7 +316,7 @@ def test_radix_sort_matches_stable_sort(n, bits):
         depth[rng.integers(0, n, n // 3)] = 12345          # many equal keys
         tile[: n // 2] = tile[0]
     ident = np.arange(n, dtype=np.uint32)
-    rs = gs.RadixSort()
+    rs = sorter()
     rs.initForScene(n, 1 << (bits - 32))
     assert rs.radixSortNumSortBits == bits
     t, d, i = rs.computeSort(tile, depth, ident)
@@ -723,10 +726,11 @@ def test_api_call_order_and_reuse(small_cloud):
 
 
 @pytest.mark.parametrize("n", [20_000_000, 150_000_000])
-def test_sort_stress_sortedness(n):
+@pytest.mark.parametrize("sorter", [gs.RadixSort, gs.RadixSort8])
+def test_sort_stress_sortedness(n, sorter):
     """Sorter alone on device-generated random keys: sortedness checked on the device.  150 M elements
-    exceed 64 groups per reduce segment (the looped ScanAdd prologue)."""
-    rs = gs.RadixSort()
+    exceed 64 groups per reduce segment (the looped ScanAdd prologue; 8-bit digits: two rounds of k_count8's LDS counters)."""
+    rs = sorter()
     ms, ok = rs.bench(n, 8160, iters=2, seed=3)
     assert ok and ms > 0
     print(f"n={n}: {ms:.3f} ms per sort, {n / ms / 1e3:.0f} M elements/s")

@@ -7,7 +7,8 @@ import numpy as np
 import vk3dgaussiansplatting_amd as gs
 from vk3dgaussiansplatting_amd import synth, dist
 name = sys.argv[1] if len(sys.argv) > 1 else "C"
-sort = {"bucket": gs.GS_SORT_TILE_BUCKET, "splat_first": gs.GS_SORT_RADIX4_SPLAT_FIRST}.get(sys.argv[2] if len(sys.argv) > 2 else "", gs.GS_SORT_RADIX4)
+sort = {"bucket": gs.GS_SORT_TILE_BUCKET, "splat_first": gs.GS_SORT_RADIX4_SPLAT_FIRST, "radix8": gs.GS_SORT_RADIX8,
+                                    "radix8_splat_first": gs.GS_SORT_RADIX8_SPLAT_FIRST}.get(sys.argv[2] if len(sys.argv) > 2 else "", gs.GS_SORT_RADIX4)
 cfg = synth.CONFIGS[name]
 cache = f"/dev/shm/gs_cloud_{cfg['n']}_{cfg['mu']}_{cfg['seed']}_{cfg.get('kind', 'uniform')}.npy"
 if os.path.exists(cache):

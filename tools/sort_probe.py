@@ -28,7 +28,8 @@ sc.getCamera().setPosition((0, 0, 0)); sc.getCamera().setRotation(0.0, 0.0); sc.
 out = {"lib": os.path.basename(os.environ.get("GS_LIB_OVERRIDE", "default")), "config": a.config}
 for record in (1, 2):
     r = gs.Renderer(w, h, record_timings=record, warmup_frames=0,
-                    sort_algorithm={"bucket": gs.GS_SORT_TILE_BUCKET, "splat_first": gs.GS_SORT_RADIX4_SPLAT_FIRST}.get(a.sort, gs.GS_SORT_RADIX4))
+                    sort_algorithm={"bucket": gs.GS_SORT_TILE_BUCKET, "splat_first": gs.GS_SORT_RADIX4_SPLAT_FIRST, "radix8": gs.GS_SORT_RADIX8,
+                                    "radix8_splat_first": gs.GS_SORT_RADIX8_SPLAT_FIRST}.get(a.sort, gs.GS_SORT_RADIX4))
     r.init(rm); r.initForScene(sc)
     if a.rows:
         rb, re = (int(x) for x in a.rows.split(":"))

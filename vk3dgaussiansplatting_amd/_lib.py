@@ -30,6 +30,8 @@ GS_TILE_ORDER_LONGEST_FIRST, GS_TILE_ORDER_RASTER = 0, 1
 GS_SORT_RADIX4 = 0
 GS_SORT_TILE_BUCKET = 1
 GS_SORT_RADIX4_SPLAT_FIRST = 2
+GS_SORT_RADIX8 = 3
+GS_SORT_RADIX8_SPLAT_FIRST = 4
 
 (BUF_SORTED_TILE, BUF_SORTED_DEPTH, BUF_SORTED_ID, BUF_RANGES, BUF_COLOR, BUF_COV, BUF_COUNT,
  BUF_UNSORTED_TILE, BUF_UNSORTED_DEPTH, BUF_UNSORTED_ID, BUF_IMAGE) = range(11)

@@ -155,16 +155,25 @@ uint32_t num_sort_bits_for(uint32_t num_tiles) {
     return ((32u + bits + kRadixBits - 1u) / kRadixBits) * kRadixBits;
 }
 
-int alloc_sort(gs_ctx* ctx, SortBuffers& s, uint32_t capacity) {
+inline bool sorts_splat_first(uint32_t algo) { return algo == GS_SORT_RADIX4_SPLAT_FIRST || algo == GS_SORT_RADIX8_SPLAT_FIRST; }
+inline uint32_t digit_bits_of(uint32_t algo) { return algo == GS_SORT_RADIX8 || algo == GS_SORT_RADIX8_SPLAT_FIRST ? 8u : (uint32_t)kRadixBits; }
+
+int alloc_sort(gs_ctx* ctx, SortBuffers& s, uint32_t capacity, uint32_t digit_bits) {
     const size_t bytes = (size_t)capacity * sizeof(uint32_t);
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(ctx, hipMalloc((void**)&s.lo[k], bytes));
         HIP_TRY(ctx, hipMalloc((void**)&s.hi[k], bytes));
         HIP_TRY(ctx, hipMalloc((void**)&s.id[k], bytes));
     }
-    const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
-    HIP_TRY(ctx, hipMalloc((void**)&s.table, (size_t)kBins * max_groups * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc((void**)&s.seg_sum, (size_t)kBins * kSegments * sizeof(uint32_t)));
+    if (digit_bits == 8u) {   // gs_sort8.hip: [groups][256] counts; segment counts + their scan
+        const uint32_t max_groups = (capacity + kSort8Tile - 1) / kSort8Tile;
+        HIP_TRY(ctx, hipMalloc((void**)&s.table, (size_t)kBins8 * max_groups * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&s.seg_sum, (size_t)2 * kBins8 * kSegments * sizeof(uint32_t)));
+    } else {
+        const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
+        HIP_TRY(ctx, hipMalloc((void**)&s.table, (size_t)kBins * max_groups * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&s.seg_sum, (size_t)kBins * kSegments * sizeof(uint32_t)));
+    }
     HIP_TRY(ctx, hipMalloc((void**)&s.params, sizeof(SortParams)));
     HIP_TRY(ctx, hipMemset(s.params, 0, sizeof(SortParams)));
     HIP_TRY(ctx, hipMalloc((void**)&s.coarse, (size_t)kMaxSortPasses * kBins * kCoarse * sizeof(uint32_t)));
@@ -230,7 +239,8 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     // RadixSort.cpp:676-692) is unobservable once every later stage runs over E instead of C.
     // (the ranges and the sort's coarse totals are cleared inside k_scan_blocks: no fill launches in a frame)
     fp.parity = (c->emit_parity ^= 1u);
-    const bool splat_first = c->cfg.sort_algorithm == GS_SORT_RADIX4_SPLAT_FIRST;
+    const bool splat_first = sorts_splat_first(c->cfg.sort_algorithm);
+    const uint32_t digit = digit_bits_of(c->cfg.sort_algorithm);
     fp.splat_first = splat_first ? 1u : 0u;
     const bool bucket = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET;
     const bool per_pass_events = c->cfg.record_timings >= 2;
@@ -272,11 +282,11 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
         auto depth_passes = [&](hipEvent_t* evs) {
             // the frame's own depth passes (shrinking depth words, payload as wide as the tile ids) over the splat list
             return launch_radix_sort(c->sort, c->n, 32u, st, evs, 0u, true, c->hi16, 1.0f, /*start*/ 1, /*coarse_pass*/ 0,
-                                     c->scratch.aux_params);
+                                     c->scratch.aux_params, digit);
         };
         auto tile_passes = [&](hipEvent_t* evs) {
             return launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, evs ? evs + 16 : nullptr, 32u, true, c->hi16,
-                                     tile_share, /*start*/ 0, /*coarse_pass*/ 8);
+                                     tile_share, /*start*/ 0, /*coarse_pass*/ 8, nullptr, digit);
         };
         if (!tm) {
             const int sorted = radix_passes(c->chain_graph, c->chain_result, [&](hipEvent_t*) {
@@ -315,7 +325,8 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
         // gpuSort->computeSort (RadixSort.cpp:207-653).  The passes' arguments are fixed once resolution and tile rows are:
         // captured once, replayed as a hipGraph.  Without timers FindRanges (same property) rides in the same graph.
         auto all_passes = [&](hipEvent_t* evs) {
-            return launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, evs, bucket ? 32u : 0u, !bucket, c->hi16, tile_share);
+            return launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, evs, bucket ? 32u : 0u, !bucket, c->hi16, tile_share,
+                                     0, 0, nullptr, digit);
         };
         if (!tm && !bucket) {
             const int sorted = radix_passes(c->chain_graph, c->chain_result, [&](hipEvent_t*) {
@@ -385,7 +396,7 @@ int finish_frame(gs_ctx* c) {
     HIP_TRY(c, hipMemcpy(&sp, c->sort.params, sizeof(sp), hipMemcpyDeviceToHost));
     gs_timings t{};
     if (c->cfg.record_timings) {
-        if (c->cfg.sort_algorithm == GS_SORT_RADIX4_SPLAT_FIRST) {
+        if (sorts_splat_first(c->cfg.sort_algorithm)) {
             // project + lists | depth passes | gather + emit | tile-word passes
             float a = 0.0f, b = 0.0f, d = 0.0f, e = 0.0f;
             HIP_TRY(c, hipEventElapsedTime(&a, c->ev[1], c->pre_ev[0]));
@@ -410,16 +421,17 @@ int finish_frame(gs_ctx* c) {
             t.radix_sort_ms += tile_ms;
         }
     }
-    if (c->cfg.record_timings >= 2 && c->cfg.sort_algorithm == GS_SORT_RADIX4_SPLAT_FIRST) {
+    if (c->cfg.record_timings >= 2 && sorts_splat_first(c->cfg.sort_algorithm)) {
         // "full" = the eight depth passes over the SPLAT list, "tile" = the tile-word passes over the elements
         float sum_pre = 0.0f, sum_tile = 0.0f, bytes_pre = 0.0f;
-        const uint32_t n_tile = (c->band_sort_bits - 32u) / kRadixBits;
-        for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t digit = digit_bits_of(c->cfg.sort_algorithm), n_pre = 32u / digit;
+        const uint32_t n_tile = (c->band_sort_bits - 32u + digit - 1u) / digit;
+        for (uint32_t k = 0; k < n_pre; ++k) {
             float ms = 0.0f;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->scatter_ev[2 * k], c->scatter_ev[2 * k + 1]));
             sum_pre += ms;
             int lo_in, lo_out;
-            scatter_depth_bytes(k * kRadixBits, 0u, true, &lo_in, &lo_out);
+            scatter_depth_bytes(k * digit, 0u, true, &lo_in, &lo_out, digit);
             bytes_pre += (float)(lo_in + lo_out) + 2.0f * (c->hi16 ? 2.0f : 4.0f) + 8.0f;   // depth + count + splat, r + w
         }
         for (uint32_t k = 0; k < n_tile; ++k) {
@@ -427,15 +439,16 @@ int finish_frame(gs_ctx* c) {
             HIP_TRY(c, hipEventElapsedTime(&ms, c->scatter_ev[16 + 2 * k], c->scatter_ev[16 + 2 * k + 1]));
             sum_tile += ms;
         }
-        t.scatter_ms_avg = sum_pre / 8.0f;
-        t.scatter_launches = 8;
-        t.scatter_bytes_per_elem = bytes_pre / 8.0f;   // per SPLAT of the list
+        t.scatter_ms_avg = sum_pre / (float)n_pre;
+        t.scatter_launches = n_pre;
+        t.scatter_bytes_per_elem = bytes_pre / (float)n_pre;   // per SPLAT of the list
         t.scatter_tile_ms_avg = n_tile ? sum_tile / (float)n_tile : 0.0f;
         t.scatter_tile_launches = n_tile;
         t.scatter_tile_bytes_per_elem = 2.0f * (c->hi16 ? 2.0f : 4.0f) + 8.0f;
     } else if (c->cfg.record_timings >= 2) {
         const uint32_t first_bit = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET ? 32u : 0u;
-        const uint32_t passes = (c->band_sort_bits - first_bit) / kRadixBits;
+        const uint32_t digit = digit_bits_of(c->cfg.sort_algorithm);
+        const uint32_t passes = (c->band_sort_bits - first_bit + digit - 1u) / digit;
         // launches that move all 24 bytes per element (k_scatter<true>) and the tile-word passes of the frame
         // path that leave the depth words behind (k_scatter<false>, 16 bytes per element) are averaged apart
         const bool bucket = c->cfg.sort_algorithm == GS_SORT_TILE_BUCKET;
@@ -444,9 +457,9 @@ int finish_frame(gs_ctx* c) {
         for (uint32_t k = 0; k < passes; ++k) {
             float ms = 0.0f;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->scatter_ev[2 * k], c->scatter_ev[2 * k + 1]));
-            const uint32_t shift = first_bit + k * kRadixBits;
+            const uint32_t shift = first_bit + k * digit;
             int lo_in, lo_out;
-            scatter_depth_bytes(shift, first_bit, !bucket, &lo_in, &lo_out);
+            scatter_depth_bytes(shift, first_bit, !bucket, &lo_in, &lo_out, digit);
             const float moved = (float)(lo_in + lo_out) + 2.0f * (c->hi16 ? 2.0f : 4.0f) + 8.0f;   // depth + tile + id, r + w
             if (shift < 32u || bucket) { sum_full += ms; ++n_full; bytes_full += moved; }
             else { sum_tile += ms; ++n_tile; bytes_tile += moved; }
@@ -492,7 +505,7 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
     gs_config cfg;
     if (cfg_in) cfg = *cfg_in; else gs_default_config(&cfg);
     if (cfg.tile_size != 16) return fail(nullptr, GS_ERR_INVALID, "gs_create: only tile_size 16 is supported");
-    if (cfg.sort_algorithm > GS_SORT_RADIX4_SPLAT_FIRST) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown sort_algorithm");
+    if (cfg.sort_algorithm > GS_SORT_RADIX8_SPLAT_FIRST) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown sort_algorithm");
     if (cfg.render_mode > GS_RENDER_FAST) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown render_mode");
     if (cfg.render_kernel != GS_RENDER_KERNEL_AUTO && cfg.render_kernel != GS_RENDER_KERNEL_WAVE_1PX &&
         cfg.render_kernel != GS_RENDER_KERNEL_WAVE_2PX && cfg.render_kernel != GS_RENDER_KERNEL_WAVE_4PX &&
@@ -610,7 +623,7 @@ static int alloc_scratch(gs_ctx* c, uint32_t n) {
     HIP_TRY(c, hipMemsetAsync(c->scratch.help_list, 0, (size_t)kEmitHelpCap * sizeof(uint2), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->scratch.help_slot, 0xFF, (size_t)c->num_blocks * sizeof(uint32_t), c->stream));
     c->emit_parity = 0;
-    if (c->cfg.sort_algorithm == GS_SORT_RADIX4_SPLAT_FIRST) {
+    if (sorts_splat_first(c->cfg.sort_algorithm)) {
         HIP_TRY(c, hipMalloc((void**)&c->scratch.block_flags, padded * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void**)&c->scratch.flag_offsets, padded * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void**)&c->scratch.sorted_sums, padded * sizeof(uint32_t)));
@@ -721,7 +734,7 @@ int gs_set_resolution(gs_ctx* c, uint32_t width, uint32_t height) {
     c->num_sort_bits = num_sort_bits_for(gw * gh);
     c->band_sort_bits = c->num_sort_bits;
     c->hi16 = (uint64_t)gw * gh <= 65535u;
-    int rc = alloc_sort(c, c->sort, c->capacity);
+    int rc = alloc_sort(c, c->sort, c->capacity, digit_bits_of(c->cfg.sort_algorithm));
     if (rc != GS_OK) { free_resolution(c); return rc; }
     // any failure from here on leaves the context without a resolution (capacity 0), never half set up
     hipError_t e = hipMalloc((void**)&c->ranges, ((size_t)gw * gh * 2 * sizeof(uint32_t) + 15) & ~(size_t)15);   // cleared 16 bytes at a time
@@ -998,7 +1011,7 @@ int gs_sort_host(gs_ctx* c, uint32_t* tile, uint32_t* depth, uint32_t* id, uint3
     if (n == 0) return GS_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     SortBuffers sb{};
-    int rc = alloc_sort(c, sb, n);
+    int rc = alloc_sort(c, sb, n, digit_bits_of(c->cfg.sort_algorithm));
     if (rc != GS_OK) { free_sort(sb); return rc; }
     const size_t bytes = (size_t)n * sizeof(uint32_t);
     hipError_t e = hipMemcpyAsync(sb.hi[0], tile, bytes, hipMemcpyHostToDevice, c->stream);
@@ -1007,7 +1020,8 @@ int gs_sort_host(gs_ctx* c, uint32_t* tile, uint32_t* depth, uint32_t* id, uint3
     int si = 0;
     if (e == hipSuccess) {
         launch_set_sort_params(sb.params, sb.coarse, n, c->stream);
-        si = launch_radix_sort(sb, n, num_sort_bits, c->stream);
+        si = launch_radix_sort(sb, n, num_sort_bits, c->stream, nullptr, 0u, false, false, 1.0f, 0, 0, nullptr,
+                               digit_bits_of(c->cfg.sort_algorithm));
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(tile, sb.hi[si], bytes, hipMemcpyDeviceToHost, c->stream);
@@ -1024,7 +1038,7 @@ int gs_sort_bench(gs_ctx* c, uint32_t n, uint32_t num_tiles, uint32_t iters, uin
     if (!c || !ms_per_sort || n == 0 || num_tiles == 0 || iters == 0) return GS_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     SortBuffers sb{};
-    int rc = alloc_sort(c, sb, n);
+    int rc = alloc_sort(c, sb, n, digit_bits_of(c->cfg.sort_algorithm));
     if (rc != GS_OK) { free_sort(sb); return rc; }
     const uint32_t bits = num_sort_bits_for(num_tiles);
     uint32_t* bad = nullptr;
@@ -1039,7 +1053,8 @@ int gs_sort_bench(gs_ctx* c, uint32_t n, uint32_t num_tiles, uint32_t iters, uin
         launch_set_sort_params(sb.params, sb.coarse, n, c->stream);
         e = hipEventRecord(e0, c->stream);
         if (e != hipSuccess) break;
-        si = launch_radix_sort(sb, n, bits, c->stream);
+        si = launch_radix_sort(sb, n, bits, c->stream, nullptr, 0u, false, false, 1.0f, 0, 0, nullptr,
+                               digit_bits_of(c->cfg.sort_algorithm));
         e = hipEventRecord(e1, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         float ms = 0.0f;
@@ -1166,6 +1181,32 @@ int gs_atomic_probe(gs_ctx* c, uint32_t workgroups, uint32_t lines, uint32_t row
     if (e1) (void)hipEventDestroy(e1);
     if (table) (void)hipFree(table);
     if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_atomic_probe: ") + hipGetErrorString(e));
+    *us_per_launch = ms * 1000.0f / (float)iters;
+    return GS_OK;
+}
+
+// Tuning only (tools/lds_probe.py): microseconds per launch of k_probe_lds.
+int gs_lds_probe(gs_ctx* c, uint32_t kind, uint32_t reps, uint32_t iters, float* us_per_launch) {
+    if (!c || !us_per_launch || kind > 6u || !iters || reps > 64u) return GS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t* out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void**)&out, (size_t)512 * 512 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) {
+        for (int w = 0; w < 3; ++w) launch_probe_lds(out, kind, reps, c->stream);
+        e = hipEventRecord(e0, c->stream);
+        for (uint32_t i = 0; i < iters; ++i) launch_probe_lds(out, kind, reps, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (out) (void)hipFree(out);
+    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_lds_probe: ") + hipGetErrorString(e));
     *us_per_launch = ms * 1000.0f / (float)iters;
     return GS_OK;
 }

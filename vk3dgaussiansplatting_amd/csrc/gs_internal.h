@@ -26,6 +26,19 @@ constexpr int kSegments = 512;                // reduce segments = Count workgro
 constexpr int kCoarse = 64;                   // coarse reduce segments (kSegments / kCoarse segments each): second Reduce level
 constexpr int kMaxSortPasses = 16;            // 64 key bits / 4
 
+// ---- GS_SORT_RADIX8*: the same sort with 8-bit digits (gs_sort8.hip) ------------------------
+constexpr int kBins8 = 256;
+#ifndef GS_SORT8_THREADS
+#define GS_SORT8_THREADS 256
+#endif
+#ifndef GS_SORT8_KEYS
+#define GS_SORT8_KEYS 16
+#endif
+constexpr int kSort8Threads = GS_SORT8_THREADS;
+constexpr int kSort8KeysPerThread = GS_SORT8_KEYS;
+constexpr int kSort8Tile = kSort8Threads * kSort8KeysPerThread;   // keys per group
+static_assert(kBins8 <= kBins * kCoarse, "a pass's 256 digit totals live in its slab of SortBuffers::coarse");
+
 // ---- InitSortList tiling -----------------------------------------------------------------
 constexpr int kProjThreads = 256;      // splats per workgroup in project + emit
 
@@ -137,21 +150,24 @@ __host__ __device__ inline uint32_t emit_helpers(uint32_t capacity) {
 
 struct SortBuffers {
     uint32_t *lo[2], *hi[2], *id[2]; // ping-pong: depth word, tile word, gaussian index; [capacity]
-    uint32_t* table;                 // [16][G_max]  per-group digit counts (sumTable)
-    uint32_t* seg_sum;               // [16][kSegments]  per-segment digit counts (reduce buffer)
+    uint32_t* table;                 // [16][G_max]  per-group digit counts (sumTable); 8-bit digits: [G8_max][256]
+    uint32_t* seg_sum;               // [16][kSegments]  per-segment digit counts (reduce buffer); 8-bit digits:
+                                     // [256][kSegments] counts, then [256][kSegments] scanned
     uint32_t* coarse;                // [kMaxSortPasses][16][kCoarse]  per-pass digit counts of the coarse segments
+                                     // (8-bit digits: the first 256 words of a pass's slab = its digit totals)
     SortParams* params;
 };
 
 // Bytes of the depth word a radix pass reads / writes per element (k_scatter<LO_IN, LO_OUT, HI16>); shared by the
 // launcher and by the timing code that reports the bytes a pass moves.
-inline void scatter_depth_bytes(uint32_t shift, uint32_t first_bit, bool drop_depth_payload, int* lo_in, int* lo_out) {
+inline void scatter_depth_bytes(uint32_t shift, uint32_t first_bit, bool drop_depth_payload, int* lo_in, int* lo_out,
+                                uint32_t digit_bits = kRadixBits) {
     *lo_in = 4; *lo_out = 4;
     if (!drop_depth_payload) return;
     if (shift >= 32u) { *lo_in = 0; *lo_out = 0; return; }
-    if (first_bit == 0u) {
+    if (first_bit == 0u) {   // what the passes still to come read: nothing below bit shift + digit_bits
         *lo_in = shift >= 16u ? 2 : 4;
-        *lo_out = shift >= 28u ? 0 : (shift >= 12u ? 2 : 4);
+        *lo_out = shift + digit_bits >= 32u ? 0 : (shift + digit_bits >= 16u ? 2 : 4);
     }
 }
 
@@ -180,7 +196,12 @@ void launch_emit_sorted(const FrameParams& fp, const SplatScratch& sc, const Sor
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events = nullptr, uint32_t first_bit = 0,
                       bool drop_depth_payload = false, bool hi16 = false, float share = 1.0f,
-                      int start = 0, uint32_t coarse_pass = 0, const SortParams* params = nullptr);
+                      int start = 0, uint32_t coarse_pass = 0, const SortParams* params = nullptr,
+                      uint32_t digit_bits = kRadixBits);
+// the same with 8-bit digits (gs_sort8.hip); launch_radix_sort forwards here when digit_bits == 8
+int launch_radix_sort8(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits, hipStream_t stream,
+                       hipEvent_t* scatter_events, uint32_t first_bit, bool drop_depth_payload, bool hi16, float share,
+                       int start, uint32_t coarse_pass, const SortParams* params);
 // GS_SORT_TILE_BUCKET: per-tile depth sort of the owned tiles (gs_tilesort.hip)
 int init_tile_sort();
 void launch_tile_sort(const FrameParams& fp, const uint32_t* ranges, uint32_t* lo, uint32_t* id,
@@ -202,6 +223,7 @@ void launch_stream_probe(int kind, const void* src, void* dst, size_t bytes, uin
 void launch_probe_step(const void* src, void* dst, uint32_t workgroups, uint32_t per_wg, uint32_t step, hipStream_t stream);
 void launch_probe_atomics(uint32_t* table, uint32_t rows, uint32_t workgroups, uint32_t lines, uint32_t stride_num, uint32_t stride_den,
                           uint32_t add, hipStream_t stream);
+void launch_probe_lds(uint32_t* out, uint32_t kind, uint32_t reps, hipStream_t stream);   // out: 512 x 512 words
 void launch_probe_persistent(void* a, void* b, uint32_t workgroups, uint32_t per_wg, uint32_t steps, uint32_t* counter,
                              uint32_t* timed_out, hipStream_t stream);
 void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,

@@ -205,6 +205,9 @@ __global__ __launch_bounds__(kCountThreads) void k_count(const SortParams* __res
 //              consecutive global indices (RadixSortScatter.comp:153-168): run-wise coalesced stores
 // The group count (not the list capacity) bounds the work: surplus workgroups leave at once.
 // ---------------------------------------------------------------------------------------------
+#ifndef GS_SCATTER_XCD
+#define GS_SCATTER_XCD 1
+#endif
 #ifndef GS_SCATTER_MINWAVES_KEY
 #define GS_SCATTER_MINWAVES_KEY 5    // resident workgroups per CU asked of the compiler: passes that carry 12 or more bytes
 #endif
@@ -397,8 +400,20 @@ void k_scatter(const SortParams* __restrict__ params, const uint32_t* __restrict
     const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
     // one group per workgroup as a rule: the grid is sized from an upper estimate of the element count (the list
     // capacity scaled to the context's share of the tiles) and walks on only if a frame exceeds it
+#if GS_SCATTER_XCD
+    // Workgroups b, b + 8, ... share an XCD (observed placement, speed only): each of the eight takes a contiguous run of
+    // the groups, so that the digit runs of neighbouring groups -- neighbours in the destination too -- meet in one L2.
+    const uint32_t per_xcd = (G + 7u) / 8u;
+    bool again = false;
+    for (uint32_t vb = blockIdx.x; vb < 8u * per_xcd; vb += gridDim.x) {
+        const uint32_t grp = (vb & 7u) * per_xcd + (vb >> 3);
+        if (grp >= G) continue;
+#else
+    bool again = false;
     for (uint32_t grp = blockIdx.x; grp < G; grp += gridDim.x) {
-        if (grp != blockIdx.x) __syncthreads();   // LDS is reused
+#endif
+        if (again) __syncthreads();   // LDS is reused
+        again = true;
         if (grp * kSortTile + kSortTile <= e)
             scatter_group<LO_IN, LO_OUT, HI16, true>(e, G, K, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table,
                                                      seg_sum, coarse, shift, s_slot, s_third, s_wcnt, s_pre);
@@ -411,7 +426,10 @@ void k_scatter(const SortParams* __restrict__ params, const uint32_t* __restrict
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit,
                       bool drop_depth_payload, bool hi16, float share, int start, uint32_t coarse_pass,
-                      const SortParams* params) {
+                      const SortParams* params, uint32_t digit_bits) {
+    if (digit_bits == 8u)
+        return launch_radix_sort8(sb, capacity, num_sort_bits, stream, scatter_events, first_bit, drop_depth_payload, hi16,
+                                  share, start, coarse_pass, params);
     if (!params) params = sb.params;
     uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
     // a context that owns a share of the tiles (tile-row band of a multi-GPU frame) launches Scatter over twice

@@ -2,6 +2,7 @@
 // (Engine/Graphics/ShaderStructs.h:59-70) to the SoA planes the per-frame kernels read with fully
 // coalesced loads.  Runs once per scene (Renderer::initForScene, Renderer.cpp:712-724), chunk by
 // chunk through a staging buffer so a 50 M-splat scene never needs a second full-size AoS copy in HBM.
+#include "gs_device_utils.h"
 #include "gs_internal.h"
 
 namespace gs {
@@ -271,6 +272,53 @@ __global__ __launch_bounds__(256) void k_probe_atomics(uint32_t* __restrict__ ta
 void launch_probe_atomics(uint32_t* table, uint32_t rows, uint32_t workgroups, uint32_t lines, uint32_t stride_num, uint32_t stride_den,
                           uint32_t add, hipStream_t stream) {
     hipLaunchKernelGGL(k_probe_atomics, dim3(workgroups), dim3(256), 0, stream, table, rows, lines, stride_num, stride_den, add);
+}
+
+// ---- How fast are 256-bin histograms in LDS?  (tuning only: the Count of the 8-bit sorter.)  1024 workgroups of 4 waves;
+//      every lane makes `reps` x 32 updates with digits from a register generator -- no memory loads -- in one of the forms
+//      below, then the counters are summed into out[] so that nothing is optimised away.
+//      kind 0 no LDS (generator only) | 1 ds_add, random digit, one histogram per wave | 2 ds_add, address = lane |
+//      3 ds_add, three digits | 4 plain read-modify-write of the lane's own column of packed byte counters |
+//      5 eight ballots + one ds_add per digit present in the round | 6 like 1 with the returning form
+__global__ __launch_bounds__(256) void k_probe_lds(uint32_t* __restrict__ out, uint32_t kind, uint32_t reps) {
+    __shared__ uint32_t s_h[4][4096];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t* h = s_h[wave];
+    for (uint32_t i = lane; i < 4096u; i += 64u) h[i] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t x = (blockIdx.x * 256u + tid) * 2654435761u + 12345u, acc = 0u;
+    for (uint32_t r = 0; r < reps; ++r) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            x = x * 1664525u + 1013904223u;
+            const uint32_t d = x >> 24;
+            if (kind == 0u) acc ^= d;
+            else if (kind == 1u) (void)__hip_atomic_fetch_add(&h[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (kind == 2u) (void)__hip_atomic_fetch_add(&h[lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (kind == 3u) (void)__hip_atomic_fetch_add(&h[d % 3u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (kind == 4u) { uint32_t* p = &h[(d >> 2) * 64u + lane]; *p = *p + (1u << (8u * (d & 3u))); }
+            else if (kind == 5u) {
+                uint32_t m_lo = 0xFFFFFFFFu, m_hi = 0xFFFFFFFFu;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int32_t sbit = __builtin_amdgcn_sbfe((int32_t)d, (uint32_t)b, 1u);
+                    const uint64_t bal = __ballot(sbit != 0);
+                    m_lo &= ~((uint32_t)bal ^ (uint32_t)sbit);
+                    m_hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)sbit);
+                }
+                const uint64_t same = ((uint64_t)m_hi << 32) | m_lo;
+                if (mbcnt(same) == 0u) (void)__hip_atomic_fetch_add(&h[d], (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else acc += __hip_atomic_fetch_add(&h[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < 4096u; i += 64u) acc += h[i];
+    out[blockIdx.x * 256u + tid] = acc;
+}
+void launch_probe_lds(uint32_t* out, uint32_t kind, uint32_t reps, hipStream_t stream) {
+    hipLaunchKernelGGL(k_probe_lds, dim3(1024), dim3(256), 0, stream, out, kind, reps);
 }
 
 void launch_probe_step(const void* src, void* dst, uint32_t workgroups, uint32_t per_wg, uint32_t step, hipStream_t stream) {

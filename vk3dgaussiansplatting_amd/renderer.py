@@ -308,9 +308,10 @@ class RadixSort(GpuSort):
 
     RS_BITS_PER_PASS = 4
     RS_BIN_COUNT = 16
+    SORT_ALGORITHM = _lib.GS_SORT_RADIX4
 
     def __init__(self, device: int = 0):
-        self._ctx = _Context(device)
+        self._ctx = _Context(device, sort_algorithm=self.SORT_ALGORITHM)
         self.maxNumSortElements = 0
         self.radixSortNumSortBits = 0
 
@@ -344,6 +345,14 @@ class RadixSort(GpuSort):
 
     def cleanup(self):
         self._ctx.close()
+
+
+class RadixSort8(RadixSort):
+    """The A/B variant behind the same seam: 8-bit digits, half the passes, same result (GS_SORT_RADIX8)."""
+
+    RS_BITS_PER_PASS = 8
+    RS_BIN_COUNT = 256
+    SORT_ALGORITHM = _lib.GS_SORT_RADIX8
 
 
 class Renderer:
