@@ -539,6 +539,20 @@ def main():
                         "keys, ranges and pixels; one frame slot.  Not the default: the default keeps the reference's "
                         "stage order (InitSortList, then all passes over the 64-bit keys)"}
 
+    def x_radix8(sort):
+        def run():
+            r8 = Ring(1, sort=sort, owner=owner)
+            ms_8 = r8.timed(min(args.steps, 300), 20)
+            same = bool(torch.equal(r8.sf.strips[0], sf_main.strips[0]))
+            r8.close()
+            return {"sort_algorithm": sort, "ms_per_step": round(ms_8, 4), "value": round(n / ms_8 / 1000.0, 2),
+                    "image_identical_to_default": same,
+                    "note": "the A/B slot of SURVEY 8(f)-4: the same stable LSD radix sort with 8-bit digits (six passes of "
+                            "Count, Scan, Scatter instead of twelve), bit-identical keys, ranges and pixels; one frame slot.  "
+                            "Not the default: the contract names the 4-bit passes" +
+                            ("; here with GS_SORT_RADIX4_SPLAT_FIRST's stage order" if "splat" in sort else "")}
+        return run
+
     def x_fast_render():
         rf_ = Ring(1, owner=owner, render_mode=gs.GS_RENDER_FAST)
         ms_f = rf_.timed(min(args.steps, 300), 20)
@@ -611,6 +625,9 @@ def main():
         extra("alt_sorter", x_alt_sorter)
         if args.sort != "splat_first":
             extra("splat_first_sorter", x_splat_first)
+        if args.sort == "radix4":
+            extra("radix8_sorter", x_radix8("radix8"))
+            extra("radix8_splat_first_sorter", x_radix8("radix8_splat_first"))
         if args.mode == "exact":
             extra("fast_render_mode", x_fast_render)
         if args.config == "C":

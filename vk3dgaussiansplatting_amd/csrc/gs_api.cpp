@@ -738,7 +738,7 @@ int gs_set_resolution(gs_ctx* c, uint32_t width, uint32_t height) {
     if (rc != GS_OK) { free_resolution(c); return rc; }
     // any failure from here on leaves the context without a resolution (capacity 0), never half set up
     hipError_t e = hipMalloc((void**)&c->ranges, ((size_t)gw * gh * 2 * sizeof(uint32_t) + 15) & ~(size_t)15);   // cleared 16 bytes at a time
-    if (e == hipSuccess) e = hipMalloc((void**)&c->tile_order, (size_t)gw * gh * 2 * sizeof(uint32_t));   // table + k_tile_order's scratch
+    if (e == hipSuccess) e = hipMalloc((void**)&c->tile_order, tile_order_words(gw, gh) * sizeof(uint32_t));   // table + scratch of the two kernels
     if (e == hipSuccess) e = hipMalloc((void**)&c->framebuffer, (size_t)width * height * 4);
     if (e == hipSuccess) e = hipMemset(c->ranges, 0, (size_t)gw * gh * 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(c->framebuffer, 0, (size_t)width * height * 4);

@@ -211,6 +211,7 @@ void launch_find_ranges(const FrameParams& fp, const uint32_t* sorted_tile, cons
                         uint32_t* ranges, hipStream_t stream);
 // order[k] = the k-th tile RenderGaussians dispatches, as an index among the context's own tiles, longest list first
 void launch_tile_order(const FrameParams& fp, const uint32_t* ranges, uint32_t* order, hipStream_t stream);
+size_t tile_order_words(uint32_t grid_w, uint32_t grid_h);   // words `order` must hold: the table and the kernels' scratch
 // order == nullptr: raster order
 void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
                    const uint32_t* ranges, const uint32_t* order, uint8_t* rgba, uint32_t render_mode,

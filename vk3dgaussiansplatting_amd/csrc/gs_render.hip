@@ -554,10 +554,10 @@ void launch_find_ranges(const FrameParams& fp, const uint32_t* sorted_tile, cons
 // Dispatch order of RenderGaussians' tiles: longest list first.  Workgroups are handed out in grid order and a tile's
 // time grows with its list, so on a capture-like scene (a few tiles with tens of thousands of entries, most with
 // hundreds) raster order leaves the heaviest tiles wherever they happen to lie and the launch ends on them; sorted by
-// list length the tail is made of the shortest tiles.  One workgroup: the owned tiles binned into 33 classes by
-// bits(end - start), longest class first, any order inside a class (every order gives the same pixels).
+// list length the tail is made of the shortest tiles.  The owned tiles are binned into 33 classes by bits(end - start),
+// longest class first, any order inside a class (every order gives the same pixels).
 // The LDS counters are fed per wave and class -- the lanes of a class elect a leader that adds their number -- not per
-// tile (1024 threads on three or four addresses took 50 us at 4K).
+// tile (1024 threads on three or four addresses are slow).
 __device__ __forceinline__ uint32_t class_slot(uint32_t cls, bool active, uint32_t* counters) {
     // For an active lane: the value of counters[cls] before this wave's lanes of that class, plus the lane's rank among
     // them.  The lanes of one class find each other with one ballot per class bit (as the radix Scatter finds equal
@@ -576,64 +576,75 @@ __device__ __forceinline__ uint32_t class_slot(uint32_t cls, bool active, uint32
     return base + rank;
 }
 
-constexpr int kOrderRounds = 32;    // tiles a thread has in flight at once: 32768 tiles (a 4K frame) per sweep of the workgroup
-__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order,
-                                                      uint32_t* __restrict__ scratch, uint32_t tiles, TileMap map) {
+// Two launches over the tiles, 1024 per workgroup.  k_tile_classes: class and slot of every tile among the tiles of its
+// class in its workgroup (arrival order), packed into scratch[c]; the workgroup's 33 class counts into wg_count.
+// k_tile_scatter: every workgroup sums the counts of the others (first position of each class, longest class first,
+// plus the tiles of that class in earlier workgroups) and places its tiles.  (One workgroup doing both took 10 us at
+// 1920 x 1080 and 29 us at 4K: a single CU's instruction issue over 32,400 tiles.)
+constexpr uint32_t kOrderTiles = 1024u;      // tiles per workgroup
+__global__ __launch_bounds__(1024) void k_tile_classes(const uint32_t* __restrict__ ranges, uint32_t* __restrict__ scratch,
+                                                        uint32_t* __restrict__ wg_count, uint32_t tiles, TileMap map) {
     __shared__ uint32_t s_count[33];
     if (threadIdx.x < 33) s_count[threadIdx.x] = 0u;
     __syncthreads();
-    // Class of every tile and its slot inside the class (arrival order: what the class counter held when the tile's
-    // wave added its lanes), packed into scratch[c] -- written and read back by the same thread.  The ranges of
-    // kOrderRounds tiles per thread are loaded up front: the kernel is one workgroup and all latency.
-    for (uint32_t c0 = 0; c0 < tiles; c0 += (uint32_t)kOrderRounds * 1024u) {
-        uint2 r[kOrderRounds];
-#pragma unroll
-        for (int k = 0; k < kOrderRounds; ++k) {
-            const uint32_t c = c0 + (uint32_t)k * 1024u + threadIdx.x;
-            r[k] = c < tiles ? reinterpret_cast<const uint2*>(ranges)[global_tile(map, c)] : make_uint2(0u, 0u);
-        }
-#pragma unroll
-        for (int k = 0; k < kOrderRounds; ++k) {
-            const uint32_t c = c0 + (uint32_t)k * 1024u + threadIdx.x;
-            if (c0 + (uint32_t)k * 1024u >= tiles) break;              // uniform: whole waves vote in every round
-            const bool active = c < tiles;
-            const uint32_t len = r[k].y > r[k].x ? r[k].y - r[k].x : 0u;
-            const uint32_t cls = len ? 32u - (uint32_t)__builtin_clz(len) : 0u;   // bits(len): 0 for an empty tile, else 1 .. 32
-            const uint32_t slot = class_slot(cls, active, s_count);
-            if (active) scratch[c] = cls | (slot << 6);
+    const uint32_t c = blockIdx.x * kOrderTiles + threadIdx.x;
+    const bool active = c < tiles;                                       // whole waves vote in class_slot
+    const uint2 r = active ? reinterpret_cast<const uint2*>(ranges)[global_tile(map, c)] : make_uint2(0u, 0u);
+    const uint32_t len = r.y > r.x ? r.y - r.x : 0u;
+    const uint32_t cls = len ? 32u - (uint32_t)__builtin_clz(len) : 0u;   // bits(len): 0 for an empty tile, else 1 .. 32
+    const uint32_t slot = class_slot(cls, active, s_count);
+    if (active) scratch[c] = cls | (slot << 6);
+    __syncthreads();
+    if (threadIdx.x < 33) wg_count[blockIdx.x * 33u + threadIdx.x] = s_count[threadIdx.x];
+}
+
+__global__ __launch_bounds__(1024) void k_tile_scatter(const uint32_t* __restrict__ scratch, const uint32_t* __restrict__ wg_count,
+                                                        uint32_t* __restrict__ order, uint32_t tiles) {
+    __shared__ uint32_t s_total[33], s_before[33], s_base[33];
+    if (threadIdx.x < 33) { s_total[threadIdx.x] = 0u; s_before[threadIdx.x] = 0u; }
+    __syncthreads();
+    const uint32_t c = blockIdx.x * kOrderTiles + threadIdx.x;
+    const uint32_t v = c < tiles ? scratch[c] : 0u;
+    // class t = lane (33 of the 64 lanes of a wave), the sixteen waves take the workgroups b' = wave, wave + 16, ...
+    {
+        const uint32_t t = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        if (t < 33u) {
+            uint32_t total = 0u, before = 0u;
+            for (uint32_t b = wave; b < gridDim.x; b += 16u) {
+                const uint32_t n = wg_count[b * 33u + t];
+                total += n;
+                before += b < blockIdx.x ? n : 0u;
+            }
+            if (total) atomicAdd(&s_total[t], total);
+            if (before) atomicAdd(&s_before[t], before);
         }
     }
     __syncthreads();
-    // first position of every class, longest class first: an inclusive DPP scan over the reversed counters (wave 0)
-    uint32_t base = 0u;
+    // first position of every class, longest class first: an inclusive DPP scan over the reversed totals (wave 0)
     if (threadIdx.x < 64) {
-        const uint32_t n = threadIdx.x < 33 ? s_count[32 - threadIdx.x] : 0u;
-        base = wave_inclusive_scan(n) - n;
+        const uint32_t n = threadIdx.x < 33 ? s_total[32 - threadIdx.x] : 0u;
+        const uint32_t start = wave_inclusive_scan(n) - n;
+        if (threadIdx.x < 33) s_base[32 - threadIdx.x] = start + s_before[32 - threadIdx.x];
     }
     __syncthreads();
-    if (threadIdx.x < 33) s_count[32 - threadIdx.x] = base;
-    __syncthreads();
-    for (uint32_t c0 = 0; c0 < tiles; c0 += (uint32_t)kOrderRounds * 1024u) {
-        uint32_t v[kOrderRounds];
-#pragma unroll
-        for (int k = 0; k < kOrderRounds; ++k) {
-            const uint32_t c = c0 + (uint32_t)k * 1024u + threadIdx.x;
-            v[k] = c < tiles ? scratch[c] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < kOrderRounds; ++k) {
-            const uint32_t c = c0 + (uint32_t)k * 1024u + threadIdx.x;
-            if (c < tiles) order[s_count[v[k] & 63u] + (v[k] >> 6)] = c;
-        }
-    }
+    if (c < tiles) order[s_base[v & 63u] + (v >> 6)] = c;
 }
 
 void launch_tile_order(const FrameParams& fp, const uint32_t* ranges, uint32_t* order, hipStream_t stream) {
     const uint32_t tiles = fp.rows_owned * fp.grid_w;
     if (tiles == 0) return;
     const TileMap map{fp.grid_w, fp.first_row, fp.row_stride};
-    // order[0 .. tiles) is the table, order[grid_w * grid_h ...) the kernel's scratch (gs_set_resolution allocates both)
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, ranges, order, order + (size_t)fp.grid_w * fp.grid_h, tiles, map);
+    // order[0 .. tiles) is the table, then tiles words of scratch, then 33 counts per workgroup (tile_order_words below)
+    const size_t all = (size_t)fp.grid_w * fp.grid_h;
+    uint32_t* scratch = order + all;
+    uint32_t* wg_count = order + 2 * all;
+    const uint32_t wgs = (tiles + kOrderTiles - 1u) / kOrderTiles;
+    hipLaunchKernelGGL(k_tile_classes, dim3(wgs), dim3(1024), 0, stream, ranges, scratch, wg_count, tiles, map);
+    hipLaunchKernelGGL(k_tile_scatter, dim3(wgs), dim3(1024), 0, stream, scratch, wg_count, order, tiles);
+}
+size_t tile_order_words(uint32_t grid_w, uint32_t grid_h) {
+    const size_t all = (size_t)grid_w * grid_h;
+    return 2 * all + ((all + kOrderTiles - 1u) / kOrderTiles) * 33u;
 }
 
 void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
