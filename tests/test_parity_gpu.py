@@ -508,7 +508,8 @@ def test_config_e_full_size(oracle_mod):
     k_project / k_emit at N = 5e7 and the 64-bit element counter; counter, keys, payload order, ranges bit-exact,
     pixels bit-exact on six tile rows spread over the frame (a full-frame CPU blend of 6.5 k-entry tile lists
     would take minutes)."""
-    e = full_size_parity(oracle_mod, "E", (gs.GS_SORT_RADIX4, gs.GS_SORT_RADIX4_SPLAT_FIRST), 2**26, 48, pixel_tile_rows=(0, 13, 27, 34, 50, 67))
+    e = full_size_parity(oracle_mod, "E", (gs.GS_SORT_RADIX4, gs.GS_SORT_RADIX4_SPLAT_FIRST, gs.GS_SORT_RADIX8, gs.GS_SORT_RADIX8_SPLAT_FIRST),
+                         2**26, 48, pixel_tile_rows=(0, 13, 27, 34, 50, 67))
     assert e > 50_000_000
 
 
@@ -999,7 +1000,7 @@ def test_randomized_frames(oracle_mod):
         pos = tuple(float(x) for x in rng.uniform(-1.0, 1.0, 3) * np.array([1.0, 0.5, 2.0]))
         yaw, pitch = float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.3, 0.3))
         sh_mode = int(rng.integers(0, 3))
-        sort = ALL_SORTS[int(rng.choice(3, p=[0.45, 0.2, 0.35]))]
+        sort = ALL_SORTS[int(rng.choice(5, p=[0.3, 0.1, 0.2, 0.2, 0.2]))]
         kernel = kernels[int(rng.integers(0, len(kernels)))]
         sc = make_scene(aos, w, h, pos=pos, yaw=yaw, pitch=pitch, sh_mode=sh_mode)
         order = gs.GS_TILE_ORDER_RASTER if case % 4 == 3 else gs.GS_TILE_ORDER_LONGEST_FIRST

@@ -6,17 +6,21 @@
 //
 //   k_count8    Count  : digit histogram of every group of kSort8Tile keys; a wave takes 2048 keys per step with 16-byte
 //                        loads of the one word the digit lives in and adds into the group's 256 LDS counters
-//                        (RadixSortCount.comp:40-91 with 256 bins).
+//                        (RadixSortCount.comp:40-91 with 256 bins; the depth passes add a run of equal digits in
+//                        neighbouring lanes -- one splat's keys -- with one atomic, see count8_keys).
 //               Reduce + ScanAdd inside a segment: workgroup s owns the contiguous groups of segment s; thread d walks
 //                        them and leaves in table[group][d] the keys of digit d in the EARLIER groups of the segment
-//                        (group-major: a row is 1 KB, written and later read as one line run), the segment totals in
-//                        seg_sum[d][s] and, one level up, in totals[d] (one atomic add per digit and workgroup).
-//   k_scan8     Scan   : workgroup d scans the 512 segment totals of digit d and adds the keys of all smaller digits:
-//                        seg_base[d][s] = global index of the first key of digit d of segment s (RadixSortScan.comp:29-71).
-//   k_scatter8  ScanAdd, the rest: thread d adds seg_base[d][segment] and table[group][d].
+//                        (group-major: a row is 1 KB, written and later read as one line run) and the segment's
+//                        totals in seg_sum[s][d], again one 1 KB row.
+//   k_scan8     Scan   : workgroup d scans the 512 segment totals of digit d: seg_base[d][s] = keys of digit d in the
+//                        segments before s, totals[d] = keys of digit d in the list (RadixSortScan.comp:29-71).
+//   k_scatter8  ScanAdd, the rest: thread d adds seg_base[d][segment] and table[group][d]; the keys of all smaller
+//                        digits come from a wave scan over totals[].
 //               Scatter: one workgroup per group: wave64 match-mask ranking over the eight digit bits (stable), the
 //                        waves' running digit counts in LDS, local sort into LDS, run-wise stores
-//                        (RadixSortScatter.comp:58-171).
+//                        (RadixSortScatter.comp:58-171).  Groups are dealt to workgroups so that neighbouring groups
+//                        share an XCD: a digit run is only 16 keys long on average, and the runs of neighbouring
+//                        groups complete each other's cache lines inside one L2.
 // Word widths inside a frame as in gs_sort.hip: 16-bit compact tile ids, depth words that shrink once their lower
 // half is consumed (pass 0 moves all of it, pass 1 keeps the upper half, pass 2 sorts on that half, pass 3 drops it).
 #include "gs_device_utils.h"
@@ -115,7 +119,10 @@ __global__ __launch_bounds__(kC8Threads) void k_count8(const SortParams* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t grp0 = blockIdx.x * K;
     const uint32_t grp_end = grp0 + K < G ? grp0 + K : G;
-    for (int i = tid; i < kC8MaxK * kBins8; i += kC8Threads) (&s_hist[0][0])[i] = 0u;
+    {   // the counters of the groups of one round (the walk below clears what it has read)
+        const uint32_t rows = grp_end > grp0 ? (grp_end - grp0 < (uint32_t)kC8MaxK ? grp_end - grp0 : (uint32_t)kC8MaxK) : 0u;
+        for (uint32_t i = tid; i < rows * kBins8; i += kC8Threads) (&s_hist[0][0])[i] = 0u;
+    }
     __syncthreads();
     uint32_t run = 0;                                    // thread d: keys of digit d in the segment so far
     for (uint32_t b0 = grp0; b0 < grp_end; b0 += kC8MaxK) {   // one round for every list a frame can hold (E <= 67 M)
