@@ -166,7 +166,7 @@ int alloc_sort(gs_ctx* ctx, SortBuffers& s, uint32_t capacity, uint32_t digit_bi
         HIP_TRY(ctx, hipMalloc((void**)&s.id[k], bytes));
     }
     if (digit_bits == 8u) {   // gs_sort8.hip: [groups][256] counts; segment counts + their scan
-        const uint32_t max_groups = (capacity + kSort8Tile - 1) / kSort8Tile;
+        const uint32_t max_groups = (capacity + kSort8TileSmall - 1) / kSort8TileSmall;   // the smaller of the two group sizes
         HIP_TRY(ctx, hipMalloc((void**)&s.table, (size_t)kBins8 * max_groups * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMalloc((void**)&s.seg_sum, (size_t)2 * kBins8 * kSegments * sizeof(uint32_t)));
     } else {

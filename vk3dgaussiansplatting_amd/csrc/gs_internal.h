@@ -28,15 +28,14 @@ constexpr int kMaxSortPasses = 16;            // 64 key bits / 4
 
 // ---- GS_SORT_RADIX8*: the same sort with 8-bit digits (gs_sort8.hip) ------------------------
 constexpr int kBins8 = 256;
-#ifndef GS_SORT8_THREADS
-#define GS_SORT8_THREADS 256
+#ifndef GS_SORT8_SMALL_BELOW
+#define GS_SORT8_SMALL_BELOW 12000000   /* lists that cannot hold this many elements sort in 2048-key groups */
 #endif
-#ifndef GS_SORT8_KEYS
-#define GS_SORT8_KEYS 16
-#endif
-constexpr int kSort8Threads = GS_SORT8_THREADS;
-constexpr int kSort8KeysPerThread = GS_SORT8_KEYS;
-constexpr int kSort8Tile = kSort8Threads * kSort8KeysPerThread;   // keys per group
+constexpr int kSort8Threads = 256;
+constexpr int kSort8KeysPerThread = 16, kSort8KeysSmall = 8;
+constexpr int kSort8Tile = kSort8Threads * kSort8KeysPerThread;   // keys per group: 4096 ...
+constexpr int kSort8TileSmall = kSort8Threads * kSort8KeysSmall;  // ... or 2048 (launch_radix_sort8 chooses)
+constexpr uint32_t kSort8SmallBelow = GS_SORT8_SMALL_BELOW;
 static_assert(kBins8 <= kBins * kCoarse, "a pass's 256 digit totals live in its slab of SortBuffers::coarse");
 
 // ---- InitSortList tiling -----------------------------------------------------------------

@@ -34,11 +34,10 @@ namespace gs {
 #define GS_S8_XCD 1
 #endif
 constexpr int kC8Chunk = 2048;                          // keys a Count wave takes per step
-constexpr int kC8ChunksPerGroup = kSort8Tile / kC8Chunk;
 constexpr int kC8Waves = 8;
 constexpr int kC8Threads = kC8Waves * 64;
 constexpr int kC8MaxK = 32;                             // groups of a segment whose counters sit in LDS at once (32 KB)
-static_assert(kSort8Tile % kC8Chunk == 0, "a group is a whole number of Count steps");
+static_assert(kSort8TileSmall % kC8Chunk == 0 && kSort8Tile % kC8Chunk == 0, "a group is a whole number of Count steps");
 
 template <bool W16>
 struct Count8Regs { uint4 v[W16 ? 4 : 8]; };            // 32 keys per lane
@@ -108,13 +107,14 @@ __device__ __forceinline__ void count8_keys(const Count8Regs<W16>& k, uint32_t c
     }
 }
 
-template <bool W16, bool RUNS>
+template <bool W16, bool RUNS, int TILE>
 __global__ __launch_bounds__(kC8Threads) void k_count8(const SortParams* __restrict__ params,
                                                        const uint32_t* __restrict__ word, uint32_t* __restrict__ table,
                                                        uint32_t* __restrict__ seg_sum, uint32_t sh, uint32_t mask) {
     __shared__ uint32_t s_hist[kC8MaxK][kBins8];
+    constexpr uint32_t kC8ChunksPerGroup = TILE / kC8Chunk;
     const uint32_t e = params->num_elems;
-    const uint32_t G = (e + kSort8Tile - 1) / kSort8Tile, K = (G + kSegments - 1) / kSegments;
+    const uint32_t G = (e + TILE - 1) / TILE, K = (G + kSegments - 1) / kSegments;
     const uint32_t chunks = (e + kC8Chunk - 1) / kC8Chunk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t grp0 = blockIdx.x * K;
@@ -186,21 +186,21 @@ __global__ __launch_bounds__(kSegments) void k_scan8(const uint32_t* __restrict_
 //   barrier 2
 //   store      position p = r*threads + tid read back linearly, global index = offset[digit] + p
 // ---------------------------------------------------------------------------------------------
-template <int LO_IN, int LO_OUT, bool HI16, bool FULL>
+template <int LO_IN, int LO_OUT, bool HI16, bool FULL, int R>
 __device__ __forceinline__ void scatter8_group(
     uint32_t e, uint32_t seg, uint32_t grp, const uint32_t* __restrict__ in_lo, const uint32_t* __restrict__ in_hi,
     const uint32_t* __restrict__ in_id, uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_hi,
     uint32_t* __restrict__ out_id, const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base,
     const uint32_t* __restrict__ totals, uint32_t shift, uint32_t mask, uint2* s_slot, typename std::conditional<HI16, uint16_t, uint32_t>::type* s_third,
     uint32_t* s_cnt, uint32_t* s_wbase, uint32_t* s_gpre, uint32_t* s_gofs, uint32_t* s_tot) {
-    constexpr int R = kSort8KeysPerThread, NT = kSort8Threads, W = NT / 64;
+    constexpr int NT = kSort8Threads, W = NT / 64, TILE = NT * R;
     using third_t = typename std::conditional<HI16, uint16_t, uint32_t>::type;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool use_hi = shift >= 32u;
     const uint32_t sh = use_hi ? shift - 32u : (LO_IN == 2 ? shift - 16u : shift);   // bit offset inside the stored word
-    const uint32_t tile_base = grp * kSort8Tile;
+    const uint32_t tile_base = grp * TILE;
     const uint32_t base = tile_base + (uint32_t)wave * (R * 64) + lane;
-    const uint32_t valid = FULL ? (uint32_t)kSort8Tile : e - tile_base;
+    const uint32_t valid = FULL ? (uint32_t)TILE : e - tile_base;
 
     uint32_t lo[R], hi[R], id[R];
     {
@@ -241,6 +241,7 @@ __device__ __forceinline__ void scatter8_group(
         if (!FULL) { const uint64_t v = __ballot(ok); m_lo = (uint32_t)v; m_hi = (uint32_t)(v >> 32); }
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
+            if (b >= 4 && (mask >> b) == 0u) break;                                     // a last pass of fewer bits (uniform)
             const int32_t sbit = __builtin_amdgcn_sbfe((int32_t)dg, (uint32_t)b, 1u);   // all ones where the bit is set
             const uint64_t bal = __ballot(sbit != 0);
             m_lo &= ~((uint32_t)bal ^ (uint32_t)sbit);                                  // lanes that agree on bit b
@@ -322,7 +323,7 @@ __device__ __forceinline__ void scatter8_group(
     }
 }
 
-template <int LO_IN, int LO_OUT, bool HI16>
+template <int LO_IN, int LO_OUT, bool HI16, int R>
 __global__ __launch_bounds__(kSort8Threads)
 void k_scatter8(const SortParams* __restrict__ params, const uint32_t* __restrict__ in_lo,
                 const uint32_t* __restrict__ in_hi, const uint32_t* __restrict__ in_id,
@@ -330,16 +331,16 @@ void k_scatter8(const SortParams* __restrict__ params, const uint32_t* __restric
                 const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_base,
                 const uint32_t* __restrict__ totals, uint32_t shift, uint32_t mask) {
     constexpr bool kThird = LO_IN == 4 || (LO_IN == 2 && !HI16);
-    constexpr int W = kSort8Threads / 64;
-    __shared__ uint2 s_slot[kSort8Tile];
-    __shared__ typename std::conditional<HI16, uint16_t, uint32_t>::type s_third[kThird ? kSort8Tile : 1];
+    constexpr int W = kSort8Threads / 64, TILE = kSort8Threads * R;
+    __shared__ uint2 s_slot[TILE];
+    __shared__ typename std::conditional<HI16, uint16_t, uint32_t>::type s_third[kThird ? TILE : 1];
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[W * kBins8];
     __shared__ __attribute__((aligned(16))) uint32_t s_wbase[W * kBins8];
     __shared__ __attribute__((aligned(16))) uint32_t s_gpre[kBins8];
     __shared__ __attribute__((aligned(16))) uint32_t s_gofs[kBins8];
     __shared__ __attribute__((aligned(16))) uint32_t s_tot[kBins8];
     const uint32_t e = params->num_elems;
-    const uint32_t G = (e + kSort8Tile - 1) / kSort8Tile, K = (G + kSegments - 1) / kSegments;
+    const uint32_t G = (e + TILE - 1) / TILE, K = (G + kSegments - 1) / kSegments;
     // Workgroups b, b + 8, ... share an XCD (observed placement, speed only): each of the eight takes a contiguous run of
     // the groups, so that the short digit runs of neighbouring groups -- neighbours in the destination too -- meet in
     // one L2 and leave it as whole lines.
@@ -356,11 +357,11 @@ void k_scatter8(const SortParams* __restrict__ params, const uint32_t* __restric
         if (again) __syncthreads();   // LDS is reused
         again = true;
         const uint32_t seg = grp / K;
-        if (grp * kSort8Tile + kSort8Tile <= e)
-            scatter8_group<LO_IN, LO_OUT, HI16, true>(e, seg, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table, seg_base,
+        if (grp * TILE + TILE <= e)
+            scatter8_group<LO_IN, LO_OUT, HI16, true, R>(e, seg, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table, seg_base,
                                                       totals, shift, mask, s_slot, s_third, s_cnt, s_wbase, s_gpre, s_gofs, s_tot);
         else
-            scatter8_group<LO_IN, LO_OUT, HI16, false>(e, seg, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table, seg_base,
+            scatter8_group<LO_IN, LO_OUT, HI16, false, R>(e, seg, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table, seg_base,
                                                        totals, shift, mask, s_slot, s_third, s_cnt, s_wbase, s_gpre, s_gofs, s_tot);
     }
 }
@@ -369,7 +370,12 @@ int launch_radix_sort8(const SortBuffers& sb, uint32_t capacity, uint32_t num_so
                        hipEvent_t* scatter_events, uint32_t first_bit, bool drop_depth_payload, bool hi16, float share,
                        int start, uint32_t coarse_pass, const SortParams* params) {
     if (!params) params = sb.params;
-    uint32_t max_groups = (capacity + kSort8Tile - 1) / kSort8Tile;
+    // Group size by what the list can be expected to hold (the host never reads the element count back): 2048-key groups for
+    // short lists -- more workgroups, shorter latency chains -- 4096 for long ones (digit runs twice as long).
+    const float bound = (float)capacity * (share < 0.5f ? share : 1.0f);   // a band holds about its share of the capacity
+    const bool small = bound < (float)kSort8SmallBelow;
+    const uint32_t tile = small ? (uint32_t)kSort8TileSmall : (uint32_t)kSort8Tile;
+    uint32_t max_groups = (capacity + tile - 1) / tile;
     if (share < 0.5f) {   // a tile-row band: see launch_radix_sort
         const uint32_t g = (uint32_t)((float)max_groups * 2.0f * share) + 64u;
         max_groups = g < max_groups ? g : max_groups;
@@ -391,17 +397,25 @@ int launch_radix_sort8(const SortBuffers& sb, uint32_t capacity, uint32_t num_so
         uint32_t* totals = sb.coarse + (size_t)(coarse_pass + pass) * kBins * kCoarse;
         const uint32_t sh = lo16 ? shift - 16u : shift & 31u;
 #define GS_LAUNCH_COUNT8(W16, RUNS)                                                                                  \
-        hipLaunchKernelGGL((k_count8<W16, RUNS>), dim3(kSegments), dim3(kC8Threads), 0, stream, params, word, sb.table, \
-                           sb.seg_sum, sh, mask)
-        if (tile_pass) { if (word16) GS_LAUNCH_COUNT8(true, false); else GS_LAUNCH_COUNT8(false, false); }
-        else { if (word16) GS_LAUNCH_COUNT8(true, true); else GS_LAUNCH_COUNT8(false, true); }
+        do { if (small) hipLaunchKernelGGL((k_count8<W16, RUNS, kSort8TileSmall>), dim3(kSegments), dim3(kC8Threads), 0, stream, \
+                                           params, word, sb.table, sb.seg_sum, sh, mask);                            \
+             else hipLaunchKernelGGL((k_count8<W16, RUNS, kSort8Tile>), dim3(kSegments), dim3(kC8Threads), 0, stream,  \
+                                     params, word, sb.table, sb.seg_sum, sh, mask); } while (0)
+        // runs of equal depth digits exist where splats are replicated into tiles: not in the splat list of the
+        // splat-first order (its passes stop at bit 32), not in the tile words
+        const bool runs = !tile_pass && num_sort_bits > 32u;
+        if (runs) { if (word16) GS_LAUNCH_COUNT8(true, true); else GS_LAUNCH_COUNT8(false, true); }
+        else { if (word16) GS_LAUNCH_COUNT8(true, false); else GS_LAUNCH_COUNT8(false, false); }
 #undef GS_LAUNCH_COUNT8
         hipLaunchKernelGGL(k_scan8, dim3(kBins8), dim3(kSegments), 0, stream, sb.seg_sum, seg_base, totals);
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass], stream);
-#define GS_LAUNCH_SCATTER8(LO_IN, LO_OUT, HI16)                                                                        \
-        hipLaunchKernelGGL((k_scatter8<LO_IN, LO_OUT, HI16>), dim3(max_groups), dim3(kSort8Threads), 0, stream, params, \
+#define GS_LAUNCH_SCATTER8_R(LO_IN, LO_OUT, HI16, R)                                                                   \
+        hipLaunchKernelGGL((k_scatter8<LO_IN, LO_OUT, HI16, R>), dim3(max_groups), dim3(kSort8Threads), 0, stream, params, \
                            sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst], sb.table, seg_base,    \
                            totals, shift, mask)
+#define GS_LAUNCH_SCATTER8(LO_IN, LO_OUT, HI16)                                                                        \
+        do { if (small) GS_LAUNCH_SCATTER8_R(LO_IN, LO_OUT, HI16, kSort8KeysSmall);                                   \
+             else GS_LAUNCH_SCATTER8_R(LO_IN, LO_OUT, HI16, kSort8KeysPerThread); } while (0)
 #define GS_LAUNCH_SCATTER8_H(LO_IN, LO_OUT) \
         do { if (hi16) GS_LAUNCH_SCATTER8(LO_IN, LO_OUT, true); else GS_LAUNCH_SCATTER8(LO_IN, LO_OUT, false); } while (0)
         if (lo_in == 4 && lo_out == 4) GS_LAUNCH_SCATTER8_H(4, 4);
@@ -411,6 +425,7 @@ int launch_radix_sort8(const SortBuffers& sb, uint32_t capacity, uint32_t num_so
         else GS_LAUNCH_SCATTER8_H(0, 0);
 #undef GS_LAUNCH_SCATTER8_H
 #undef GS_LAUNCH_SCATTER8
+#undef GS_LAUNCH_SCATTER8_R
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass + 1], stream);
         src = dst;
     }
