@@ -572,8 +572,8 @@ def test_cpp_driver_runs(tmp_path):
     data = open(ppm, "rb").read()
     assert data.startswith(b"P6\n640 360\n255\n") and len(data) == 15 + 640 * 360 * 3
     assert max(data[15:]) > 0
-    # the same frame through the other two sorters (--sort): identical file
-    for sort in ("splat_first", "bucket"):
+    # the same frame through the other sorters (--sort): identical file
+    for sort in ("splat_first", "bucket", "radix8", "radix8_splat_first"):
         other = str(tmp_path / f"frame_{sort}.ppm")
         subprocess.run([exe, "--synthetic", "50000", "--res", "640x360", "--warmup", "3", "--frames", "10", "--sort", sort,
                         "--ppm", other], check=True, capture_output=True, text=True)

@@ -4,7 +4,7 @@
 // Renderer.cpp:477-510 does, and print them.
 //
 //   gsplat_bench <scene.ply | --synthetic N> [--scene garden|train|bicycle|origin] [--res WxH]
-//                [--warmup F] [--frames F] [--fast] [--sort radix4|splat_first|bucket] [--out frame.png|frame.ppm]
+//                [--warmup F] [--frames F] [--fast] [--sort radix4|splat_first|bucket|radix8|radix8_splat_first] [--out frame.png|frame.ppm]
 #include "../include/gsplat.h"
 
 #include <cmath>
@@ -42,7 +42,8 @@ int main(int argc, char** argv) {
 
     gs_config cfg; gs_default_config(&cfg);
     cfg.render_mode = fast ? GS_RENDER_FAST : GS_RENDER_EXACT;
-    cfg.sort_algorithm = sort == "splat_first" ? GS_SORT_RADIX4_SPLAT_FIRST : sort == "bucket" ? GS_SORT_TILE_BUCKET : GS_SORT_RADIX4;
+    cfg.sort_algorithm = sort == "splat_first" ? GS_SORT_RADIX4_SPLAT_FIRST : sort == "bucket" ? GS_SORT_TILE_BUCKET
+                       : sort == "radix8" ? GS_SORT_RADIX8 : sort == "radix8_splat_first" ? GS_SORT_RADIX8_SPLAT_FIRST : GS_SORT_RADIX4;
     cfg.record_timings = 1;                                  // RECORD_GPU_TIMES (GfxSettings.h:7) on: this is the benchmark build
     gs_ctx* ctx = nullptr;
     if (gs_create(&cfg, &ctx) != GS_OK) { fprintf(stderr, "[Log Error]: %s\n", gs_last_error(nullptr)); return 1; }
