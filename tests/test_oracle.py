@@ -100,11 +100,12 @@ def _main_xcheck_inputs(which):
 @pytest.mark.parametrize("which", ["small", "dense"])
 def test_shader_main_bodies_cross_check(oracle_mod, which):
     """CROSS-CHECK, not a pin: tests/golden/ref_main_*.npz is what the main() bodies of the reference's own
-    InitSortList.comp (:82-151), FindRanges.comp (:42-71) and RenderGaussians.comp (:56-152) produce when their text
-    is compiled as C++ over the reference's vendored glm (oracle/ref_main_xcheck.cpp: invocations in ascending order,
-    256 host threads + a barrier per RenderGaussians workgroup) -- the element counter, the list as emitted (tile,
-    depth key, splat, in order), the stored colour and covariance of every splat, the tile ranges out of FindRanges run
-    over the list capacity with its 0xFFFFFFFF tail, and the frame.  The oracle must agree bit for bit: that rules out a
+    InitSortList.comp (:82-151), the six RadixSort/*.comp (dispatched as RadixSort.cpp:207-653 does), FindRanges.comp
+    (:42-71) and RenderGaussians.comp (:56-152) produce when their text is compiled as C++ over the reference's vendored
+    glm (oracle/ref_main_xcheck.cpp: invocations in ascending order; workgroups with barriers as fibers run from barrier
+    to barrier, subgroup operations emulated) -- the element counter, the list as emitted (tile, depth key, splat, in
+    order), the list as the reference's radix shaders sort it, the stored colour and covariance of every splat, the tile
+    ranges out of FindRanges run over the list capacity with its 0xFFFFFFFF tail, and the frame.  The oracle must agree bit for bit: that rules out a
     shared misreading of the cull predicates (:94, :100), the emit loop (:130-150), the range writes (:48-70), the batch
     loop, the zero-determinant rule (:94-107), the two `continue` conditions (:127) and add-then-test transmittance
     (:131-142).  Where the reference is mounted the committed dump is regenerated and compared first."""
