@@ -266,7 +266,7 @@ def main():
         sys.exit(dry_run(args, world, rank))
 
     # roofline.traffic: measured by child runs under rocprofv3 --pmc before this process initialises the GPU
-    pmc = "not measured (--no-pmc)" if args.no_pmc else "not measured (one-GPU runs of the radix4 / splat_first sorters only)"
+    pmc = "not measured (--no-pmc)" if args.no_pmc else "not measured (one-GPU runs of the radix sorters only)"
     if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCP_TOOL_LIBRARIES"):
         pmc = "not measured (this process already runs under rocprofv3)"
     elif world == 1 and not args.no_pmc and not args.rehearse and args.sort != "bucket":
@@ -707,24 +707,28 @@ def main():
             return tot / n_l if n_l else None
 
         moved_launch = moved_full * e_rank
-        traffic = pmc_bytes(tuple(DEPTH_SCATTERS)) if args.sort == "radix4" else None
-        trace_us = pmc_trace_us(tuple(DEPTH_SCATTERS)) if traffic else None
+        wide = args.sort.startswith("radix8")                         # 8-bit digits: k_count8 / k_scan8 / k_scatter8
+        sk, ck = ("k_scatter8", "k_count8") if wide else ("k_scatter", "k_count")
+        depth_scatters = tuple(k.replace("k_scatter", sk) for k in DEPTH_SCATTERS)
+        traffic = pmc_bytes(depth_scatters) if args.sort in ("radix4", "radix8") else None
+        trace_us = pmc_trace_us(depth_scatters) if traffic else None
         basis_bytes = traffic if traffic else moved_launch
         achieved = rate(basis_bytes, scat)
         # the whole sort stage: every Count and Scatter launch of the frame over the RadixSort bucket
         twb = int(info.tile_word_bytes)
-        count_bytes = (4 * min(passes_full, 4) + 2 * max(passes_full - 4, 0) + twb * passes_tile) * e_rank
+        w32 = 2 if wide else 4                                        # passes whose digit lies in the lower depth half-word
+        count_bytes = (4 * min(passes_full, w32) + 2 * max(passes_full - w32, 0) + twb * passes_tile) * e_rank
         stage_moved = count_bytes + (moved_full * passes_full + moved_tile * passes_tile) * e_rank
         stage_traffic = None
-        if isinstance(pmc, dict) and args.sort == "radix4":
-            frames = max(1.0, sum(v["launches"] for k, v in pmc.items() if k.startswith("k_scatter")) / max(passes_full + passes_tile, 1))
+        if isinstance(pmc, dict) and args.sort in ("radix4", "radix8"):
+            frames = max(1.0, sum(v["launches"] for k, v in pmc.items() if k.startswith(sk + "<")) / max(passes_full + passes_tile, 1))
             stage_traffic = sum(v["launches"] * (v["read_bytes"] + v["write_bytes"]) for k, v in pmc.items()
-                                if k.startswith(("k_scatter", "k_count"))) / frames
+                                if k.startswith((sk + "<", ck + "<", "k_scan8"))) / frames
         sort_ms = float(buckets[1])
         stage_bytes = stage_traffic if stage_traffic else stage_moved
         roofline = {
             "bound": "hbm",
-            "kernel": "k_scatter, the depth-word passes (radix Scatter moving key + payload, one launch per 4-bit pass)",
+            "kernel": f"{sk}, the depth-word passes (radix Scatter moving key + payload, one launch per {8 if wide else 4}-bit pass)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "basis": "pmc" if traffic else "moved",
@@ -749,7 +753,7 @@ def main():
                             "frac": round(rate(24.0 * e_rank, scat) / HBM_PEAK_GBPS, 4),
                             "note": "SURVEY 8(d): 12 B read + 12 B written per element and launch; the layout moves fewer, so "
                                     "this can exceed 1 -- not an HBM utilisation"},
-            "stage": {"what": "every Count + Scatter launch of the frame over the RadixSort bucket",
+            "stage": {"what": ("every Count + Scan + Scatter" if wide else "every Count + Scatter") + " launch of the frame over the RadixSort bucket",
                       "ms": round(sort_ms, 4), "moved_bytes": stage_moved,
                       "traffic": round(stage_traffic) if stage_traffic else None,
                       "achieved": round(rate(stage_bytes, sort_ms), 1),
@@ -765,14 +769,14 @@ def main():
             "measured_copy_at_pass_footprint": f"{fp_bytes} bytes per buffer (what one such launch reads), {copy_fp_kind}",
             "guide_copy_GBps": HBM_GUIDE_COPY_GBPS,
         }
-        if args.sort == "splat_first":
+        if args.sort in ("splat_first", "radix8_splat_first"):
             # the depth passes run over the splat list (a quarter of the elements, latency-bound launches): the dominant
             # HBM kernel of the sort is the tile-word pass
             mv = rate(moved_tile * e_rank, scat_tile)
-            tr = pmc_bytes(("k_scatter<0,0,",))
+            tr = pmc_bytes((sk + "<0,0,",))
             ach = rate(tr, scat_tile) if tr else mv
             roofline = {
-                "bound": "hbm", "kernel": "k_scatter<0, 0, .> (tile-word passes of GS_SORT_RADIX4_SPLAT_FIRST)",
+                "bound": "hbm", "kernel": f"{sk}<0, 0, .> (tile-word passes of GS_SORT_RADIX{8 if wide else 4}_SPLAT_FIRST)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                 "basis": "pmc" if tr else "moved", "traffic": round(tr) if tr else None,
                 "avg_launch_ms": round(scat_tile, 5), "launches_per_frame": passes_tile,
@@ -785,9 +789,9 @@ def main():
                                              "bytes_per_splat": moved_full}}
         elif passes_tile:
             mv = rate(moved_tile * e_rank, scat_tile)
-            tr = pmc_bytes(("k_scatter<0,0,",))
+            tr = pmc_bytes((sk + "<0,0,",))
             roofline["tile_word_passes"] = {
-                "kernel": "k_scatter<0, 0, .> (tile-word passes: depth words not carried)",
+                "kernel": f"{sk}<0, 0, .> (tile-word passes: depth words not carried)",
                 "avg_launch_ms": round(scat_tile, 5), "launches_per_frame": passes_tile,
                 "traffic": round(tr) if tr else None,
                 "achieved": round(rate(tr, scat_tile) if tr else mv, 1),
