@@ -327,6 +327,27 @@ def test_radix_sort_matches_stable_sort(n, bits, sorter):
     rs.cleanup()
 
 
+@pytest.mark.parametrize("sorter", [gs.RadixSort, gs.RadixSort8])
+@pytest.mark.parametrize("bits", [36, 44])
+def test_radix_sort_ignores_bits_above_num_sort_bits(sorter, bits):
+    """RadixSort.cpp:203-204, 309: the passes stop at radixSortNumSortBits; tile-word bits above them never take part
+    (the 8-bit variant's last pass covers fewer than eight bits and must mask its digit)."""
+    n = 70_001
+    rng = np.random.default_rng(bits)
+    tile = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)          # garbage above the sorted bits
+    depth = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    depth[::3] = depth[0]
+    ident = np.arange(n, dtype=np.uint32)
+    rs = sorter()
+    rs.initForScene(n, 1 << (bits - 32))
+    assert rs.radixSortNumSortBits == bits
+    t, d, i = rs.computeSort(tile, depth, ident)
+    key = ((tile.astype(np.uint64) << np.uint64(32)) | depth.astype(np.uint64)) & np.uint64((1 << bits) - 1)
+    order = np.argsort(key, kind="stable")
+    assert np.array_equal(i, ident[order]) and np.array_equal(t, tile[order]) and np.array_equal(d, depth[order])
+    rs.cleanup()
+
+
 def test_radix_sort_all_equal_and_presorted():
     rs = gs.RadixSort()
     n = 50_000
