@@ -29,6 +29,11 @@
 
 namespace gs {
 
+// The keys of a pass are read once: non-temporal loads keep them from displacing the partly written destination lines
+// in L2, which neighbouring groups are about to complete (config C's RadixSort 0.590 -> 0.552 ms, config D's 1.59 ->
+// 1.33 with the 4-bit passes; DESIGN.md section 4.1.  Non-temporal STORES, or such loads in Count, cost 10-80 %).
+#define GS_KEY_LOAD(p) __builtin_nontemporal_load(p)
+
 __device__ __forceinline__ uint32_t digit_of(uint32_t word, uint32_t sh) { return (word >> sh) & 15u; }
 
 constexpr int kSortWaves = kSortThreads / 64;
@@ -275,14 +280,14 @@ __device__ __forceinline__ void scatter_group(
 #pragma unroll
         for (int r = 0; r < R; ++r) {   // coalesced: 64 consecutive elements per wave-instruction
             const bool ok = FULL || base + r * 64 < e;
-            if constexpr (HI16) hi[r] = ok ? (uint32_t)hi16[r * 64] : 0xFFFFu;
-            else hi[r] = ok ? hi32[r * 64] : 0xFFFFFFFFu;
-            if constexpr (LO_IN == 4) lo[r] = ok ? lo32[r * 64] : 0xFFFFFFFFu;
-            else if constexpr (LO_IN == 2) lo[r] = ok ? (uint32_t)lo16[r * 64] : 0xFFFFu;
+            if constexpr (HI16) hi[r] = ok ? (uint32_t)GS_KEY_LOAD(&hi16[r * 64]) : 0xFFFFu;
+            else hi[r] = ok ? GS_KEY_LOAD(&hi32[r * 64]) : 0xFFFFFFFFu;
+            if constexpr (LO_IN == 4) lo[r] = ok ? GS_KEY_LOAD(&lo32[r * 64]) : 0xFFFFFFFFu;
+            else if constexpr (LO_IN == 2) lo[r] = ok ? (uint32_t)GS_KEY_LOAD(&lo16[r * 64]) : 0xFFFFu;
             else lo[r] = 0u;
         }
 #pragma unroll
-        for (int r = 0; r < R; ++r) id[r] = (FULL || base + r * 64 < e) ? id32[r * 64] : 0u;
+        for (int r = 0; r < R; ++r) id[r] = (FULL || base + r * 64 < e) ? GS_KEY_LOAD(&id32[r * 64]) : 0u;
     }
 
     // ---- per digit: total over all coarse segments, and over those before this group's (row of 16 lanes = one

@@ -30,6 +30,11 @@
 
 namespace gs {
 
+// The keys of a pass are read once: non-temporal loads keep them from displacing the partly written destination lines
+// in L2, which neighbouring groups are about to complete (config C's RadixSort 0.590 -> 0.552 ms, config D's 1.59 ->
+// 1.33 with the 4-bit passes; DESIGN.md section 4.1.  Non-temporal STORES, or such loads in Count, cost 10-80 %).
+#define GS_KEY_LOAD(p) __builtin_nontemporal_load(p)
+
 #ifndef GS_S8_XCD
 #define GS_S8_XCD 1
 #endif
@@ -210,14 +215,14 @@ __device__ __forceinline__ void scatter8_group(
 #pragma unroll
         for (int r = 0; r < R; ++r) {   // coalesced: 64 consecutive elements per wave-instruction
             const bool ok = FULL || base + r * 64 < e;
-            if constexpr (HI16) hi[r] = ok ? (uint32_t)hi16[r * 64] : 0xFFFFu;
-            else hi[r] = ok ? hi32[r * 64] : 0xFFFFFFFFu;
-            if constexpr (LO_IN == 4) lo[r] = ok ? lo32[r * 64] : 0xFFFFFFFFu;
-            else if constexpr (LO_IN == 2) lo[r] = ok ? (uint32_t)lo16[r * 64] : 0xFFFFu;
+            if constexpr (HI16) hi[r] = ok ? (uint32_t)GS_KEY_LOAD(&hi16[r * 64]) : 0xFFFFu;
+            else hi[r] = ok ? GS_KEY_LOAD(&hi32[r * 64]) : 0xFFFFFFFFu;
+            if constexpr (LO_IN == 4) lo[r] = ok ? GS_KEY_LOAD(&lo32[r * 64]) : 0xFFFFFFFFu;
+            else if constexpr (LO_IN == 2) lo[r] = ok ? (uint32_t)GS_KEY_LOAD(&lo16[r * 64]) : 0xFFFFu;
             else lo[r] = 0u;
         }
 #pragma unroll
-        for (int r = 0; r < R; ++r) id[r] = (FULL || base + r * 64 < e) ? id32[r * 64] : 0u;
+        for (int r = 0; r < R; ++r) id[r] = (FULL || base + r * 64 < e) ? GS_KEY_LOAD(&id32[r * 64]) : 0u;
     }
     // Scan + ScanAdd outputs for this group (L2-resident): keys ahead of the group's first key of digit tid
     uint32_t gpre = 0u, dtot = 0u;
