@@ -12,7 +12,7 @@
 //   from the 48-byte SplatRaster records (screen position, inverse covariance, colour: set up once per splat by
 //   k_project), prefetch one batch ahead of the blend loop, drop while staging the splats that provably touch no
 //   pixel of the rectangle (conservative, unobservable), and use wave votes for the early-outs the reference lacks
-//   (its `done` only zeroes `limit`, :111).  k_tile_order: the order in which the tiles are dispatched.
+//   (its `done` only zeroes `limit`, :111).  k_tile_classes + k_tile_scatter: the order in which the tiles are dispatched.
 // GS_RENDER_EXACT evaluates every expression in the reference's order without contraction and with
 // the pinned exp of oracle/gs_oracle.h => pixels bit-identical to the CPU oracle.
 // GS_RENDER_FAST uses fused multiply-adds and the hardware exp2 (what a GLSL compiler is free to
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
     constexpr int LPR = 64 / ROWS;         // lanes per row
     static_assert(LPR * PX == kTile, "lane layout");
     const int lane = threadIdx.x;
-    const uint32_t tile_in_band = order ? order[blockIdx.x / WPT] : blockIdx.x / WPT;   // longest lists first (k_tile_order)
+    const uint32_t tile_in_band = order ? order[blockIdx.x / WPT] : blockIdx.x / WPT;   // longest lists first (k_tile_classes, k_tile_scatter)
     const uint32_t sub = blockIdx.x % WPT;
     const uint32_t krow = tile_in_band / fp.grid_w;                    // index among this context's tile rows
     const uint32_t ty = fp.first_row + krow * fp.row_stride;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
     __shared__ float4 s_batch[256][3];     // {sx, sy, inv.x, inv.y}, {inv.z, r, g, b}, {a, skip threshold, -, -}; 64 slots per wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile_in_band = order ? order[blockIdx.x] : blockIdx.x;   // longest lists first (k_tile_order)
+    const uint32_t tile_in_band = order ? order[blockIdx.x] : blockIdx.x;   // longest lists first (k_tile_classes, k_tile_scatter)
     const uint32_t krow = tile_in_band / fp.grid_w;                    // index among this context's tile rows
     const uint32_t ty = fp.first_row + krow * fp.row_stride;
     const uint32_t tx = tile_in_band % fp.grid_w;
