@@ -822,6 +822,8 @@ def main():
                 ["init_sort_list", "radix_sort", "find_ranges", "render", "total"], allstats[0][2:7].tolist())},
             "buckets_note": "rank 0, hipEvents at the reference's 7 timestamp points (Renderer.cpp:557-622), mean of "
                             f"{k_inst} frames with a host wait per frame",
+            # M sort elements per second = E / radix_ms / 1000 (rank 0's elements over rank 0's bucket)
+            "sort_melems_per_s": round(e_rank / float(allstats[0][3]) / 1000.0, 1) if float(allstats[0][3]) > 0 else None,
             "frame_wall_ms_with_host_wait": round(wall_wait, 4),
             "host_ms": host_t,
             "frame_slots_identical": slots_ok,
