@@ -210,9 +210,6 @@ __global__ __launch_bounds__(kCountThreads) void k_count(const SortParams* __res
 //              consecutive global indices (RadixSortScatter.comp:153-168): run-wise coalesced stores
 // The group count (not the list capacity) bounds the work: surplus workgroups leave at once.
 // ---------------------------------------------------------------------------------------------
-#ifndef GS_SCATTER_XCD
-#define GS_SCATTER_XCD 1
-#endif
 #ifndef GS_SCATTER_MINWAVES_KEY
 #define GS_SCATTER_MINWAVES_KEY 5    // resident workgroups per CU asked of the compiler: passes that carry 12 or more bytes
 #endif
@@ -405,7 +402,6 @@ void k_scatter(const SortParams* __restrict__ params, const uint32_t* __restrict
     const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
     // one group per workgroup as a rule: the grid is sized from an upper estimate of the element count (the list
     // capacity scaled to the context's share of the tiles) and walks on only if a frame exceeds it
-#if GS_SCATTER_XCD
     // Workgroups b, b + 8, ... share an XCD (observed placement, speed only): each of the eight takes a contiguous run of
     // the groups, so that the digit runs of neighbouring groups -- neighbours in the destination too -- meet in one L2.
     const uint32_t per_xcd = (G + 7u) / 8u;
@@ -413,10 +409,6 @@ void k_scatter(const SortParams* __restrict__ params, const uint32_t* __restrict
     for (uint32_t vb = blockIdx.x; vb < 8u * per_xcd; vb += gridDim.x) {
         const uint32_t grp = (vb & 7u) * per_xcd + (vb >> 3);
         if (grp >= G) continue;
-#else
-    bool again = false;
-    for (uint32_t grp = blockIdx.x; grp < G; grp += gridDim.x) {
-#endif
         if (again) __syncthreads();   // LDS is reused
         again = true;
         if (grp * kSortTile + kSortTile <= e)

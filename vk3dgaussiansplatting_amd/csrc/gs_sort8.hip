@@ -35,9 +35,6 @@ namespace gs {
 // 1.33 with the 4-bit passes; DESIGN.md section 4.1.  Non-temporal STORES, or such loads in Count, cost 10-80 %).
 #define GS_KEY_LOAD(p) __builtin_nontemporal_load(p)
 
-#ifndef GS_S8_XCD
-#define GS_S8_XCD 1
-#endif
 constexpr int kC8Chunk = 2048;                          // keys a Count wave takes per step
 constexpr int kC8Waves = 8;
 constexpr int kC8Threads = kC8Waves * 64;
@@ -349,16 +346,11 @@ void k_scatter8(const SortParams* __restrict__ params, const uint32_t* __restric
     // Workgroups b, b + 8, ... share an XCD (observed placement, speed only): each of the eight takes a contiguous run of
     // the groups, so that the short digit runs of neighbouring groups -- neighbours in the destination too -- meet in
     // one L2 and leave it as whole lines.
-#if GS_S8_XCD
     const uint32_t per_xcd = (G + 7u) / 8u;
     bool again = false;
     for (uint32_t vb = blockIdx.x; vb < 8u * per_xcd; vb += gridDim.x) {
         const uint32_t grp = (vb & 7u) * per_xcd + (vb >> 3);
         if (grp >= G) continue;
-#else
-    bool again = false;
-    for (uint32_t grp = blockIdx.x; grp < G; grp += gridDim.x) {
-#endif
         if (again) __syncthreads();   // LDS is reused
         again = true;
         const uint32_t seg = grp / K;
