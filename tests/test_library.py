@@ -155,6 +155,35 @@ def test_ply_conversion(tmp_path, fmt):
     assert np.allclose(got[:, ~exact], want[:, ~exact], rtol=2e-7, atol=0)
 
 
+@pytest.mark.parametrize("which", ["mixed", "oneside"])
+def test_ply_loader_cross_check(tmp_path, which):
+    """CROSS-CHECK of the conversions of ResourceManager::loadGaussians (ResourceManager.cpp:167-300): tests/golden/ref_ply.npz
+    holds what the reference's own function -- its text over its vendored happly containers, glm, SMath and
+    ShaderStructs (oracle/ref_ply_xcheck.cpp) -- makes of two property tables: sign flips, exp of the scales, the
+    normalised and permuted quaternion, sigmoid opacity, f_rest regrouping, and the Morton order (`oneside`: with the
+    `maxPos = numeric_limits<float>::min()` start value in two axes).  gs_convert_ply on the same table written as a
+    .ply must give the same records in the same order, bit for bit.  Where the reference is mounted the committed dump
+    is regenerated and compared first."""
+    from conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_ply.npz"))
+    table, want = g[f"table_{which}"], g[f"records_{which}"]
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_ply_xcheck")
+    if os.path.isdir("/root/reference/vkGaussianSplatting") and os.path.exists(exe):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("make_ply_xcheck", os.path.join(ROOT, "tests", "golden", "make_ply_xcheck.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        assert mod.run(table).tobytes() == want.tobytes()
+        assert mod.tables()[which].tobytes() == table.tobytes() and list(mod.PROPS) == list(PLY_PROPS)
+    path = str(tmp_path / "cloud.ply")
+    _write_ply(path, table)
+    rm = gs.ResourceManager()
+    rm.loadGaussians(path)
+    got = rm.getGaussians()
+    assert got.shape == want.shape
+    assert got.view(np.uint32).tobytes() == want.view(np.uint32).tobytes()
+
+
 def test_ply_streaming_conversion_many_rows_and_partial_output(tmp_path):
     """The two-sweep converter (positions -> Morton order, then every row straight into its slot) on a file of several
     read chunks (70 k rows x 248 B = 17 MB; the chunk is 16 MB) with many equal Morton codes (positions on a coarse
