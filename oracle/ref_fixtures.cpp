@@ -5,10 +5,14 @@
 // GPU box, where only the committed JSON fixtures are used.
 //
 // What it pins (the only parts of the path that are host C++ compilable without Vulkan/Win32):
-//   * camera matrices: glm::lookAt / glm::perspective / glm::normalize / glm::cross with the
-//     project's defines GLM_FORCE_RADIANS; GLM_FORCE_DEPTH_ZERO_TO_ONE; GLM_FORCE_QUAT_DATA_WXYZ
-//     (vkGaussianSplatting.vcxproj:50), called the way Engine/Graphics/Camera.cpp:7-48 calls them
-//     (Camera.cpp itself needs Window/GLFW/pch.h and cannot be compiled here);
+//   * camera matrices: Camera::updateDirVectors / updateMatrices / recalculate -- the text of
+//     Engine/Graphics/Camera.cpp:4-54, cut into a temporary directory by the Makefile (Camera.cpp as a file needs
+//     pch.h / Window / GLFW) -- over glm::lookAt / perspective / normalize / cross with the project's defines
+//     GLM_FORCE_RADIANS; GLM_FORCE_DEPTH_ZERO_TO_ONE; GLM_FORCE_QUAT_DATA_WXYZ (vkGaussianSplatting.vcxproj:50).
+//     Glue: a class Camera with the members Camera.h:14-37 declares and a Window that answers getFramebufferSize /
+//     getAspectRatio.  `sin(this->yaw)` on a float picks sinf under MSVC (its <cmath> puts the float overloads into
+//     the global namespace) and may pick sin(double) elsewhere: the text is compiled both ways and the program fails
+//     if the two disagree on any fixture pose;
 //   * Morton codes: SMath::encodeZorderCurve (Engine/SMath.h:24-34).
 #define GLM_FORCE_RADIANS
 #define GLM_FORCE_DEPTH_ZERO_TO_ONE
@@ -19,6 +23,37 @@
 #include <cstdio>
 #include <cstring>
 #include <SMath.h>  // -I /root/reference/vkGaussianSplatting/Engine, pulls <glm/glm.hpp>
+
+struct Window {
+    float aspect;
+    void getFramebufferSize(int& w, int& h) const { w = 1600; h = 900; }
+    float getAspectRatio() const { return aspect; }
+};
+enum class SphericalHarmonicsMode { ALL_BANDS };
+#define GS_REF_CAMERA_CLASS                                                                                           \
+    class Camera {                                                                                                    \
+    public:                                                                                                           \
+        glm::mat4 projectionMatrix, viewMatrix;                                                                       \
+        glm::vec3 position, forwardDir, rightDir, upDir;                                                              \
+        float yaw, pitch;                                                                                             \
+        SphericalHarmonicsMode shMode;                                                                                \
+        const Window* window;                                                                                         \
+        void updateDirVectors();                                                                                      \
+        void updateMatrices();                                                                                        \
+        void recalculate();                                                                                           \
+        const static float NEAR_PLANE;                                                                                \
+        const static float FAR_PLANE;                                                                                 \
+    };
+namespace cam_as_compiled_here {   // unqualified sin / cos as this compiler resolves them
+GS_REF_CAMERA_CLASS
+#include "camera_cpp_4_54.inc"
+}
+namespace cam_float_overloads {    // ... and with the float overloads in scope, as under MSVC
+using std::sin;
+using std::cos;
+GS_REF_CAMERA_CLASS
+#include "camera_cpp_4_54.inc"
+}
 
 static uint32_t bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
@@ -46,15 +81,18 @@ int main() {
     const int ncam = sizeof(cams) / sizeof(cams[0]);
     for (int c = 0; c < ncam; ++c) {
         const Cam& k = cams[c];
-        glm::vec3 position(k.px, k.py, k.pz);
-        // Camera.cpp:10-16
-        glm::vec3 forwardDir((float)(sin((double)k.yaw) * cos((double)k.pitch)),
-                             (float)sin((double)k.pitch),
-                             (float)(cos((double)k.yaw) * cos((double)k.pitch)));
-        forwardDir = glm::normalize(forwardDir);
-        // Camera.cpp:34-46
-        glm::mat4 view = glm::lookAt(position, position + forwardDir, glm::vec3(0.0f, 1.0f, 0.0f));
-        glm::mat4 proj = glm::perspective(glm::radians(90.0f), k.aspect, 0.1f, 100.0f);
+        const Window window{k.aspect};
+        cam_as_compiled_here::Camera cam;
+        cam.window = &window; cam.position = glm::vec3(k.px, k.py, k.pz); cam.yaw = k.yaw; cam.pitch = k.pitch;
+        cam.recalculate();                                            // Camera.cpp:7-54
+        cam_float_overloads::Camera camf;
+        camf.window = &window; camf.position = cam.position; camf.yaw = k.yaw; camf.pitch = k.pitch;
+        camf.recalculate();
+        if (std::memcmp(&cam.viewMatrix, &camf.viewMatrix, 64) != 0 || std::memcmp(&cam.projectionMatrix, &camf.projectionMatrix, 64) != 0) {
+            std::fprintf(stderr, "Camera.cpp: sin/cos overload resolution changes the matrices of pose %s\n", k.name);
+            return 3;
+        }
+        const glm::mat4 view = cam.viewMatrix, proj = cam.projectionMatrix;
         std::printf("  {\"name\": \"%s\", \"pos\": [%u, %u, %u], \"yaw\": %u, \"pitch\": %u, \"aspect\": %u,\n",
                     k.name, bits(k.px), bits(k.py), bits(k.pz), bits(k.yaw), bits(k.pitch), bits(k.aspect));
         std::printf("   \"view\": [");

@@ -152,7 +152,8 @@ def test_shader_main_bodies_cross_check(oracle_mod, which):
 
 
 def test_camera_matrices_match_reference_glm(oracle_mod, ref_golden):
-    """view/proj bit-identical to glm::lookAt / glm::perspective run from /root/reference (Camera.cpp:7-48)."""
+    """view/proj bit-identical to the reference's own Camera::recalculate (the text of Camera.cpp:4-54 over its glm,
+    oracle/ref_fixtures.cpp) for its scene poses."""
     for cam in ref_golden["cameras"]:
         pos = _f32(cam["pos"])
         yaw, pitch, aspect = (float(_f32([cam[k]])[0]) for k in ("yaw", "pitch", "aspect"))
