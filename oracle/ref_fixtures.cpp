@@ -13,7 +13,11 @@
 //     getAspectRatio.  `sin(this->yaw)` on a float picks sinf under MSVC (its <cmath> puts the float overloads into
 //     the global namespace) and may pick sin(double) elsewhere: the text is compiled both ways and the program fails
 //     if the two disagree on any fixture pose;
-//   * Morton codes: SMath::encodeZorderCurve (Engine/SMath.h:24-34).
+//   * Morton codes: SMath::encodeZorderCurve (Engine/SMath.h:24-34);
+//   * the host formulas that size the path: Renderer::getNumTiles / getCeilPowTwo (the text of Renderer.cpp:696-710)
+//     and RadixSort::getMinNumBits (RadixSort.cpp:4-13), cut the same way, on classes that hold what they read
+//     (swapchain extent, TILE_SIZE = 16 as Renderer.h:146); combined as Renderer.cpp:725 (list capacity) and
+//     RadixSort.cpp:203-204 (sort bits) combine them.
 #define GLM_FORCE_RADIANS
 #define GLM_FORCE_DEPTH_ZERO_TO_ONE
 #define GLM_FORCE_QUAT_DATA_WXYZ
@@ -54,6 +58,22 @@ using std::cos;
 GS_REF_CAMERA_CLASS
 #include "camera_cpp_4_54.inc"
 }
+
+struct VkExtent2D { uint32_t width, height; };
+struct Swapchain { VkExtent2D extent; const VkExtent2D& getVkExtent() const { return extent; } };
+class Renderer {
+public:
+    static const uint32_t TILE_SIZE = 16;      // Renderer.h:146
+    Swapchain swapchain;
+    uint32_t getNumTiles() const;
+    uint32_t getCeilPowTwo(uint32_t x) const;
+};
+#include "renderer_cpp_696_710.inc"
+class RadixSort {
+public:
+    uint32_t getMinNumBits(uint32_t x) const;
+};
+#include "radixsort_cpp_4_13.inc"
 
 static uint32_t bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
@@ -110,6 +130,23 @@ int main() {
         uint32_t code = SMath::encodeZorderCurve(glm::uvec3(x, y, z));
         std::printf("  [%u, %u, %u, %u]%s\n", x, y, z, code, i + 1 < nm ? "," : "");
     }
+    std::printf(" ],\n \"sizes\": [\n");
+    // resolutions of the README tables and of the BASELINE configs, splat counts of its scenes and of the configs
+    const uint32_t res[][2] = {{640, 360}, {1280, 720}, {1600, 900}, {1920, 1080}, {3840, 2160}, {200, 120}, {1, 1}, {17, 33}};
+    const uint32_t counts[] = {1u, 600u, 100000u, 559263u, 1026508u, 4386142u, 5834784u, 50000000u};
+    const int nres = sizeof(res) / sizeof(res[0]), ncnt = sizeof(counts) / sizeof(counts[0]);
+    for (int r = 0; r < nres; ++r)
+        for (int c = 0; c < ncnt; ++c) {
+            Renderer renderer;
+            renderer.swapchain.extent = VkExtent2D{res[r][0], res[r][1]};
+            const uint32_t tiles = renderer.getNumTiles();
+            const uint32_t capacity = renderer.getCeilPowTwo(counts[c] + 64 * 16 * tiles);              // Renderer.cpp:725
+            const RadixSort sorter{};
+            const uint32_t sort_bits = 32 + sorter.getMinNumBits(tiles - 1);                              // RadixSort.cpp:203
+            const uint32_t num_sort_bits = uint32_t((sort_bits + 4 - 1) / 4) * 4;                        // RadixSort.cpp:204
+            std::printf("  [%u, %u, %u, %u, %u, %u]%s\n", res[r][0], res[r][1], counts[c], tiles, capacity, num_sort_bits,
+                        r + 1 < nres || c + 1 < ncnt ? "," : "");
+        }
     std::printf(" ]\n}\n");
     return 0;
 }

@@ -162,6 +162,22 @@ def test_camera_matrices_match_reference_glm(oracle_mod, ref_golden):
         assert np.array_equal(proj.view(np.uint32), np.array(cam["proj"], np.uint32)), cam["name"]
 
 
+def test_host_sizes_match_reference(oracle_mod, ref_golden):
+    """Tile count, list capacity and sort bits out of the reference's own Renderer::getNumTiles / getCeilPowTwo
+    (Renderer.cpp:696-710, combined as :725) and RadixSort::getMinNumBits (RadixSort.cpp:4-13, combined as :203-204),
+    for the README's resolutions and scene sizes, the BASELINE configs and a few odd grids."""
+    import vk3dgaussiansplatting_amd as gs
+    assert len(ref_golden["sizes"]) == 64
+    for w, h, n, tiles, capacity, bits in ref_golden["sizes"]:
+        gw, gh = oracle_mod.grid(w, h)
+        assert gw * gh == tiles
+        assert oracle_mod.capacity(n, tiles) == capacity
+        assert oracle_mod.num_sort_bits(tiles) == bits
+        rs = gs.RadixSort.__new__(gs.RadixSort)                  # the mirror's formula alone: no context, no GPU
+        rs.initForScene(capacity, tiles)
+        assert rs.radixSortNumSortBits == bits
+
+
 def test_morton_matches_reference_smath(oracle_mod, ref_golden):
     for x, y, z, code in ref_golden["morton"]:
         assert oracle_mod.morton(x, y, z) == code

@@ -327,6 +327,22 @@ def test_radix_sort_matches_stable_sort(n, bits, sorter):
     rs.cleanup()
 
 
+def test_scene_sizes_match_reference_formulas():
+    """gs_set_resolution sizes the list and the sort as the reference's own Renderer::getNumTiles / getCeilPowTwo
+    (Renderer.cpp:696-710, :725) and RadixSort::getMinNumBits (RadixSort.cpp:4-13, :203-204) do: the rows of
+    tests/golden/ref_glm_smath.json ("sizes", out of the reference's text) with up to 100,000 splats."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_glm_smath.json")))
+    clouds = {n: synth.generate(n, 640, 360, -3.0, seed=5) for n in (1, 600, 100_000)}
+    rows = [r for r in g["sizes"] if r[2] in clouds]
+    assert len(rows) == 24
+    for w, h, n, tiles, capacity, bits in rows:
+        r = make_renderer(make_scene(clouds[n], w, h), w, h)
+        info = r.sceneInfo()
+        assert (info.capacity, info.num_sort_bits) == (capacity, bits), (w, h, n)
+        r.cleanup()
+
+
 @pytest.mark.parametrize("sorter", [gs.RadixSort, gs.RadixSort8])
 @pytest.mark.parametrize("bits", [36, 44])
 def test_radix_sort_ignores_bits_above_num_sort_bits(sorter, bits):
