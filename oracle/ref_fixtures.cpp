@@ -17,7 +17,13 @@
 //   * the host formulas that size the path: Renderer::getNumTiles / getCeilPowTwo (the text of Renderer.cpp:696-710)
 //     and RadixSort::getMinNumBits (RadixSort.cpp:4-13), cut the same way, on classes that hold what they read
 //     (swapchain extent, TILE_SIZE = 16 as Renderer.h:146); combined as Renderer.cpp:725 (list capacity) and
-//     RadixSort.cpp:203-204 (sort bits) combine them.
+//     RadixSort.cpp:203-204 (sort bits) combine them;
+//   * the reference's two synthetic scenes: TestSortScene::init (Scenes/TestSortScene.cpp:6-35) and
+//     SimpleTestGaussiansScene::init (Scenes/SimpleTestGaussiansScene.cpp:5-30), their text on scene classes whose
+//     camera records setPosition / setRotation and whose resource manager collects addGaussian; GaussianData{} with
+//     its default initialisers comes from the reference's ShaderStructs.h, SMath::PI from the text of SMath.cpp:4-11
+//     (3.141592f, not the float nearest to pi); rand() is MSVC's (seed 1: the reference never calls srand), which
+//     only colours depend on.
 #define GLM_FORCE_RADIANS
 #define GLM_FORCE_DEPTH_ZERO_TO_ONE
 #define GLM_FORCE_QUAT_DATA_WXYZ
@@ -26,6 +32,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 #include <SMath.h>  // -I /root/reference/vkGaussianSplatting/Engine, pulls <glm/glm.hpp>
 
 struct Window {
@@ -75,6 +82,37 @@ public:
 };
 #include "radixsort_cpp_4_13.inc"
 
+#include <Graphics/ShaderStructs.h>   // GaussianData with its default member initialisers
+#include "smath_cpp_4_11.inc"        // const float SMath::PI, SMath::roundToThreeDecimals
+namespace scenes {
+using Camera = cam_as_compiled_here::Camera;     // Camera::NEAR_PLANE / FAR_PLANE of Camera.cpp:4-5
+static uint32_t msvc_rand_state = 1u;
+static int rand() { msvc_rand_state = msvc_rand_state * 214013u + 2531011u; return (int)((msvc_rand_state >> 16) & 0x7fffu); }
+struct SceneCamera {
+    glm::vec3 position; float yaw = 0.0f, pitch = 0.0f;
+    void init(const Window&) {}
+    void setPosition(const glm::vec3& p) { position = p; }
+    void setRotation(float y, float p) { yaw = y; pitch = p; }
+    void update() {}
+};
+struct SceneResources {
+    std::vector<GaussianData> gaussians;
+    uint32_t addGaussian(const GaussianData& g) { gaussians.push_back(g); return (uint32_t)gaussians.size() - 1u; }
+};
+#define GS_REF_SCENE_CLASS(NAME)                                                                                      \
+    class NAME {                                                                                                      \
+    public:                                                                                                           \
+        SceneCamera camera; SceneResources resources; Window window{16.0f / 9.0f};                                    \
+        const Window& getWindow() const { return window; }                                                            \
+        SceneResources& getResourceManager() { return resources; }                                                    \
+        void init();                                                                                                  \
+    };
+GS_REF_SCENE_CLASS(TestSortScene)
+#include "testsortscene_cpp_6_35.inc"
+GS_REF_SCENE_CLASS(SimpleTestGaussiansScene)
+#include "simplescene_cpp_5_30.inc"
+}
+
 static uint32_t bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
 static uint64_t sm_state = 0x1234567ull;
@@ -90,11 +128,12 @@ int main() {
     // Scene poses: GardenScene.cpp:11-12, TrainScene.cpp:11-12, BicycleScene.cpp:11-12,
     // TestSortScene.cpp:11-12, SimpleTestGaussiansScene.cpp:11-12; aspects 16:9 and 4:3.
     const Cam cams[] = {
-        {"garden", -0.620010f, 0.189628f, 2.271181f, 2.971590f, -1.074159f, 1920.0f / 1080.0f},
-        {"train", -2.857887f, 0.188856f, 1.048745f, 1.361593f, 0.005841f, 1280.0f / 720.0f},
-        {"bicycle", 0.945927f, -0.294418f, -0.181088f, -1.108407f, -0.324159f, 1600.0f / 900.0f},
+        // the scene files write these as double literals (the Makefile checks the text): converted as the calls convert them
+        {"garden", (float)-0.620010, (float)0.189628, (float)2.271181, (float)2.971590, (float)-1.074159, 1920.0f / 1080.0f},
+        {"train", (float)-2.857887, (float)0.188856, (float)1.048745, (float)1.361593, (float)0.005841, 1280.0f / 720.0f},
+        {"bicycle", (float)0.945927, (float)-0.294418, (float)-0.181088, (float)-1.108407, (float)-0.324159, 1600.0f / 900.0f},
         {"testsort", 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1280.0f / 720.0f},
-        {"simple", 0.0f, 0.0f, 2.0f, 3.14159265358979323846f, 0.0f, 640.0f / 360.0f},
+        {"simple", 0.0f, 0.0f, 2.0f, SMath::PI, 0.0f, 640.0f / 360.0f},     // SimpleTestGaussiansScene.cpp:11-12
         {"fourthirds", 1.5f, -2.25f, 0.75f, 0.7f, 0.3f, 128.0f / 96.0f},
     };
     std::printf("{\n \"cameras\": [\n");
@@ -147,6 +186,33 @@ int main() {
             std::printf("  [%u, %u, %u, %u, %u, %u]%s\n", res[r][0], res[r][1], counts[c], tiles, capacity, num_sort_bits,
                         r + 1 < nres || c + 1 < ncnt ? "," : "");
         }
-    std::printf(" ]\n}\n");
+    std::printf(" ],\n \"scenes\": {\n");
+    // pose [pos xyz, yaw, pitch] and, per gaussian, position xyz, scale xyzw, rot xyzw, shCoeffs[0] xyzw as float bits;
+    // everything else of the 336-byte record must be zero
+    auto dump = [](const char* name, const scenes::SceneCamera& cam, const std::vector<GaussianData>& gs, bool last) -> bool {
+        std::printf("  \"%s\": {\"pose\": [%u, %u, %u, %u, %u], \"gaussians\": [\n", name, bits(cam.position.x), bits(cam.position.y),
+                    bits(cam.position.z), bits(cam.yaw), bits(cam.pitch));
+        for (size_t i = 0; i < gs.size(); ++i) {
+            const float* f = reinterpret_cast<const float*>(&gs[i]);
+            static_assert(sizeof(GaussianData) == 336, "the reference's record");
+            for (int k = 16; k < 84; ++k) if (bits(f[k]) != 0u) return false;
+            if (bits(f[3]) != 0u) return false;
+            std::printf("   [");
+            const int idx[15] = {0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+            for (int k = 0; k < 15; ++k) std::printf("%u%s", bits(f[idx[k]]), k < 14 ? ", " : "");
+            std::printf("]%s\n", i + 1 < gs.size() ? "," : "");
+        }
+        std::printf("  ]}%s\n", last ? "" : ",");
+        return true;
+    };
+    {
+        scenes::msvc_rand_state = 1u;
+        scenes::TestSortScene a; a.init();
+        if (!dump("TestSortScene", a.camera, a.resources.gaussians, false)) return 4;
+        scenes::msvc_rand_state = 1u;
+        scenes::SimpleTestGaussiansScene b; b.init();
+        if (!dump("SimpleTestGaussiansScene", b.camera, b.resources.gaussians, true)) return 4;
+    }
+    std::printf(" }\n}\n");
     return 0;
 }

@@ -232,8 +232,9 @@ def test_scene_presets_follow_reference():
     assert np.array_equal(g[:, 0], -8.0 + np.arange(16, dtype=np.float32))   # SimpleTestGaussiansScene.cpp:20
     assert np.all(g[:, 2] == -1.0) and np.allclose(g[0, 4:8], [0.1, 0.2, 0.5, 0.0])
     assert np.array_equal(g[0, 8:12], [0, 0, 0, 1])                            # GaussianData default rot
-    # MSVC rand() seed 1: 41, 18467, 6334 -> /10000
-    assert np.allclose(g[0, 12:15], [0.0041, 0.8467, 0.6334])
+    # MSVC rand() seed 1: 41, 18467, 6334 -> /10000; the vec4's arguments are evaluated right to left (renderer._rand_colour)
+    assert np.allclose(g[0, 12:15], [0.6334, 0.8467, 0.0041])
+    assert sc.getCamera().getYaw() == float(np.float32(3.141592))                  # SMath::PI, SMath.cpp:4
     r = gs.Renderer(1920, 1080)
     assert r.getNumTiles() == 120 * 68 and r.getCeilPowTwo(5_834_784 + 1024 * 8160) == 2**24
     rs_bits = gs.RadixSort.getMinNumBits(8160 - 1)

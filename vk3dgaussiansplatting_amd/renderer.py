@@ -53,7 +53,7 @@ class Camera:
 
     def __init__(self, aspect_ratio: float = 1280.0 / 720.0):
         self.position = np.array([0.0, 0.0, 2.0], dtype=np.float32)   # Camera.cpp:61
-        self.yaw = float(np.float32(math.pi))                         # Camera.cpp:66
+        self.yaw = SMATH_PI                                           # Camera.cpp:66
         self.pitch = 0.0
         self.shMode = SphericalHarmonicsMode.ALL_BANDS
         self.aspectRatio = float(aspect_ratio)
@@ -94,6 +94,12 @@ class Camera:
 
     def getPosition(self):
         return self.position
+
+    def getYaw(self):                      # Camera.h:52-53
+        return self.yaw
+
+    def getPitch(self):
+        return self.pitch
 
     def getShMode(self):
         return self.shMode
@@ -170,11 +176,22 @@ class Scene:
         return self.resourceManager
 
 
+SMATH_PI = float(np.float32(3.141592))     # SMath.cpp:4 -- not the float nearest to pi
+
+
 def _msvc_rand(seed=1):
     state = seed
     while True:
         state = (state * 214013 + 2531011) & 0xFFFFFFFF
         yield (state >> 16) & 0x7FFF
+
+
+def _rand_colour(rnd):
+    """glm::vec4((rand() % 10000) / 10000.0f, ..., ..., 1.0f): the order in which the three arguments are evaluated is
+    unspecified in C++; g++ (the cross-check of tests/golden/ref_glm_smath.json) and MSVC x64 go right to left, so the
+    first draw lands in blue."""
+    b, g, r = (np.float32((next(rnd) % 10000) / np.float32(10000.0)) for _ in range(3))
+    return (r, g, b, 1.0)
 
 
 class TestSortScene(Scene):
@@ -192,8 +209,7 @@ class TestSortScene(Scene):
             keyDepth = np.uint32((i + 1) * 1024)
             zOffset = (np.float32(keyDepth) / np.float32(4294967295)) * (far - near) + near
             pos = (np.float32((np.float32(-8.0) + np.float32(i)) * np.float32(0.01)), 0.0, zOffset)
-            sh0 = tuple(np.float32((next(rnd) % 10000) / np.float32(10000.0)) for _ in range(3)) + (1.0,)
-            self.resourceManager.addGaussian(makeGaussian(pos, (0.02, 0.02, 0.02, 0.02), sh0=sh0))
+            self.resourceManager.addGaussian(makeGaussian(pos, (0.02, 0.02, 0.02, 0.02), sh0=_rand_colour(rnd)))
 
 
 class SimpleTestGaussiansScene(Scene):
@@ -201,13 +217,12 @@ class SimpleTestGaussiansScene(Scene):
 
     def init(self):
         self.camera.setPosition((0.0, 0.0, 2.0))
-        self.camera.setRotation(float(np.float32(math.pi)), 0.0)
+        self.camera.setRotation(SMATH_PI, 0.0)
         self.camera.recalculate()
         rnd = _msvc_rand()
         for i in range(16):
-            sh0 = tuple(np.float32((next(rnd) % 10000) / np.float32(10000.0)) for _ in range(3)) + (1.0,)
             self.resourceManager.addGaussian(
-                makeGaussian((-8.0 + float(i), 0.0, -1.0), (0.1, 0.2, 0.5, 0.0), sh0=sh0))
+                makeGaussian((-8.0 + float(i), 0.0, -1.0), (0.1, 0.2, 0.5, 0.0), sh0=_rand_colour(rnd)))
 
 
 class PlyScene(Scene):
