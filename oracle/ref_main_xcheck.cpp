@@ -431,7 +431,7 @@ int main(int argc, char** argv) {
         listBuffer.sortData = sorted.data();
         rangesBuffer.rangeData = ranges.data();
         ubo.viewMat = viewMat; ubo.projMat = projMat;
-        pc.resolution = uvec4(width, height, 0u, 0u);
+        pc.resolution = uvec4(width, height, n, 0u);            // Subrenderer.cpp:317-323
         swapchainImage = Image{image.data(), width, height};
         for (uint32_t ty = 0; ty < grid_h; ++ty)
             for (uint32_t tx = 0; tx < grid_w; ++tx)
