@@ -34,6 +34,7 @@ if [ "${1:-}" = "--install" ]; then
     [ -s $s8/passes_radix4.txt ] && cp $s8/passes_radix4.txt profiles/${r}_bench_configC_passes.txt
     [ -s $s8/sorters.txt ] && cp $s8/sorters.txt profiles/${r}_sorters_by_config.txt
     [ -s $s8/lds_probe.txt ] && cp $s8/lds_probe.txt profiles/${r}_lds_probe.txt
+    [ -s $s8/pmc_frame_radix8.txt ] && cp $s8/pmc_frame_radix8.txt profiles/${r}_pmc_frame_traffic_configC_radix8.txt
   fi
   ls -la profiles | tail -40
   exit 0
@@ -62,6 +63,7 @@ if [ "${1:-}" = "--radix8" ]; then
     timeout -k 10 250 python tools/band_cost.py $c $k > $out/band_${c}_$k.txt 2>&1 || echo "FAIL band $c $k"
   done; done
   timeout -k 10 120 python tools/lds_probe.py > $out/lds_probe.txt 2>&1 || echo "FAIL lds probe"
+  EXTRA_ARGS="--no-pmc --sort radix8" tools/pmc_frame.sh > $out/pmc_frame_radix8.txt 2>&1 || echo "FAIL pmc frame radix8"
   cat $out/passes_radix8.txt; cut -c1-230 $out/sorters.txt
   exit 0
 fi
