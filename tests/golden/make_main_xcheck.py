@@ -7,6 +7,9 @@ vendored glm by oracle/ref_main_xcheck.cpp, authoring container only -- produce 
           half-filled last row and column), so that pixels saturate, the `nextT < 0.0001` break and the alpha / f
           `continue`s all fire, and tile lists run over several 256-entry batches
 
+  configA : BASELINE config A at full size -- 100,000 splats @ 640 x 360, E = 246,569, 3,853 Count workgroups, eleven
+          passes of the reference's radix shaders (ref_main_configA.npz; the records come from synth, hash asserted)
+
 A CROSS-CHECK of the restatements against the shader text, not a pin of GLSL arithmetic (header of
 oracle/ref_main_xcheck.cpp).
 
@@ -25,7 +28,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 EXE = os.path.join(ROOT, "oracle", "_ref", "ref_main_xcheck")
 
 
-def run(aos, view, proj, cam_pos, w, h, sh_mode):
+def run(aos, view, proj, cam_pos, w, h, sh_mode, exe=None):
     n = aos.shape[0]
     tiles = ((w + 15) // 16) * ((h + 15) // 16)
     with tempfile.TemporaryDirectory() as d:
@@ -34,7 +37,7 @@ def run(aos, view, proj, cam_pos, w, h, sh_mode):
             f.write(struct.pack("<4I", n, w, h, sh_mode))
             f.write(np.asarray(view, "<f4").tobytes() + np.asarray(proj, "<f4").tobytes() + np.asarray(cam_pos, "<f4").tobytes())
             f.write(np.ascontiguousarray(aos, "<f4").tobytes())
-        subprocess.run([EXE, fin, fout], check=True)
+        subprocess.run([exe or EXE, fin, fout], check=True)
         raw = open(fout, "rb").read()
     counter, capacity = struct.unpack_from("<2I", raw, 0)
     e = min(counter, capacity)
@@ -64,6 +67,35 @@ def dense_inputs():
     return aos, view, proj, pos, w, h
 
 
+CONFIG_A_AOS_SHA256 = "dc8b5f6239df17ab4f9dc09a83e860baaa22eb380054d4b055e6eb47d62f3d3d"
+
+
+def config_a_inputs(rotated=False):
+    """BASELINE config A (100,000 splats @ 640 x 360) out of the package's own generator; the records are NOT stored in
+    the fixture -- their hash is, and the tests assert it."""
+    import hashlib
+    sys.path.insert(0, ROOT)
+    import oracle
+    from vk3dgaussiansplatting_amd import synth
+    aos, cfg = synth.generate_config("A")
+    assert hashlib.sha256(aos.tobytes()).hexdigest() == CONFIG_A_AOS_SHA256, "synth.generate_config('A') changed"
+    w, h = cfg["width"], cfg["height"]
+    pos = np.array([0.3, -0.1, -1.5] if rotated else [0.0, 0.0, 0.0], np.float32)
+    view, proj = oracle.camera_matrices(pos, 0.15 if rotated else 0.0, -0.08 if rotated else 0.0, w / h)
+    return aos, view, proj, pos, w, h
+
+
+def config_a_fixture(o):
+    """What ref_main_configA.npz keeps of a dump: the emitted list, the sorted splat ids (sorted tile words follow from
+    the ranges, sorted depth words from the list), ranges, frame; hashes of the sorted list, colours and covariances."""
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    return dict(counter=o["counter"], capacity=o["capacity"], list=o["list"], sorted_id=o["sorted"][:, 2].copy(),
+                ranges=o["ranges"], rgba=o["rgba"], sorted_sha256=np.array(sha(o["sorted"])),
+                color_sha256=np.array(sha(o["color"])), cov_sha256=np.array(sha(o["cov"])),
+                aos_sha256=np.array(CONFIG_A_AOS_SHA256))
+
+
 if __name__ == "__main__":
     if not os.path.exists(EXE):
         sys.exit("build oracle/_ref/ref_main_xcheck first (make -C oracle ref; needs /root/reference)")
@@ -88,3 +120,8 @@ if __name__ == "__main__":
     path = os.path.join(GOLDEN, "ref_main_dense.npz")
     np.savez_compressed(path, aos=aos, view=view, proj=proj, cam_pos=pos, width=np.uint32(w), height=np.uint32(h), **o)
     print("wrote", path, os.path.getsize(path), "bytes")
+    if "--no-config-a" not in sys.argv:     # ~75 s: 3,853 Count workgroups x 11 passes x 2 subgroup sizes as fibers
+        o = run(*config_a_inputs(), 0)
+        path = os.path.join(GOLDEN, "ref_main_configA.npz")
+        np.savez_compressed(path, **config_a_fixture(o))
+        print("wrote", path, os.path.getsize(path), "bytes; E =", int(o["counter"]))

@@ -151,6 +151,103 @@ def test_shader_main_bodies_cross_check(oracle_mod, which):
         assert lens.max() > 256, "the dense scene must need more than one 256-entry batch"
 
 
+def _load_golden_script(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(GOLDEN, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _reference_harness_present():
+    from conftest import ROOT
+    return os.path.isdir("/root/reference/vkGaussianSplatting") and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_main_xcheck"))
+
+
+def test_config_a_through_the_reference_shader_text(oracle_mod):
+    """BASELINE config A at FULL size -- 100,000 splats @ 640 x 360, E = 246,569 -- through the reference's own shader
+    text (tests/golden/ref_main_configA.npz, make_main_xcheck.py: InitSortList.comp:82-151, the six RadixSort/*.comp over
+    3,853 Count workgroups and eleven passes, FindRanges.comp over the 2^20 capacity, RenderGaussians.comp:56-152 over 920
+    tiles, all as C++ over the reference's glm under the numeric contract).  The oracle reproduces counter, emitted list,
+    sorted list, ranges, colour, covariance and every pixel bit for bit.  The records are not in the fixture: they come
+    out of synth and their hash is asserted.  Where the reference is mounted the dump is regenerated first (~75 s).
+    A cross-check, not a pin."""
+    import hashlib
+    mm = _load_golden_script("make_main_xcheck")
+    x = np.load(os.path.join(GOLDEN, "ref_main_configA.npz"))
+    aos, view, proj, pos, w, h = mm.config_a_inputs()
+    assert hashlib.sha256(aos.tobytes()).hexdigest() == str(x["aos_sha256"])
+    if _reference_harness_present():
+        fresh = mm.config_a_fixture(mm.run(aos, view, proj, pos, w, h, 0))
+        for k in x.files:
+            assert np.asarray(fresh[k]).tobytes() == np.asarray(x[k]).tobytes(), k
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    r = oracle_mod.full_pipeline(oracle_mod.make_params(w, h, view, proj, pos, sh_mode=0), aos)
+    e, s1 = r["e"], r["stage1"]
+    assert s1["counter"] == int(x["counter"]) == 246569 and s1["capacity"] == int(x["capacity"]) == 1 << 20
+    assert np.array_equal(np.stack([s1["tile"][:e], s1["depth"][:e], s1["id"][:e]], axis=1), x["list"])
+    assert np.array_equal(r["id"][:e], x["sorted_id"])
+    assert sha(np.stack([r["tile"][:e], r["depth"][:e], r["id"][:e]], axis=1).astype(np.uint32)) == str(x["sorted_sha256"])
+    assert np.array_equal(r["ranges"], x["ranges"])
+    assert sha(s1["color"]) == str(x["color_sha256"]) and sha(s1["cov"]) == str(x["cov_sha256"])
+    assert np.array_equal(r["image"], x["rgba"])
+
+
+# What the parity envelope measured (tests/golden/make_envelope.py, profiles/r04_parity_envelope.txt): per scene the
+# largest figures over the three non-contract evaluations of the reference's text.
+ENVELOPE_BOUNDS = {   # scene: (max fraction of emitting splats whose depth key moves, max |key difference|, channel values that move)
+    "small": (0.24, 192, 1), "dense": (0.16, 128, 0), "extreme": (0.29, 192, 0), "configA": (0.0, 0, 9), "configA_rot": (0.16, 128, 106)}
+
+
+@pytest.mark.parametrize("scene", list(ENVELOPE_BOUNDS))
+def test_parity_envelope(oracle_mod, scene):
+    """How far may a LEGAL evaluation of the reference's shader text move from the numeric contract the oracle (and the
+    HIP path) implement?  tests/golden/ref_envelope.npz holds what the nine main() bodies produce when nothing is
+    imposed on them -- glm's own mat4 * vec4 association and normalize, libm's expf (`native`), the same with every
+    a * b + c fused (`native_fma`), and with exp(x) = exp2(x log2 e) on top (`gpu_like`) -- as differences from the
+    contract's dump, for five scenes up to BASELINE config A at full size.  Measured and asserted here against the
+    oracle's own output: the set of emitting splats, every tile box, the element count and the ENTIRE sorted order are
+    the same in every variant; depth keys move in 14-29 % of the splats under a rotated camera, by at most 1.5 units in
+    the last place of the float they are converted from (|d key| <= 192); no channel of any pixel moves by more than ONE
+    8-bit step, and at most 106 of 691,200 channel values move at all.  That is the support north_star's "keys
+    bit-exact, pixels within 1 ULP of the reference renderer" can get in this container: the keys are exact against
+    the contract only; order, ranges and +-1 step hold across every evaluation measured.  Where the reference is mounted
+    the three small scenes are regenerated and compared first (GS_ENVELOPE_FULL=1: config A too, ~3 min)."""
+    import hashlib
+    me = _load_golden_script("make_envelope")
+    z = np.load(os.path.join(GOLDEN, "ref_envelope.npz"))
+    inputs = dict(me.scenes())[scene] if scene.startswith("configA") else dict(me.scenes(small_only=True))[scene]
+    aos, view, proj, pos, w, h = inputs
+    n, grid_w = aos.shape[0], (w + 15) // 16
+    if _reference_harness_present() and (not scene.startswith("configA") or os.environ.get("GS_ENVELOPE_FULL") == "1"):
+        keep, lines = {}, []
+        me.record(scene, inputs, me.run_scene(scene, inputs), keep, lines)
+        for k, v in keep.items():
+            assert np.asarray(v).tobytes() == np.asarray(z[k]).tobytes(), k
+    r = oracle_mod.full_pipeline(oracle_mod.make_params(w, h, view, proj, pos, sh_mode=0), aos)
+    e, s1 = r["e"], r["stage1"]
+    lst = np.stack([s1["tile"][:e], s1["depth"][:e], s1["id"][:e]], axis=1)
+    em, key, box = me.per_splat(lst, n, grid_w)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert [sha(r["image"]), sha(key), sha(box), sha(em)] == list(z[f"{scene}_contract_sha256"]), "oracle != contract dump"
+    assert e == int(z[f"{scene}_counter"])
+    frac_max, dkey_max, moved_max = ENVELOPE_BOUNDS[scene]
+    worst = [0.0, 0, 0]
+    for v in me.VARIANTS[1:]:
+        assert int(z[f"{scene}_{v}_counter"]) == e                                   # same number of sort elements
+        assert z[f"{scene}_{v}_emits_idx"].size == 0 and z[f"{scene}_{v}_box_idx"].size == 0   # same culls, same tile boxes
+        assert int(z[f"{scene}_{v}_sorted_positions_differ"]) == 0 and int(z[f"{scene}_{v}_tile_lists_differ"]) == 0
+        vkey = me.apply_sparse(key, z[f"{scene}_{v}_key_idx"], z[f"{scene}_{v}_key_val"])
+        dk = np.abs(vkey.astype(np.int64) - key.astype(np.int64))
+        img = me.apply_sparse(r["image"], z[f"{scene}_{v}_rgba_idx"], z[f"{scene}_{v}_rgba_val"])
+        d = np.abs(img.astype(np.int16) - r["image"].astype(np.int16))
+        assert d.max(initial=0) <= 1, (scene, v)                                     # north_star's tolerance
+        worst = [max(worst[0], (dk != 0).sum() / max(em.sum(), 1)), max(worst[1], int(dk.max(initial=0))), max(worst[2], int((d != 0).sum()))]
+    assert worst[0] <= frac_max and worst[1] <= dkey_max and worst[2] <= moved_max, worst
+    if scene != "configA":
+        assert worst[1] == dkey_max and worst[2] == moved_max, worst                 # the table in DESIGN.md is what was measured
+
+
 def test_camera_matrices_match_reference_glm(oracle_mod, ref_golden):
     """view/proj bit-identical to the reference's own Camera::recalculate (the text of Camera.cpp:4-54 over its glm,
     oracle/ref_fixtures.cpp) for its scene poses."""

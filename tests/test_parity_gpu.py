@@ -198,6 +198,86 @@ def test_shader_main_bodies_cross_check(which, sort):
         r.cleanup()
 
 
+def _golden_script(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(GOLDEN, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _scene_from_matrices(aos, view, proj, pos, w, h):
+    rm = gs.ResourceManager()
+    rm.setGaussians(aos)
+    sc = gs.Scene(rm, aspect_ratio=w / h)
+    sc.camera.viewMatrix, sc.camera.projectionMatrix = view, proj
+    sc.camera.position = pos
+    sc.camera.setShMode(0)
+    return sc
+
+
+def _emitted_list(r, sc):
+    r.debugInitSortList(sc)
+    return np.stack([r.debugRead(b) for b in (gs.BUF_UNSORTED_TILE, gs.BUF_UNSORTED_DEPTH, gs.BUF_UNSORTED_ID)], axis=1)
+
+
+@pytest.mark.parametrize("sort", ALL_SORTS)
+def test_config_a_through_the_reference_shader_text(sort):
+    """BASELINE config A at full size against tests/golden/ref_main_configA.npz directly (no oracle code runs): what the
+    reference's own InitSortList.comp, six RadixSort/*.comp (3,853 Count workgroups, eleven passes), FindRanges.comp and
+    RenderGaussians.comp text produce for the 100,000 splats @ 640 x 360 (oracle/ref_main_xcheck.cpp).  Counter, the
+    list as emitted, the sorted list, ranges, colour / covariance (by hash, over the emitting splats' rows as the dump
+    has them) and every pixel, bit for bit, with all five sorters.  A cross-check, not a pin."""
+    import hashlib
+    mm = _golden_script("make_main_xcheck")
+    x = np.load(os.path.join(GOLDEN, "ref_main_configA.npz"))
+    aos, view, proj, pos, w, h = mm.config_a_inputs()
+    assert hashlib.sha256(aos.tobytes()).hexdigest() == str(x["aos_sha256"])
+    sc = _scene_from_matrices(aos, view, proj, pos, w, h)
+    r = make_renderer(sc, w, h, sort=sort)
+    img = r.draw(sc)
+    assert np.array_equal(img, x["rgba"])
+    assert r.timings().emitted_elements == int(x["counter"]) and r.sceneInfo().capacity == int(x["capacity"])
+    ids, tiles, depth = r.debugRead(gs.BUF_SORTED_ID), r.debugRead(gs.BUF_SORTED_TILE), r.debugRead(gs.BUF_SORTED_DEPTH)
+    assert np.array_equal(ids, x["sorted_id"])
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(np.stack([tiles, depth, ids], axis=1).astype(np.uint32)) == str(x["sorted_sha256"])
+    assert np.array_equal(r.debugRead(gs.BUF_RANGES), x["ranges"])
+    assert sha(r.debugRead(gs.BUF_COV)) == str(x["cov_sha256"])
+    assert np.array_equal(_emitted_list(r, sc), x["list"])
+    r.cleanup()
+
+
+@pytest.mark.parametrize("scene", ["small", "dense", "extreme", "configA", "configA_rot"])
+def test_parity_envelope(scene):
+    """The HIP frame against the OTHER legal evaluations of the reference's shader text (tests/golden/ref_envelope.npz,
+    make_envelope.py; no oracle code runs): the frame, the per-splat depth keys, tile boxes and emit flags of the HIP
+    path must hash to the contract's dump, and every variant -- glm's native association and normalize with libm's expf,
+    the same with fused multiply-adds, and with exp = exp2(x log2 e) -- has the same emitting splats, the same tile
+    boxes, the same element count and sorted order, depth keys within 192 (1.5 units in the last place of the float
+    they are converted from) and every channel of every pixel within ONE 8-bit step of the HIP frame."""
+    import hashlib
+    me = _golden_script("make_envelope")
+    z = np.load(os.path.join(GOLDEN, "ref_envelope.npz"))
+    aos, view, proj, pos, w, h = dict(me.scenes(small_only=not scene.startswith("configA")))[scene]
+    sc = _scene_from_matrices(aos, view, proj, pos, w, h)
+    r = make_renderer(sc, w, h)
+    img = r.draw(sc)
+    e = r.timings().emitted_elements
+    em, key, box = me.per_splat(_emitted_list(r, sc), aos.shape[0], (w + 15) // 16)
+    r.cleanup()
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert [sha(img), sha(key), sha(box), sha(em)] == list(z[f"{scene}_contract_sha256"])
+    for v in me.VARIANTS[1:]:
+        assert int(z[f"{scene}_{v}_counter"]) == e == int(z[f"{scene}_counter"])
+        assert z[f"{scene}_{v}_emits_idx"].size == 0 and z[f"{scene}_{v}_box_idx"].size == 0
+        assert int(z[f"{scene}_{v}_sorted_positions_differ"]) == 0 and int(z[f"{scene}_{v}_tile_lists_differ"]) == 0
+        vkey = me.apply_sparse(key, z[f"{scene}_{v}_key_idx"], z[f"{scene}_{v}_key_val"])
+        assert np.abs(vkey.astype(np.int64) - key.astype(np.int64)).max(initial=0) <= 192
+        vimg = me.apply_sparse(img, z[f"{scene}_{v}_rgba_idx"], z[f"{scene}_{v}_rgba_val"])
+        assert np.abs(vimg.astype(np.int16) - img.astype(np.int16)).max(initial=0) <= 1
+
+
 def test_init_sort_list_stage(oracle_mod, small_cloud):
     """Emission order is the canonical one: ascending splat index, then row-major tile (N7/N8)."""
     w, h = 320, 180
