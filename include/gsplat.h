@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define GS_API_VERSION 2   /* 2: gs_config grew tile_order */
+#define GS_API_VERSION 3   /* 2: gs_config grew tile_order; 3: gs_config starts with struct_size, gs_api_version(),
+                              gs_runtime_versions(), gs_dist_* / gs_gather_strips */
 
 /* status codes */
 #define GS_OK 0
@@ -79,6 +80,9 @@ typedef struct gs_ctx gs_ctx;
 #define GS_TILE_ORDER_RASTER 1u        /* row-major, like the reference's dispatch (Subrenderer.cpp:330-333) */
 
 typedef struct gs_config {
+    uint32_t struct_size;     /* sizeof(gs_config) as the CALLER's header declares it (gs_default_config fills it in).
+                                 gs_create copies that many bytes and keeps its defaults for fields the caller's
+                                 header does not know yet; a struct larger than the library's is refused. */
     int32_t device_ordinal;   /* HIP device index */
     uint32_t tile_size;       /* 16; only 16 is supported (TILE_SIZE) */
     float near_plane;         /* 0.1f   Camera::NEAR_PLANE */
@@ -163,6 +167,13 @@ typedef struct gs_scene_info {
 #define GS_BUF_UNSORTED_ID 9
 #define GS_BUF_IMAGE 10        /* uint8[H][W][4]             internal framebuffer */
 
+/* GS_API_VERSION of the library that is actually loaded: compare with the header's before anything else
+ * (gsplat.hpp and the Python binding do). */
+uint32_t gs_api_version(void);
+/* HIP_VERSION the library was compiled against, and the HIP runtime / driver versions of the libamdhip64 the process
+ * really bound (a process holds ONE HIP runtime -- INTEGRATION.md, "One HIP runtime per process"); any pointer may be NULL. */
+int gs_runtime_versions(int* hip_build, int* hip_runtime, int* hip_driver);
+
 void gs_default_config(gs_config* cfg);
 
 /* Renderer::init (Renderer.cpp:688-694) + GpuSort::singleInitResources (RadixSort.cpp:23-142). */
@@ -218,6 +229,35 @@ int gs_set_tile_rows(gs_ctx* ctx, uint32_t row_begin, uint32_t row_end);
  * (ceil(rows_owned) * 16 rows of `width` pixels); gs_render (host image) always writes the real rows. */
 int gs_set_tile_rows_interleaved(gs_ctx* ctx, uint32_t phase, uint32_t stride, uint32_t compact_output);
 int gs_get_scene_info(const gs_ctx* ctx, gs_scene_info* out);
+
+/* Multi-GPU extension, the exchange step (no reference counterpart): one process per GPU, every
+ * rank renders its tile rows into a strip (gs_render_device* with gs_set_tile_rows*), and the strips meet on the
+ * root over RCCL -- point-to-point transfers over xGMI inside a node, enqueued on the context's stream behind the
+ * frame that wrote the strip.  RCCL is bound at gs_dist_init (librccl.so.1 by name, or the copy the process
+ * already holds), not at link time.
+ *   gs_dist_unique_id : ncclGetUniqueId -- call on ONE rank, hand the GS_DIST_UNIQUE_ID_BYTES bytes to the others by
+ *                       any means (pipe, file, MPI, torch.distributed broadcast);
+ *   gs_dist_init      : ncclCommInitRank for this context's GPU; collective over all `world` ranks;
+ *   gs_gather_strips  : strip_dev = this rank's `bytes` bytes on the device; gathered_dev = world * bytes bytes on
+ *                       the root's device (rank r's strip at offset r * bytes; ignored on other ranks, may be NULL
+ *                       there).  Asynchronous: ordered on the context's stream, wait with gs_synchronize;
+ *   gs_dist_destroy   : ncclCommDestroy (gs_destroy does it too). */
+#define GS_DIST_UNIQUE_ID_BYTES 128
+int gs_dist_unique_id(void* id_out);
+int gs_dist_init(gs_ctx* ctx, const void* unique_id, int rank, int world);
+int gs_gather_strips(gs_ctx* ctx, const void* strip_dev, void* gathered_dev, size_t bytes, int root);
+int gs_dist_destroy(gs_ctx* ctx);
+/* The same for a host that holds no device memory of its own -- Renderer::draw on R GPUs (Renderer.cpp:297-515):
+ *   gs_dist_shard_rows : after gs_set_resolution + gs_dist_init; rank r of R takes its tile rows (contiguous band of
+ *                        ceil(Ty / R) rows, or rows r, r + R, ... when interleaved != 0) and the library allocates the
+ *                        strip (and, on rank 0, the gather buffer);
+ *   gs_render_sharded  : every rank calls it with the same camera: the rank's rows are rendered into its strip, the
+ *                        strips gathered on rank 0 and the whole frame copied to rgba_out there (HOST, height*width*4
+ *                        bytes as in gs_render; ignored on the other ranks, may be NULL).  Synchronous.  The frame is
+ *                        bit-identical to the one GPU frame of gs_render. */
+int gs_dist_shard_rows(gs_ctx* ctx, uint32_t interleaved);
+int gs_render_sharded(gs_ctx* ctx, const float view[16], const float proj[16], const float cam_pos[3],
+                      uint32_t sh_mode, uint8_t* rgba_out);
 
 /* Renderer::draw (Renderer.cpp:297-515): updateUniformBuffer(view, proj) (:531-538), the push
  * constants of Subrenderer.cpp:152-160 (camPos, shMode as an INTEGER 0/1/2), then the recorded

@@ -31,6 +31,11 @@ public:
     int init(const gs_config* cfg = nullptr) {
         const int rc_clean = cleanup();
         if (rc_clean != GS_OK) return rc_clean;
+        if (gs_api_version() != GS_API_VERSION) {   // the structs below are laid out as THIS header declares them
+            error_ = "libgsplat_hip.so has API version " + std::to_string(gs_api_version()) + ", this header " +
+                     std::to_string(GS_API_VERSION);
+            return GS_ERR_INVALID;
+        }
         gs_config def;
         if (!cfg) { gs_default_config(&def); def.record_timings = 1; cfg = &def; }
         const int rc = gs_create(cfg, &ctx_);

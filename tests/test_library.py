@@ -25,6 +25,29 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"libgsplat_hip.so does not export {name}"
     assert sorted(_lib.EXPORTS) == declared
+    # ... and nothing else: what the product library exports with a gs_ prefix IS the header (tuning probes live in
+    # tools/probe/libgsplat_probe.so)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("gs_") and ln.split()[-2] in "TW"})
+    assert exported == declared, sorted(set(exported) ^ set(declared))
+    assert L.gs_api_version() == _lib.API_VERSION == int(re.search(r"#define GS_API_VERSION (\d+)", open(os.path.join(ROOT, "include", "gsplat.h")).read()).group(1))
+
+
+def test_config_struct_size_is_checked():
+    """gs_config starts with struct_size (what the caller's header knows of the struct): a struct that claims to be
+    larger than the library's, or smaller than the version-3 layout, is refused before anything else is read."""
+    L = _lib.lib()
+    cfg = _lib.GsConfig()
+    L.gs_default_config(C.byref(cfg))
+    assert cfg.struct_size == C.sizeof(_lib.GsConfig) == 52
+    h = C.c_void_p()
+    for bad in (0, 4, C.sizeof(_lib.GsConfig) - 4, C.sizeof(_lib.GsConfig) + 4, 1 << 20):
+        cfg.struct_size = bad
+        assert L.gs_create(C.byref(cfg), C.byref(h)) == _lib.GS_ERR_INVALID and not h.value
+        assert b"struct_size" in L.gs_last_error(None)
+    info = _lib.runtime_info()
+    assert info["hip_build"] >= 70000000
 
 
 def test_product_never_imports_oracle():

@@ -695,6 +695,82 @@ def test_cpp_driver_runs(tmp_path):
         subprocess.run([exe, "--synthetic", "50000", "--res", "640x360", "--warmup", "3", "--frames", "10", "--sort", sort,
                         "--ppm", other], check=True, capture_output=True, text=True)
         assert open(other, "rb").read() == data
+    # the sharded-frame path of the same host (--ranks R forks one process per GPU before any GPU call; one card here, so
+    # R = 1): gs_dist_unique_id -> gs_dist_init -> gs_dist_shard_rows -> gs_render_sharded, contiguous and interleaved
+    # rows, no Python and no device pointer in the host -- identical file
+    for extra in (["--ranks", "1", "--interleaved"], ["--ranks", "1"]):
+        other = str(tmp_path / "frame_dist.ppm")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GSPLAT_BENCH_DIST="1")
+        p = subprocess.run([exe, "--synthetic", "50000", "--res", "640x360", "--warmup", "2", "--frames", "5", "--ppm", other] + extra,
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode == 0 and "frame + gather" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+        assert open(other, "rb").read() == data
+
+
+@pytest.mark.parametrize("with_torch", [False, True])
+def test_c_abi_sharded_frame_single_rank(with_torch):
+    """The exchange step behind the C-ABI (gs_dist.cpp: RCCL bound at gs_dist_init, grouped ncclSend / ncclRecv on the
+    context's stream) on the one GPU a test box has -- world size 1 is all one card allows: unique id, communicator,
+    gs_dist_shard_rows + gs_render_sharded (contiguous and interleaved rows) against gs_render's frame, the low-level
+    gs_gather_strips on caller-owned device memory, call-order status codes, destroy in both orders.  In a child process
+    (this one never holds a communicator), once with torch imported first -- the process then holds torch's RCCL and HIP
+    runtime, the configuration of bench.py -- and once without torch (the library binds librccl.so.1 by name)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import ctypes as C, sys
+        import numpy as np
+        WITH_TORCH = @WITH_TORCH@
+        if WITH_TORCH:
+            import torch
+        from vk3dgaussiansplatting_amd import _lib, synth
+        if not WITH_TORCH:
+            _lib.preload_rccl()
+        L = _lib.lib()
+        w, h, n = 640, 360, 30000
+        aos = synth.generate(n, w, h, -3.0, seed=5)
+        view = np.zeros(16, np.float32); proj = np.zeros(16, np.float32); pos = np.zeros(3, np.float32)
+        assert L.gs_camera_matrices(pos.ctypes.data, 0.0, 0.0, w / h, 0.1, 100.0, view.ctypes.data, proj.ctypes.data) == 0
+        ctx = C.c_void_p()
+        assert L.gs_create(None, C.byref(ctx)) == 0
+        assert L.gs_upload_gaussians(ctx, aos.ctypes.data, n) == 0 and L.gs_set_resolution(ctx, w, h) == 0
+        ref = np.zeros((h, w, 4), np.uint8)
+        assert L.gs_render(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0, ref.ctypes.data) == 0 and ref.any()
+        img = np.zeros_like(ref)
+        # call order
+        assert L.gs_dist_shard_rows(ctx, 0) == _lib.GS_ERR_INVALID
+        assert L.gs_render_sharded(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0, img.ctypes.data) == _lib.GS_ERR_INVALID
+        assert L.gs_gather_strips(ctx, 1, 1, 16, 0) == _lib.GS_ERR_INVALID
+        ident = C.create_string_buffer(_lib.DIST_UNIQUE_ID_BYTES)
+        assert L.gs_dist_unique_id(ident) == 0
+        assert L.gs_dist_init(ctx, ident, 1, 1) == _lib.GS_ERR_INVALID and L.gs_dist_init(ctx, None, 0, 1) == _lib.GS_ERR_INVALID
+        assert L.gs_dist_init(ctx, ident, 0, 1) == 0, L.gs_last_error(ctx)
+        assert L.gs_dist_init(ctx, ident, 0, 1) == _lib.GS_ERR_INVALID          # twice
+        for interleaved in (0, 1, 0):
+            assert L.gs_dist_shard_rows(ctx, interleaved) == 0, L.gs_last_error(ctx)
+            for _ in range(2):
+                img[:] = 0
+                assert L.gs_render_sharded(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0, img.ctypes.data) == 0, L.gs_last_error(ctx)
+                assert np.array_equal(img, ref), interleaved
+        assert L.gs_render_sharded(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0, None) == _lib.GS_ERR_INVALID   # the root needs the image
+        if WITH_TORCH:
+            strip = torch.randint(0, 256, (272 * 3840 * 4,), dtype=torch.uint8, device="cuda")
+            out = torch.zeros_like(strip)
+            assert L.gs_gather_strips(ctx, strip.data_ptr(), out.data_ptr(), strip.numel(), 0) == 0 and L.gs_synchronize(ctx) == 0
+            assert torch.equal(strip, out)
+            assert L.gs_gather_strips(ctx, strip.data_ptr(), None, strip.numel(), 0) == _lib.GS_ERR_INVALID
+            assert L.gs_gather_strips(ctx, strip.data_ptr(), out.data_ptr(), strip.numel(), 1) == _lib.GS_ERR_INVALID
+        assert L.gs_dist_destroy(ctx) == 0 and L.gs_dist_destroy(ctx) == 0
+        # a second communicator on the same context, left for gs_destroy to take down
+        assert L.gs_dist_unique_id(ident) == 0 and L.gs_dist_init(ctx, ident, 0, 1) == 0
+        assert L.gs_set_tile_rows(ctx, 0, (h + 15) // 16) == 0
+        assert L.gs_render(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0, img.ctypes.data) == 0 and np.array_equal(img, ref)
+        assert L.gs_destroy(ctx) == 0
+        print("dist-ok", _lib.runtime_info()["runtime_path"])
+    """).replace("@WITH_TORCH@", str(bool(with_torch)))
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "dist-ok" in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
 
 
 @pytest.mark.parametrize("n,w,h,mu", [

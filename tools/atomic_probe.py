@@ -8,7 +8,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vk3dgaussiansplatting_amd import _lib
 L = _lib.lib()
-L.gs_atomic_probe.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.POINTER(C.c_float)]
+import probe_lib; P = probe_lib.load()
 h = C.c_void_p(); assert L.gs_create(None, C.byref(h)) == 0
 print("workgroups  lines/WG  share   plain stores   atomic adds   [us per launch, mean of 20]")
 for wgs, rows in ((1896, 1896), (6408, 6408), (16169, 16169)):       # a 1/8 band of D, config C, config D
@@ -17,7 +17,7 @@ for wgs, rows in ((1896, 1896), (6408, 6408), (16169, 16169)):       # a 1/8 ban
             r = []
             for add in (0, 1):
                 us = C.c_float()
-                rc = L.gs_atomic_probe(h, wgs, lines, rows, 1, share, add, 20, C.byref(us))
+                rc = P.gs_atomic_probe(h, wgs, lines, rows, 1, share, add, 20, C.byref(us))
                 r.append("failed" if rc else f"{us.value:8.2f}")
             print(f"{wgs:10d} {lines:9d} {share:6d}   {r[0]:>12s}   {r[1]:>11s}", flush=True)
 L.gs_destroy(h)

@@ -5,8 +5,20 @@
 //
 //   gsplat_bench <scene.ply | --synthetic N> [--scene garden|train|bicycle|origin] [--res WxH]
 //                [--warmup F] [--frames F] [--fast] [--sort radix4|splat_first|bucket|radix8|radix8_splat_first] [--out frame.png|frame.ppm]
+//                [--ranks R [--interleaved]]
+//
+// --ranks R: the multi-GPU frame of SURVEY 8(e) without any Python -- R processes, one per GPU (rank r on device r),
+// forked BEFORE anything touches a GPU; every rank loads the same scene, owns a band of tile rows (or every R-th row:
+// --interleaved), renders it into a strip in HBM, and the strips meet on rank 0 through gs_gather_strips (RCCL,
+// point-to-point over xGMI).  Rank 0 creates the communicator id and hands it to its siblings through pipes opened
+// before the fork; it prints the mean frame time over the gather and writes the assembled frame with --out.
 #include "../include/gsplat.h"
 
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,10 +34,49 @@ static uint64_t sm(uint64_t& s) {
 }
 static float uni(uint64_t& s) { return (float)((sm(s) >> 40) * (1.0 / 16777216.0)); }
 
+static bool write_all(int fd, const void* p, size_t n) {
+    const char* c = static_cast<const char*>(p);
+    while (n) { const ssize_t k = write(fd, c, n); if (k <= 0) return false; c += k; n -= (size_t)k; }
+    return true;
+}
+static bool read_all(int fd, void* p, size_t n) {
+    char* c = static_cast<char*>(p);
+    while (n) { const ssize_t k = read(fd, c, n); if (k <= 0) return false; c += k; n -= (size_t)k; }
+    return true;
+}
+
+// One rank of a sharded frame (after the fork; `id_fd`: read end of this rank's pipe, or the write ends on rank 0).
+static int run_rank(gs_ctx* ctx, int rank, int ranks, bool interleaved, const std::vector<int>& id_fds, uint32_t w, uint32_t h,
+                    const float* view, const float* proj, const float* pos, uint32_t warmup, uint32_t frames, const std::string& out) {
+    unsigned char id[GS_DIST_UNIQUE_ID_BYTES];
+    if (rank == 0) {
+        if (gs_dist_unique_id(id) != GS_OK) { fprintf(stderr, "[Log Error]: gs_dist_unique_id failed\n"); return 1; }
+        for (int fd : id_fds) if (!write_all(fd, id, sizeof(id))) { fprintf(stderr, "[Log Error]: cannot hand the id to a rank\n"); return 1; }
+    } else if (!read_all(id_fds[0], id, sizeof(id))) { fprintf(stderr, "[Log Error]: rank %d got no id\n", rank); return 1; }
+    if (gs_dist_init(ctx, id, rank, ranks) != GS_OK) { fprintf(stderr, "[Log Error]: rank %d: %s\n", rank, gs_last_error(ctx)); return 1; }
+    if (gs_dist_shard_rows(ctx, interleaved ? 1u : 0u) != GS_OK) { fprintf(stderr, "[Log Error]: rank %d: %s\n", rank, gs_last_error(ctx)); return 1; }
+    std::vector<uint8_t> img(rank == 0 ? (size_t)w * h * 4 : 0);
+    double ms = 0.0;
+    for (uint32_t f = 0; f < warmup + frames; ++f) {         // every rank draws every frame (Engine.cpp:45-78)
+        const auto t0 = std::chrono::steady_clock::now();
+        if (gs_render_sharded(ctx, view, proj, pos, 0, rank == 0 ? img.data() : nullptr) < 0) {
+            fprintf(stderr, "[Log Error]: rank %d: %s\n", rank, gs_last_error(ctx)); return 1;
+        }
+        if (f >= warmup) ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (rank == 0) {
+        printf("ranks: %d (%s tile rows)   frame + gather + copy to host ms (host clock, rank 0): %.3f\n", ranks,
+               interleaved ? "interleaved" : "contiguous", ms / std::max(1u, frames));
+        if (!out.empty() && gs_write_image(out.c_str(), img.data(), w, h) != GS_OK) fprintf(stderr, "cannot write %s\n", out.c_str());
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     std::string ply, scene = "origin", ppm, sort = "radix4";   // GPU_SORT_ALGORITHM (Renderer.h:33)
     uint32_t n_syn = 0, w = 1280, h = 720, warmup = 1000, frames = 1000;   // window 1280x720: Engine.cpp:35; WAIT_ELAPSED_*_FRAMES_FOR_AVG: Renderer.h:142-143
-    bool fast = false;
+    bool fast = false, interleaved = false;
+    int ranks = 1, rank = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--synthetic" && i + 1 < argc) n_syn = (uint32_t)atol(argv[++i]);
@@ -36,11 +87,32 @@ int main(int argc, char** argv) {
         else if ((a == "--out" || a == "--ppm") && i + 1 < argc) ppm = argv[++i];
         else if (a == "--fast") fast = true;
         else if (a == "--sort" && i + 1 < argc) sort = argv[++i];
+        else if (a == "--ranks" && i + 1 < argc) ranks = atoi(argv[++i]);
+        else if (a == "--interleaved") interleaved = true;
         else ply = a;
     }
     if (ply.empty() && !n_syn) { fprintf(stderr, "usage: gsplat_bench <scene.ply | --synthetic N> [...]\n"); return 2; }
+    if (ranks < 1 || ranks > 64) { fprintf(stderr, "--ranks must be in [1, 64]\n"); return 2; }
+
+    // one process per GPU, forked before any GPU call (nothing above this line touches HIP); rank 0 stays the parent
+    std::vector<int> id_fds;                 // rank 0: write ends towards ranks 1 .. R-1; rank r: its read end
+    std::vector<pid_t> children;
+    const bool sharded = ranks > 1 || interleaved || std::getenv("GSPLAT_BENCH_DIST") != nullptr;   // the last two: the R = 1 form of the path
+    if (ranks > 1) {
+        std::vector<int> wr;
+        for (int r = 1; r < ranks && rank == 0; ++r) {
+            int fd[2];
+            if (pipe(fd) != 0) { perror("pipe"); return 1; }
+            const pid_t pid = fork();
+            if (pid < 0) { perror("fork"); return 1; }
+            if (pid == 0) { rank = r; close(fd[1]); for (int o : wr) close(o); id_fds.assign(1, fd[0]); children.clear(); }
+            else { close(fd[0]); wr.push_back(fd[1]); children.push_back(pid); }
+        }
+        if (rank == 0) id_fds = wr;
+    }
 
     gs_config cfg; gs_default_config(&cfg);
+    cfg.device_ordinal = rank;
     cfg.render_mode = fast ? GS_RENDER_FAST : GS_RENDER_EXACT;
     cfg.sort_algorithm = sort == "splat_first" ? GS_SORT_RADIX4_SPLAT_FIRST : sort == "bucket" ? GS_SORT_TILE_BUCKET
                        : sort == "radix8" ? GS_SORT_RADIX8 : sort == "radix8_splat_first" ? GS_SORT_RADIX8_SPLAT_FIRST : GS_SORT_RADIX4;
@@ -77,6 +149,14 @@ int main(int argc, char** argv) {
     else if (scene == "bicycle") { pos[0] = 0.945927f; pos[1] = -0.294418f; pos[2] = -0.181088f; yaw = -1.108407f; pitch = -0.324159f; }
     float view[16], proj[16];
     gs_camera_matrices(pos, yaw, pitch, (float)w / (float)h, cfg.near_plane, cfg.far_plane, view, proj);
+
+    if (sharded) {
+        int rc = run_rank(ctx, rank, ranks, interleaved, id_fds, w, h, view, proj, pos, warmup, frames, ppm);
+        gs_destroy(ctx);
+        for (int fd : id_fds) close(fd);
+        for (pid_t pid : children) { int st = 0; waitpid(pid, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : 1; }
+        return rc;
+    }
 
     gs_scene_info info; gs_get_scene_info(ctx, &info);
     printf("[Log]: Number of gaussians: %u   sort list capacity: %u   passes: %u\n", info.num_gaussians, info.capacity, info.num_sort_bits / 4);

@@ -8,7 +8,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vk3dgaussiansplatting_amd import _lib
 L = _lib.lib()
-L.gs_lds_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+import probe_lib; P = probe_lib.load()
 h = C.c_void_p(); assert L.gs_create(None, C.byref(h)) == 0
 kinds = ["no LDS (generator only)", "ds_add, random digit", "ds_add, address = lane", "ds_add, three digits",
          "read-modify-write of the lane's own packed column", "8 ballots + ds_add per digit present", "ds_add_rtn, random digit"]
@@ -17,7 +17,7 @@ for k, name in enumerate(kinds):
     row = []
     for reps in (0, 2, 8):
         us = C.c_float()
-        rc = L.gs_lds_probe(h, k, reps, 50, C.byref(us))
+        rc = P.gs_lds_probe(h, k, reps, 50, C.byref(us))
         row.append("  failed" if rc else f"{us.value:8.2f}")
     print(f"{k} {name:48s} {row[0]}  {row[1]}  {row[2]}", flush=True)
 L.gs_destroy(h)

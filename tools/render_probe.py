@@ -60,9 +60,9 @@ if not a.no_stats:
     r.drawDevice(sc, None, sync=True)
     info = r.sceneInfo(); T = info.tiles_x * info.tiles_y
     out = np.zeros((T, 8), np.uint32)
-    L = _lib.lib(); L.gs_debug_render_stats.argtypes = [C.c_void_p] * 5
+    import probe_lib; P = probe_lib.load()
     p = lambda x: x.ctypes.data_as(C.c_void_p)
-    rc = L.gs_debug_render_stats(r._ctx.handle, p(cam.getViewMatrix()), p(cam.getProjectionMatrix()), p(cam.getPosition()), p(out))
+    rc = P.gs_debug_render_stats(r._ctx.handle, p(cam.getViewMatrix()), p(cam.getProjectionMatrix()), p(cam.getPosition()), p(out))
     ln, vis, need, ticks, walked = (out[:, i].astype(np.float64) for i in range(5))
     print(f"stats rc {rc} tiles {T} E {ln.sum():.0f}")
     print("entries staged before the tile was done: mean %.0f p50 %.0f p99 %.0f max %.0f; total / E = %.3f" %

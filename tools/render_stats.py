@@ -18,9 +18,9 @@ r = gs.Renderer(w, h, warmup_frames=0); r.init(rm); r.initForScene(sc)
 r.drawDevice(sc)
 info = r.sceneInfo(); T = info.tiles_x * info.tiles_y
 out = np.zeros((T, 8), np.uint32)
-L = _lib.lib(); L.gs_debug_render_stats.argtypes = [C.c_void_p] * 5
+import probe_lib; P = probe_lib.load()
 p = lambda a: a.ctypes.data_as(C.c_void_p)
-rc = L.gs_debug_render_stats(r._ctx.handle, p(cam.getViewMatrix()), p(cam.getProjectionMatrix()), p(cam.getPosition()), p(out))
+rc = P.gs_debug_render_stats(r._ctx.handle, p(cam.getViewMatrix()), p(cam.getProjectionMatrix()), p(cam.getPosition()), p(out))
 ln, vis, need, ticks = (out[:, i].astype(np.float64) for i in range(4))
 print("rc", rc, "tiles", T, "E", ln.sum())
 print("list length  mean %.0f max %.0f" % (ln.mean(), ln.max()))

@@ -9,7 +9,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vk3dgaussiansplatting_amd import _lib
 L = _lib.lib()
-L.gs_sync_probe.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+import probe_lib; P = probe_lib.load()
 h = C.c_void_p(); assert L.gs_create(None, C.byref(h)) == 0
 print("workgroups  bytes/WG   launches (graph)   persistent + barrier   [us per step, 22 steps, mean of 20]")
 for wgs in (256, 475, 1024, 1896, 2048):          # 475 = k_count's grid for a 1/8 band of config D, 1896 = its k_scatter groups
@@ -17,7 +17,7 @@ for wgs in (256, 475, 1024, 1896, 2048):          # 475 = k_count's grid for a 1
         res = []
         for persistent in (0, 1):
             us, to = C.c_float(), C.c_uint32()
-            rc = L.gs_sync_probe(h, persistent, wgs, 22, nbytes, 20, C.byref(us), C.byref(to))
+            rc = P.gs_sync_probe(h, persistent, wgs, 22, nbytes, 20, C.byref(us), C.byref(to))
             res.append("failed" if rc else ("timed out (grid not resident)" if to.value else f"{us.value:7.2f}"))
         print(f"{wgs:10d} {nbytes:9d}   {res[0]:>16s}   {res[1]:>20s}", flush=True)
 L.gs_destroy(h)

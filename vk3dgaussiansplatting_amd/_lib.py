@@ -41,6 +41,7 @@ RECORD_BYTES = 336
 
 class GsConfig(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("device_ordinal", C.c_int32),
         ("tile_size", C.c_uint32),
         ("near_plane", C.c_float),
@@ -110,8 +111,11 @@ EXPORTS = [
     "gs_get_scene_info", "gs_render", "gs_render_device", "gs_render_device_async",
     "gs_synchronize", "gs_get_timings", "gs_debug_read", "gs_debug_init_sort_list",
     "gs_set_stream", "gs_camera_matrices", "gs_sort_host", "gs_sort_bench", "gs_membench", "gs_write_image", "gs_share_scene",
-    "gs_get_host_timings", "gs_set_tile_rows_interleaved",
+    "gs_get_host_timings", "gs_set_tile_rows_interleaved", "gs_api_version", "gs_runtime_versions",
+    "gs_dist_unique_id", "gs_dist_init", "gs_gather_strips", "gs_dist_destroy", "gs_dist_shard_rows", "gs_render_sharded",
 ]
+API_VERSION = 3            # GS_API_VERSION of include/gsplat.h this binding was written against
+DIST_UNIQUE_ID_BYTES = 128
 
 
 class GsplatLibraryMissing(RuntimeError):
@@ -169,6 +173,14 @@ def lib() -> C.CDLL:
     _one_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, u32, f32 = C.c_void_p, C.c_uint32, C.c_float
+    # the structs above are this file's copy of the header: refuse a library of another API version instead of handing
+    # it structs it reads differently
+    if not hasattr(L, "gs_api_version"):
+        raise GsplatLibraryMissing(f"{LIB_PATH} predates gs_api_version(): rebuild it (make -C {CSRC})")
+    L.gs_api_version.argtypes = []
+    L.gs_api_version.restype = u32
+    if L.gs_api_version() != API_VERSION:
+        raise GsplatLibraryMissing(f"{LIB_PATH} has API version {L.gs_api_version()}, this binding expects {API_VERSION}: rebuild it")
     ctxp = C.c_void_p
     L.gs_default_config.argtypes = [C.POINTER(GsConfig)]
     L.gs_default_config.restype = None
@@ -200,5 +212,64 @@ def lib() -> C.CDLL:
     L.gs_share_scene.argtypes = [ctxp, ctxp]
     L.gs_get_host_timings.argtypes = [ctxp, C.POINTER(GsHostTimings)]
     L.gs_set_tile_rows_interleaved.argtypes = [ctxp, u32, u32, u32]
+    L.gs_runtime_versions.argtypes = [C.POINTER(C.c_int)] * 3
+    L.gs_dist_unique_id.argtypes = [vp]
+    L.gs_dist_init.argtypes = [ctxp, vp, C.c_int, C.c_int]
+    L.gs_gather_strips.argtypes = [ctxp, vp, vp, C.c_size_t, C.c_int]
+    L.gs_dist_destroy.argtypes = [ctxp]
+    L.gs_dist_shard_rows.argtypes = [ctxp, u32]
+    L.gs_render_sharded.argtypes = [ctxp, vp, vp, vp, u32, vp]
     _lib = L
+    _check_hip_runtime(L)
     return L
+
+
+def hip_runtime_path() -> str | None:
+    """The libamdhip64 this process really bound (from /proc/self/maps)."""
+    try:
+        for line in open("/proc/self/maps"):
+            if "libamdhip64" in line:
+                return line.split()[-1]
+    except OSError:
+        pass
+    return None
+
+
+def runtime_info() -> dict:
+    """HIP version the library was built against, the runtime / driver versions the process bound, and that runtime's path."""
+    b, r, d = C.c_int(0), C.c_int(0), C.c_int(0)
+    rc = lib().gs_runtime_versions(C.byref(b), C.byref(r), C.byref(d))
+    return {"rc": rc, "hip_build": b.value, "hip_runtime": r.value, "hip_driver": d.value, "runtime_path": hip_runtime_path()}
+
+
+def _check_hip_runtime(L) -> None:
+    """libgsplat_hip.so is compiled against /opt/rocm's headers and may run on the libamdhip64 a PyTorch wheel bundles
+    (_one_hip_runtime): a different MAJOR version is reported -- loudly, once -- because nothing else would."""
+    b, r = C.c_int(0), C.c_int(0)
+    if L.gs_runtime_versions(C.byref(b), C.byref(r), None) != GS_OK or not b.value or not r.value:
+        return                                     # no usable runtime here (CPU-only container): nothing to compare
+    if b.value // 10_000_000 != r.value // 10_000_000:
+        import warnings
+        warnings.warn(f"libgsplat_hip.so was built against HIP {b.value} but the process bound HIP runtime {r.value} "
+                      f"({hip_runtime_path()}); set GS_HIP_RUNTIME=system to keep /opt/rocm's runtime in processes that never import torch")
+
+
+def preload_rccl() -> None:
+    """gs_dist_init binds RCCL by SONAME (librccl.so.1).  In a process that will import torch later, map the copy the
+    PyTorch wheel bundles first, so that both sides end up on ONE RCCL over ONE HIP runtime."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("GS_HIP_RUNTIME") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+    if os.path.exists(bundled):
+        try:
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass

@@ -5,11 +5,13 @@
 // GS_ERR_NO_DEVICE / GS_ERR_HIP.
 #include "../../include/gsplat.h"
 #include "gs_internal.h"
+#include "gs_ctx.h"
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -19,71 +21,6 @@
 using namespace gs;
 
 static thread_local std::string g_create_error;
-
-// The uploaded gaussian arrays (read-only on the path), reference-counted so that the contexts that render them
-// (gs_share_scene: frame slots, tile-row bands) can be destroyed in any order.
-struct SharedScene {
-    SceneBuffers b{};
-    uint32_t n = 0;
-    std::atomic<uint32_t> refs{1};
-};
-
-using HostClock = std::chrono::steady_clock;
-
-struct gs_ctx {
-    gs_config cfg{};
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[7] = {};
-    hipEvent_t scatter_ev[32] = {};   // record_timings == 2: a pair per pass (<= 16 passes)
-    hipEvent_t alt_ev[2] = {};        // GS_SORT_TILE_BUCKET: after FindRanges / after the per-tile sort
-    hipStream_t helper_stream = nullptr;   // GS_SORT_TILE_BUCKET: big size classes run beside the small ones
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-    std::string last_error;
-
-    // scene
-    uint32_t n = 0;
-    SceneBuffers scene{};
-    SplatScratch scratch{};
-    uint32_t num_blocks = 0;
-    uint32_t emit_parity = 0;     // FrameParams::parity of the last InitSortList launch
-    SharedScene* shared = nullptr;    // owner of `scene`'s arrays (this context holds one reference)
-
-    // resolution-dependent
-    uint32_t width = 0, height = 0, grid_w = 0, grid_h = 0;
-    // tile rows of this context: first_row + k * row_stride < row_end, k < rows_owned (FrameParams)
-    uint32_t row_begin = 0, row_end = 0, row_stride = 1, first_row = 0, rows_owned = 0;
-    bool compact_out = false;
-    uint32_t capacity = 0, num_sort_bits = 0;
-    // what the sort of the owned tiles runs over: compact tile ids, so ceil((32 + bits(T_owned - 1)) / 4) passes
-    // (the reference's formula, RadixSort.cpp:203-204, for the context's own tile count)
-    uint32_t band_sort_bits = 0;
-    bool hi16 = false;   // the frame's sort list stores the compact tile ids as uint16 (at most 65535 owned tiles)
-    SortBuffers sort{};
-    uint32_t* ranges = nullptr;
-    uint32_t* tile_order = nullptr;   // [tiles] RenderGaussians' dispatch order (GS_TILE_ORDER_LONGEST_FIRST)
-    uint8_t* framebuffer = nullptr;
-    int sorted_index = 0;       // which ping-pong half holds the sorted list after the last frame
-    // The radix passes of a frame (3 launches per pass, parameters fixed once resolution and band are) replayed
-    // as one hipGraph launch: 36 launches -> 1 on the host side.  Built lazily, dropped when anything it baked in
-    // changes.  Not used while per-Scatter events are recorded (record_timings == 2).
-    hipGraphExec_t sort_graph = nullptr;
-    hipGraphExec_t presort_graph = nullptr;   // GS_SORT_RADIX4_SPLAT_FIRST: the eight depth passes over the splat list
-    hipGraphExec_t chain_graph = nullptr;     // ... without timers: everything from the splat list to FindRanges as one graph
-    int chain_result = 0;
-    hipEvent_t pre_ev[3] = {};        // ... after the splat list / after its passes / after the emit
-    int sort_graph_result = 0, presort_result = 1;
-    bool sort_graph_failed = false;
-    bool depth_dropped = false;   // last frame's tile-word passes did not carry the depth words (see k_scatter)
-
-    gs_timings timings{};
-    gs_host_timings host{};           // RECORD_CPU_TIMES (Renderer.cpp:299-456)
-    HostClock::time_point last_entry{};
-    bool have_entry = false;
-    bool have_frame = false;
-    bool unsorted_valid = false;   // last thing run was gs_debug_init_sort_list
-};
 
 namespace {
 
@@ -119,6 +56,7 @@ void free_scene(gs_ctx* c) {
     free_dev(c->scratch.raster); free_dev(c->scratch.depth_key); free_dev(c->scratch.tiles_touched);
     free_dev(c->scratch.extents); free_dev(c->scratch.block_sums); free_dev(c->scratch.block_offsets);
     free_dev(c->scratch.help_list); free_dev(c->scratch.help_count); free_dev(c->scratch.help_slot);
+    free_dev(c->scratch.wave_wrote);
     free_dev(c->scratch.band_list);
     free_dev(c->scratch.block_flags); free_dev(c->scratch.flag_offsets);
     free_dev(c->scratch.sorted_sums); free_dev(c->scratch.aux_params);
@@ -174,6 +112,7 @@ int alloc_sort(gs_ctx* ctx, SortBuffers& s, uint32_t capacity, uint32_t digit_bi
         HIP_TRY(ctx, hipMalloc((void**)&s.table, (size_t)kBins * max_groups * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMalloc((void**)&s.seg_sum, (size_t)kBins * kSegments * sizeof(uint32_t)));
     }
+    s.digit_bits = digit_bits;
     HIP_TRY(ctx, hipMalloc((void**)&s.params, sizeof(SortParams)));
     HIP_TRY(ctx, hipMemset(s.params, 0, sizeof(SortParams)));
     HIP_TRY(ctx, hipMalloc((void**)&s.coarse, (size_t)kMaxSortPasses * kBins * kCoarse * sizeof(uint32_t)));
@@ -184,40 +123,6 @@ int check_launch(gs_ctx* ctx, const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, GS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
     return GS_OK;
-}
-
-FrameParams make_frame_params(const gs_ctx* c, const float* view, const float* proj,
-                              const float* cam_pos, uint32_t sh_mode) {
-    FrameParams fp{};
-    std::memcpy(fp.view, view, sizeof(fp.view));
-    std::memcpy(fp.proj, proj, sizeof(fp.proj));
-    std::memcpy(fp.cam_pos, cam_pos, sizeof(fp.cam_pos));
-    fp.sh_mode = sh_mode;
-    fp.width = c->width; fp.height = c->height;
-    fp.grid_w = c->grid_w; fp.grid_h = c->grid_h;
-    fp.row_begin = c->row_begin; fp.row_end = c->row_end;
-    fp.row_stride = c->row_stride; fp.first_row = c->first_row; fp.rows_owned = c->rows_owned;
-    fp.compact_out = c->compact_out ? 1u : 0u;
-    fp.num_gaussians = c->n;
-    fp.capacity = c->capacity;
-    fp.near_plane = c->cfg.near_plane; fp.far_plane = c->cfg.far_plane;
-    fp.ndc_cull = c->cfg.ndc_cull; fp.in_view_limit = c->cfg.in_view_limit;
-    fp.tan_fov_y = (float)std::tan((double)(c->cfg.fov_y * 0.5f));   // Common.glsl:53, host-folded
-    fp.hi16 = c->hi16 ? 1u : 0u;
-    fp.parity = 0u;       // set by the InitSortList launch sites
-    // |W|_2^2 <= min(trace, largest absolute row sum) of M = W^T W (Gershgorin); exactly 1 (+ rounding) for a rigid view
-    double m[3][3], tr = 0.0, gersh = 0.0;
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            m[i][j] = 0.0;
-            for (int k = 0; k < 3; ++k) m[i][j] += (double)view[i * 4 + k] * (double)view[j * 4 + k];
-        }
-    for (int i = 0; i < 3; ++i) {
-        tr += m[i][i];
-        gersh = std::max(gersh, std::fabs(m[i][0]) + std::fabs(m[i][1]) + std::fabs(m[i][2]));
-    }
-    fp.w_norm2 = (float)(std::min(tr, gersh) * (1.0 + 1e-5));
-    return fp;
 }
 
 // Renderer::recordCommandBuffer (Renderer.cpp:540-629): stage order + the 7 timestamp points.
@@ -299,7 +204,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
                 if (ordered) launch_tile_order(fps, c->ranges, c->tile_order, st);
                 return si;
             });
-            if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+            if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: the radix passes could not be enqueued (hipGraphLaunch failed or sort buffers of another digit width)");
             c->sorted_index = sorted;
             ranges_done = true;
         } else {
@@ -307,7 +212,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
             if (int r = check_launch(c, "InitSortList")) return r;
             HIP_TRY(c, hipEventRecord(c->pre_ev[0], st));
             const int presorted = radix_passes(c->presort_graph, c->presort_result, depth_passes);
-            if (presorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+            if (presorted < 0) return fail(c, GS_ERR_HIP, "gs_render: the radix passes could not be enqueued (hipGraphLaunch failed or sort buffers of another digit width)");
             if (int r = check_launch(c, "RadixSort")) return r;
             HIP_TRY(c, hipEventRecord(c->pre_ev[1], st));
             launch_gather_sorted(fps, c->scratch, c->sort, presorted, st);
@@ -315,7 +220,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
             if (int r = check_launch(c, "InitSortList")) return r;
             HIP_TRY(c, hipEventRecord(c->pre_ev[2], st));
             const int sorted = radix_passes(c->sort_graph, c->sort_graph_result, tile_passes);
-            if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+            if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: the radix passes could not be enqueued (hipGraphLaunch failed or sort buffers of another digit width)");
             c->sorted_index = sorted;
         }
     } else {
@@ -335,12 +240,12 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
                 if (ordered) launch_tile_order(fp, c->ranges, c->tile_order, st);
                 return si;
             });
-            if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+            if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: the radix passes could not be enqueued (hipGraphLaunch failed or sort buffers of another digit width)");
             c->sorted_index = sorted;
             ranges_done = true;
         } else {
             const int sorted = radix_passes(c->sort_graph, c->sort_graph_result, all_passes);
-            if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: hipGraphLaunch failed");
+            if (sorted < 0) return fail(c, GS_ERR_HIP, "gs_render: the radix passes could not be enqueued (hipGraphLaunch failed or sort buffers of another digit width)");
             c->sorted_index = sorted;
         }
     }
@@ -482,9 +387,20 @@ int finish_frame(gs_ctx* c) {
 
 extern "C" {
 
+uint32_t gs_api_version(void) { return GS_API_VERSION; }
+
+int gs_runtime_versions(int* hip_build, int* hip_runtime, int* hip_driver) {
+    if (hip_build) *hip_build = HIP_VERSION;
+    int v = 0;
+    if (hip_runtime) { if (hipRuntimeGetVersion(&v) != hipSuccess) return GS_ERR_HIP; *hip_runtime = v; }
+    if (hip_driver) { if (hipDriverGetVersion(&v) != hipSuccess) return GS_ERR_HIP; *hip_driver = v; }
+    return GS_OK;
+}
+
 void gs_default_config(gs_config* cfg) {
     if (!cfg) return;
     std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (uint32_t)sizeof(*cfg);
     cfg->device_ordinal = 0;
     cfg->tile_size = 16;            // Renderer.h:146
     cfg->near_plane = 0.1f;         // Camera.cpp:4
@@ -503,7 +419,16 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
     if (!out) return fail(nullptr, GS_ERR_INVALID, "gs_create: out is null");
     *out = nullptr;
     gs_config cfg;
-    if (cfg_in) cfg = *cfg_in; else gs_default_config(&cfg);
+    gs_default_config(&cfg);
+    if (cfg_in) {
+        // struct_size says how much of the struct the caller's header knows: fields beyond it keep their defaults, a
+        // struct from a NEWER header than this library is refused instead of being read past what is understood
+        if (cfg_in->struct_size < offsetof(gs_config, tile_order) + sizeof(uint32_t) || cfg_in->struct_size > sizeof(gs_config))
+            return fail(nullptr, GS_ERR_INVALID, "gs_create: gs_config.struct_size does not match this library (call gs_default_config first; "
+                                                 "compare GS_API_VERSION with gs_api_version())");
+        std::memcpy(&cfg, cfg_in, cfg_in->struct_size);
+        cfg.struct_size = (uint32_t)sizeof(cfg);
+    }
     if (cfg.tile_size != 16) return fail(nullptr, GS_ERR_INVALID, "gs_create: only tile_size 16 is supported");
     if (cfg.sort_algorithm > GS_SORT_RADIX8_SPLAT_FIRST) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown sort_algorithm");
     if (cfg.render_mode > GS_RENDER_FAST) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown render_mode");
@@ -577,6 +502,7 @@ int gs_destroy(gs_ctx* c) {
     if (!c) return GS_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->dist_comm) (void)gs_dist_destroy(c);
     free_resolution(c);
     free_scene(c);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -615,6 +541,8 @@ static int alloc_scratch(gs_ctx* c, uint32_t n) {
     HIP_TRY(c, hipMemsetAsync(c->scratch.block_sums, 0, padded * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->scratch.block_offsets, 0, padded * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->scratch.raster, 0, N * sizeof(SplatRaster), c->stream));
+    HIP_TRY(c, hipMalloc((void**)&c->scratch.wave_wrote, (size_t)c->num_blocks * 4));
+    HIP_TRY(c, hipMemsetAsync(c->scratch.wave_wrote, 0, (size_t)c->num_blocks * 4, c->stream));
     HIP_TRY(c, hipMalloc((void**)&c->scratch.help_list, (size_t)kEmitHelpCap * sizeof(uint2)));
     HIP_TRY(c, hipMalloc((void**)&c->scratch.help_count, 4 * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void**)&c->scratch.band_list, (size_t)c->num_blocks * sizeof(uint32_t)));
@@ -943,8 +871,13 @@ int gs_debug_read(gs_ctx* c, int which, void* dst, size_t bytes) {
                 HIP_TRY(c, hipMemcpy(opacity.data(), c->scene.opacity, (size_t)c->n * sizeof(float), hipMemcpyDeviceToHost));
                 HIP_TRY(c, hipMemcpy(touched.data(), c->scratch.tiles_touched, (size_t)c->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
             }
-            std::vector<float> outv((size_t)c->n * 4);
+            // records of a wave (64 consecutive splats) that k_project did not store this frame -- wholly culled, or with
+            // nothing to emit into this context's tile rows -- read back as zero, what a culled splat's scratch holds
+            std::vector<uint8_t> wrote((size_t)c->num_blocks * 4);
+            HIP_TRY(c, hipMemcpy(wrote.data(), c->scratch.wave_wrote, wrote.size(), hipMemcpyDeviceToHost));
+            std::vector<float> outv((size_t)c->n * 4, 0.0f);
             for (uint32_t i = 0; i < c->n; ++i) {
+                if (!wrote[i / 64u]) continue;
                 const SplatRaster& r = host[i];
                 float* o = &outv[(size_t)i * 4];
                 if (which == GS_BUF_COLOR) { o[0] = r.r; o[1] = r.g; o[2] = r.b; o[3] = touched[i] ? opacity[i] : 0.0f; }
@@ -1023,6 +956,7 @@ int gs_sort_host(gs_ctx* c, uint32_t* tile, uint32_t* depth, uint32_t* id, uint3
         si = launch_radix_sort(sb, n, num_sort_bits, c->stream, nullptr, 0u, false, false, 1.0f, 0, 0, nullptr,
                                digit_bits_of(c->cfg.sort_algorithm));
         e = hipGetLastError();
+        if (si < 0) { free_sort(sb); return fail(c, GS_ERR_INVALID, "gs_sort_host: sort buffers of another digit width"); }
     }
     if (e == hipSuccess) e = hipMemcpyAsync(tile, sb.hi[si], bytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(depth, sb.lo[si], bytes, hipMemcpyDeviceToHost, c->stream);
@@ -1055,6 +989,7 @@ int gs_sort_bench(gs_ctx* c, uint32_t n, uint32_t num_tiles, uint32_t iters, uin
         if (e != hipSuccess) break;
         si = launch_radix_sort(sb, n, bits, c->stream, nullptr, 0u, false, false, 1.0f, 0, 0, nullptr,
                                digit_bits_of(c->cfg.sort_algorithm));
+        if (si < 0) { si = 0; e = hipErrorInvalidValue; break; }
         e = hipEventRecord(e1, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         float ms = 0.0f;
@@ -1075,139 +1010,6 @@ int gs_sort_bench(gs_ctx* c, uint32_t n, uint32_t num_tiles, uint32_t iters, uin
     if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_sort_bench: ") + hipGetErrorString(e));
     *ms_per_sort = total_ms / (float)iters;
     if (sorted_ok) *sorted_ok = bad_host == 0 ? 1u : 0u;
-    return GS_OK;
-}
-
-// Tuning only (not declared in gsplat.h): re-runs RenderGaussians of the last frame with per-tile
-// counters; out = uint32[tiles][8] {list length, splats visited, splats needing exp, clock ticks, entries staged, 0, 0, 0}.
-int gs_debug_render_stats(gs_ctx* c, const float* view, const float* proj, const float* cam_pos, uint32_t* out) {
-    if (!c || !out || !c->have_frame) return GS_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
-    const FrameParams fp = make_frame_params(c, view, proj, cam_pos, 0);
-    const size_t tiles = (size_t)c->grid_w * c->grid_h;
-    uint4* d = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&d, tiles * 2 * sizeof(uint4)));
-    HIP_TRY(c, hipMemsetAsync(d, 0, tiles * 2 * sizeof(uint4), c->stream));
-    launch_render_stats(fp, c->scratch.raster, c->sort.id[c->sorted_index], c->ranges, c->framebuffer, d, c->stream);
-    hipError_t e = hipMemcpyAsync(out, d, tiles * 2 * sizeof(uint4), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
-    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_debug_render_stats: ") + hipGetErrorString(e));
-    return GS_OK;
-}
-
-// Tuning only (not declared in gsplat.h): microseconds per dependent step of `workgroups` x 256 threads that each move
-// bytes_per_wg bytes written by another workgroup in the step before -- persistent = 0: one kernel launch per step (a
-// hipGraph replay of `steps` launches, as the frame replays its radix passes); persistent = 1: ONE launch with a
-// device-wide counter barrier (release / acquire at agent scope) between the steps.  timed_out = 1 when the persistent
-// grid was not wholly resident and a bounded spin gave up (the number is then meaningless).
-int gs_sync_probe(gs_ctx* c, int persistent, uint32_t workgroups, uint32_t steps, uint32_t bytes_per_wg, uint32_t iters,
-                  float* us_per_step, uint32_t* timed_out) {
-    if (!c || !us_per_step || !timed_out || workgroups == 0 || steps == 0 || iters == 0) return GS_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
-    const uint32_t per_wg = bytes_per_wg / 16u;
-    const size_t bytes = std::max<size_t>(16, (size_t)workgroups * per_wg * 16);
-    void *a = nullptr, *b = nullptr;
-    uint32_t* flags = nullptr;             // [0] barrier counter, [1] timed out
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipGraphExec_t exec = nullptr;
-    hipError_t e = hipMalloc(&a, bytes);
-    if (e == hipSuccess) e = hipMalloc(&b, bytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&flags, 8);
-    if (e == hipSuccess) e = hipMemsetAsync(a, 1, bytes, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(b, 2, bytes, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(flags, 0, 8, c->stream);
-    if (e == hipSuccess) e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess && !persistent) {
-        hipGraph_t graph = nullptr;
-        e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
-        if (e == hipSuccess) {
-            for (uint32_t s = 0; s < steps; ++s) launch_probe_step((s & 1u) ? b : a, (s & 1u) ? a : b, workgroups, per_wg, s, c->stream);
-            e = hipStreamEndCapture(c->stream, &graph);
-        }
-        if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        if (graph) (void)hipGraphDestroy(graph);
-    }
-    float ms = 0.0f;
-    uint32_t host_flags[2] = {0u, 0u};
-    for (uint32_t it = 0; it < iters + 2u && e == hipSuccess; ++it) {          // two warm-up rounds
-        if (it == 2u) e = hipEventRecord(e0, c->stream);
-        if (persistent) {
-            if (e == hipSuccess) e = hipMemsetAsync(flags, 0, 4, c->stream);   // the counter; the flag stays
-            launch_probe_persistent(a, b, workgroups, per_wg, steps, flags, flags + 1, c->stream);
-        } else if (e == hipSuccess) {
-            e = hipGraphLaunch(exec, c->stream);
-        }
-    }
-    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    if (e == hipSuccess && persistent) e = hipMemcpy(host_flags, flags, 8, hipMemcpyDeviceToHost);
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (a) (void)hipFree(a);
-    if (b) (void)hipFree(b);
-    if (flags) (void)hipFree(flags);
-    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_sync_probe: ") + hipGetErrorString(e));
-    *us_per_step = ms * 1000.0f / (float)iters / (float)steps;
-    *timed_out = host_flags[1];
-    return GS_OK;
-}
-
-// Tuning only: microseconds of one launch of `workgroups` workgroups that each issue `lines` 16-lane atomic adds (add = 1) or plain
-// stores (add = 0) to rows of a rows x 16 counter table; stride_num / stride_den workgroups share a starting row.
-int gs_atomic_probe(gs_ctx* c, uint32_t workgroups, uint32_t lines, uint32_t rows, uint32_t stride_num, uint32_t stride_den, uint32_t add,
-                    uint32_t iters, float* us_per_launch) {
-    if (!c || !us_per_launch || !workgroups || !rows || !stride_den || !iters) return GS_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
-    uint32_t* table = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipError_t e = hipMalloc((void**)&table, (size_t)rows * 64);
-    if (e == hipSuccess) e = hipMemsetAsync(table, 0, (size_t)rows * 64, c->stream);
-    if (e == hipSuccess) e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    float ms = 0.0f;
-    if (e == hipSuccess) {
-        for (int w = 0; w < 3; ++w) launch_probe_atomics(table, rows, workgroups, lines, stride_num, stride_den, add, c->stream);
-        e = hipEventRecord(e0, c->stream);
-        for (uint32_t i = 0; i < iters; ++i) launch_probe_atomics(table, rows, workgroups, lines, stride_num, stride_den, add, c->stream);
-        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (table) (void)hipFree(table);
-    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_atomic_probe: ") + hipGetErrorString(e));
-    *us_per_launch = ms * 1000.0f / (float)iters;
-    return GS_OK;
-}
-
-// Tuning only (tools/lds_probe.py): microseconds per launch of k_probe_lds.
-int gs_lds_probe(gs_ctx* c, uint32_t kind, uint32_t reps, uint32_t iters, float* us_per_launch) {
-    if (!c || !us_per_launch || kind > 6u || !iters || reps > 64u) return GS_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
-    uint32_t* out = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipError_t e = hipMalloc((void**)&out, (size_t)512 * 512 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    float ms = 0.0f;
-    if (e == hipSuccess) {
-        for (int w = 0; w < 3; ++w) launch_probe_lds(out, kind, reps, c->stream);
-        e = hipEventRecord(e0, c->stream);
-        for (uint32_t i = 0; i < iters; ++i) launch_probe_lds(out, kind, reps, c->stream);
-        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (out) (void)hipFree(out);
-    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_lds_probe: ") + hipGetErrorString(e));
-    *us_per_launch = ms * 1000.0f / (float)iters;
     return GS_OK;
 }
 

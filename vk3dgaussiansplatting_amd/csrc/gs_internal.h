@@ -117,6 +117,8 @@ struct SplatScratch {
     uint32_t* depth_key;     // [N]
     uint32_t* tiles_touched; // [N]  0 for culled / zero-extent splats
     uint2* extents;          // [N]  packed u16: .x = minx | miny<<16, .y = maxx | maxy<<16 (row-clamped)
+    uint8_t* wave_wrote;     // [4 * ceil(N/kProjThreads)]  1: this frame's k_project stored the raster records of the wave's
+                             //       64 splats (else they are stale / zero: gs_debug_read zero-fills them)
     uint32_t* block_sums;    // [ceil(N/kProjThreads)]  tile counts per project workgroup
     uint32_t* block_offsets; // same size, exclusive scan
     // k_emit load balance: a project workgroup whose 256 splats emit more than kEmitSlice elements registers one
@@ -155,6 +157,7 @@ struct SortBuffers {
     uint32_t* coarse;                // [kMaxSortPasses][16][kCoarse]  per-pass digit counts of the coarse segments
                                      // (8-bit digits: the first 256 words of a pass's slab = its digit totals)
     SortParams* params;
+    uint32_t digit_bits;             // what alloc_sort sized table / seg_sum for (4 or 8): the launchers refuse the other width
 };
 
 // Bytes of the depth word a radix pass reads / writes per element (k_scatter<LO_IN, LO_OUT, HI16>); shared by the
@@ -192,6 +195,7 @@ void launch_emit_sorted(const FrameParams& fp, const SplatScratch& sc, const Sor
 // hi16: the hi arrays hold 16-bit tile ids (frame path, at most 65535 owned tiles).
 // start: the ping-pong buffer the list lies in; coarse_pass: first slab of sb.coarse to use (one per pass; two sorts
 // in one frame must not share slabs); params: dispatch record of this list (default sb.params).
+// Returns -1 without launching anything when digit_bits is not the width sb was allocated for.
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events = nullptr, uint32_t first_bit = 0,
                       bool drop_depth_payload = false, bool hi16 = false, float share = 1.0f,
@@ -219,15 +223,6 @@ void launch_aos_to_soa(const float* chunk, uint32_t first, uint32_t count, uint3
                        const SceneBuffers& s, hipStream_t stream);
 void launch_block_bounds(uint32_t n, const SceneBuffers& s, hipStream_t stream);
 void launch_stream_probe(int kind, const void* src, void* dst, size_t bytes, uint32_t blocks, hipStream_t stream);
-// tuning only (gs_sync_probe)
-void launch_probe_step(const void* src, void* dst, uint32_t workgroups, uint32_t per_wg, uint32_t step, hipStream_t stream);
-void launch_probe_atomics(uint32_t* table, uint32_t rows, uint32_t workgroups, uint32_t lines, uint32_t stride_num, uint32_t stride_den,
-                          uint32_t add, hipStream_t stream);
-void launch_probe_lds(uint32_t* out, uint32_t kind, uint32_t reps, hipStream_t stream);   // out: 512 x 512 words
-void launch_probe_persistent(void* a, void* b, uint32_t workgroups, uint32_t per_wg, uint32_t steps, uint32_t* counter,
-                             uint32_t* timed_out, hipStream_t stream);
-void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
-                         const uint32_t* ranges, uint8_t* rgba, uint4* stats, hipStream_t stream);
 // helpers for the stand-alone sorter entry points
 void launch_set_sort_params(SortParams* params, uint32_t* coarse, uint32_t n, hipStream_t stream);
 void launch_fill_random_keys(uint32_t* lo, uint32_t* hi, uint32_t* id, uint32_t n,

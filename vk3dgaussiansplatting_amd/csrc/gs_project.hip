@@ -278,7 +278,11 @@ __global__ __launch_bounds__(kCullThreads) void k_band_cull(const FrameParams fp
     const uint32_t mask = (uint32_t)(__ballot(skip) >> (lane & ~3)) & 0xFu;     // the four waves of my block
     const bool leader = (lane & 3) == 0 && b < num_blocks;
     const bool survives = leader && mask != 0xFu;
-    if (leader && !survives) { sc.block_sums[b] = 0u; if (fp.splat_first) sc.block_flags[b] = 0u; }
+    if (leader && !survives) {
+        sc.block_sums[b] = 0u;
+        if (fp.splat_first) sc.block_flags[b] = 0u;
+        reinterpret_cast<uint32_t*>(sc.wave_wrote)[b] = 0u;           // none of its four waves writes records this frame
+    }
     // one returning atomic per workgroup (on one address they complete at about 90 per microsecond)
     const uint64_t vote = __ballot(survives);
     if (lane == 0) s_cnt[wave] = (uint32_t)__builtin_popcountll(vote);
@@ -329,6 +333,7 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
     }
     const uint32_t g = blk * kProjThreads + threadIdx.x;
     uint32_t count = 0;
+    bool kept = false;                                                          // passed both culls: its record is stored (N6)
     float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0;   // culled splats: zero record
 
     if (g < n && !wave_skip) {
@@ -362,98 +367,99 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
                     band_skip = misses_owned_rows(fp, sy_b - rmax, sy_b + rmax);
                 }
                 if (!band_skip) {
-                float scale[3], rot[4], cov[3];
+                    float scale[3], rot[4], cov[3];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) scale[a] = scene.scale[a * (size_t)n + g];
+                    for (int a = 0; a < 3; ++a) scale[a] = scene.scale[a * (size_t)n + g];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) rot[a] = scene.rot[a * (size_t)n + g];
-                get_covariance(fp, scale, rot, vp, cov);              // :113-120
+                    for (int a = 0; a < 4; ++a) rot[a] = scene.rot[a * (size_t)n + g];
+                    get_covariance(fp, scale, rot, vp, cov);              // :113-120
 
-                // getScreenSpacePosition, Common.glsl:80-89 (same proj*viewPos and division as above)
-                float sx = ndc_x, sy = -ndc_y;
-                sx = (sx + 1.0f) * 0.5f;
-                sy = (sy + 1.0f) * 0.5f;
-                sx = sx * (float)fp.width;
-                sy = sy * (float)fp.height;
+                    // getScreenSpacePosition, Common.glsl:80-89 (same proj*viewPos and division as above)
+                    float sx = ndc_x, sy = -ndc_y;
+                    sx = (sx + 1.0f) * 0.5f;
+                    sy = (sy + 1.0f) * 0.5f;
+                    sx = sx * (float)fp.width;
+                    sy = sy * (float)fp.height;
 
-                // getGaussianTileExtents, InitSortList.comp:47-68
-                const float det = cov[0] * cov[2] - cov[1] * cov[1];
-                const float m = (cov[0] + cov[2]) * 0.5f;
-                const float lambda0 = m + sqrtf(maxf(m * m - det, 0.0f));
-                const float lambda1 = m - sqrtf(maxf(m * m - det, 0.0f));
-                const float radius = ceilf(3.0f * sqrtf(maxf(lambda0, lambda1)));
-                const int gw = (int)fp.grid_w, gh = (int)fp.grid_h;
-                const int min_x = clampi(f2i_sat((sx - radius) / 16.0f), 0, gw);
-                const int min_y = clampi(f2i_sat((sy - radius) / 16.0f), 0, gh);
-                int tx = f2i_sat((sx + radius) / 16.0f);
-                int ty = f2i_sat((sy + radius) / 16.0f);
-                const int max_x = clampi(tx == 2147483647 ? tx : tx + 1, 0, gw);
-                const int max_y = clampi(ty == 2147483647 ? ty : ty + 1, 0, gh);
+                    // getGaussianTileExtents, InitSortList.comp:47-68
+                    const float det = cov[0] * cov[2] - cov[1] * cov[1];
+                    const float m = (cov[0] + cov[2]) * 0.5f;
+                    const float lambda0 = m + sqrtf(maxf(m * m - det, 0.0f));
+                    const float lambda1 = m - sqrtf(maxf(m * m - det, 0.0f));
+                    const float radius = ceilf(3.0f * sqrtf(maxf(lambda0, lambda1)));
+                    const int gw = (int)fp.grid_w, gh = (int)fp.grid_h;
+                    const int min_x = clampi(f2i_sat((sx - radius) / 16.0f), 0, gw);
+                    const int min_y = clampi(f2i_sat((sy - radius) / 16.0f), 0, gh);
+                    int tx = f2i_sat((sx + radius) / 16.0f);
+                    int ty = f2i_sat((sy + radius) / 16.0f);
+                    const int max_x = clampi(tx == 2147483647 ? tx : tx + 1, 0, gw);
+                    const int max_y = clampi(ty == 2147483647 ? ty : ty + 1, 0, gh);
 
-                // tile rows of this context (multi-GPU) as compact indices [k0, k1); identity for [0, grid_h)
-                int y0 = min_y > (int)fp.row_begin ? min_y : (int)fp.row_begin;
-                int y1 = max_y < (int)fp.row_end ? max_y : (int)fp.row_end;
-                if (y1 < y0) y1 = y0;
-                const int k0 = owned_rows_below(fp, y0), k1 = owned_rows_below(fp, y1);
-                count = (uint32_t)(max_x - min_x) * (uint32_t)(k1 - k0);   // :130
+                    // tile rows of this context (multi-GPU) as compact indices [k0, k1); identity for [0, grid_h)
+                    int y0 = min_y > (int)fp.row_begin ? min_y : (int)fp.row_begin;
+                    int y1 = max_y < (int)fp.row_end ? max_y : (int)fp.row_end;
+                    if (y1 < y0) y1 = y0;
+                    const int k0 = owned_rows_below(fp, y0), k1 = owned_rows_below(fp, y1);
+                    count = (uint32_t)(max_x - min_x) * (uint32_t)(k1 - k0);   // :130
 
-                // :126-127.  The reference stores colour + covariance for every non-culled splat (N6).
-                // Colour is only ever read by RenderGaussians through the sorted list, so for a splat
-                // that emits no element here (off-screen inside the 1.3 NDC cull margin, or outside this
-                // context's tile-row band) the 192-byte SH read and the colour evaluation are skipped:
-                // unobservable in keys, ranges and pixels (SURVEY "F" list).
-                rec0 = make_float4(sx, sy, 0.0f, 0.0f);
-                rec2 = make_float4(0.0f, cov[0], cov[1], cov[2]);
-                if (count != 0u) {
-                    // RenderGaussians.comp:94-107, once per splat instead of once per (tile, splat): the inverse of
-                    // the 2x2 covariance (IEEE reciprocal, then three products) and the zero-determinant rule
-                    float opacity = scene.opacity[g];
-                    float inv_x = 0.0f, inv_y = 0.0f, inv_z = 0.0f;
-                    if (det != 0.0f) {
-                        const float det_inv = 1.0f / det;                  // :99
-                        inv_x = cov[2] * det_inv;                          // :100
-                        inv_y = -cov[1] * det_inv;
-                        inv_z = cov[0] * det_inv;
-                    } else {
-                        opacity = 0.0f;                                    // :104
+                    // :126-127.  The reference stores colour + covariance for every non-culled splat (N6).
+                    // Colour is only ever read by RenderGaussians through the sorted list, so for a splat
+                    // that emits no element here (off-screen inside the 1.3 NDC cull margin, or outside this
+                    // context's tile-row band) the 192-byte SH read and the colour evaluation are skipped:
+                    // unobservable in keys, ranges and pixels (SURVEY "F" list).
+                    kept = true;
+                    rec0 = make_float4(sx, sy, 0.0f, 0.0f);
+                    rec2 = make_float4(0.0f, cov[0], cov[1], cov[2]);
+                    if (count != 0u) {
+                        // RenderGaussians.comp:94-107, once per splat instead of once per (tile, splat): the inverse of
+                        // the 2x2 covariance (IEEE reciprocal, then three products) and the zero-determinant rule
+                        float opacity = scene.opacity[g];
+                        float inv_x = 0.0f, inv_y = 0.0f, inv_z = 0.0f;
+                        if (det != 0.0f) {
+                            const float det_inv = 1.0f / det;                  // :99
+                            inv_x = cov[2] * det_inv;                          // :100
+                            inv_y = -cov[1] * det_inv;
+                            inv_z = cov[0] * det_inv;
+                        } else {
+                            opacity = 0.0f;                                    // :104
+                        }
+                        rec0.z = inv_x; rec0.w = inv_y;
+                        rec2.x = opacity;
+                        // colour, InitSortList.comp:124-126 + Common.glsl:141-170
+                        const float ddx = px - fp.cam_pos[0], ddy = py - fp.cam_pos[1], ddz = pz - fp.cam_pos[2];
+                        const float len = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+                        float basis[16];
+                        sh_eval4(ddx / len, ddy / len, ddz / len, basis);
+                        float res[3] = {0.0f, 0.0f, 0.0f};
+                        const float* shp = scene.sh + g;
+                        if (fp.sh_mode == 0u) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                                for (int c = 0; c < 3; ++c)
+                                    res[c] = res[c] + shp[(size_t)(i * 3 + c) * n] * basis[i];
+                        } else if (fp.sh_mode == 1u) {
+#pragma unroll
+                            for (int i = 1; i < 16; ++i)
+#pragma unroll
+                                for (int c = 0; c < 3; ++c)
+                                    res[c] = res[c] + shp[(size_t)(i * 3 + c) * n] * basis[i];
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) res[c] = res[c] - 0.5f;
+                        } else if (fp.sh_mode == 2u) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) res[c] = res[c] + shp[(size_t)c * n] * basis[0];
+                        }
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            res[c] = res[c] + 0.5f;
+                            res[c] = maxf(res[c], 0.0f);
+                        }
+                        rec1 = make_float4(inv_z, res[0], res[1], res[2]);
+                        sc.depth_key[g] = depth_key;
+                        sc.extents[g] = make_uint2((uint32_t)min_x | ((uint32_t)k0 << 16),
+                                                   (uint32_t)max_x | ((uint32_t)k1 << 16));
                     }
-                    rec0.z = inv_x; rec0.w = inv_y;
-                    rec2.x = opacity;
-                    // colour, InitSortList.comp:124-126 + Common.glsl:141-170
-                    const float ddx = px - fp.cam_pos[0], ddy = py - fp.cam_pos[1], ddz = pz - fp.cam_pos[2];
-                    const float len = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
-                    float basis[16];
-                    sh_eval4(ddx / len, ddy / len, ddz / len, basis);
-                    float res[3] = {0.0f, 0.0f, 0.0f};
-                    const float* shp = scene.sh + g;
-                    if (fp.sh_mode == 0u) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i)
-#pragma unroll
-                            for (int c = 0; c < 3; ++c)
-                                res[c] = res[c] + shp[(size_t)(i * 3 + c) * n] * basis[i];
-                    } else if (fp.sh_mode == 1u) {
-#pragma unroll
-                        for (int i = 1; i < 16; ++i)
-#pragma unroll
-                            for (int c = 0; c < 3; ++c)
-                                res[c] = res[c] + shp[(size_t)(i * 3 + c) * n] * basis[i];
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) res[c] = res[c] - 0.5f;
-                    } else if (fp.sh_mode == 2u) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) res[c] = res[c] + shp[(size_t)c * n] * basis[0];
-                    }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        res[c] = res[c] + 0.5f;
-                        res[c] = maxf(res[c], 0.0f);
-                    }
-                    rec1 = make_float4(inv_z, res[0], res[1], res[2]);
-                    sc.depth_key[g] = depth_key;
-                    sc.extents[g] = make_uint2((uint32_t)min_x | ((uint32_t)k0 << 16),
-                                               (uint32_t)max_x | ((uint32_t)k1 << 16));
-                }
                 }   // !band_skip
             }
         }
@@ -468,14 +474,20 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
     // per-workgroup total -> block_sums (input of the scan that replaces the atomic counter)
     const uint32_t wsum = wave_sum_to_lane63(count);
     const uint32_t wflags = (uint32_t)__popcll(__ballot(count != 0u));   // emitting splats (GS_SORT_RADIX4_SPLAT_FIRST)
+    const bool wave_kept = __ballot(kept) != 0ull;
     if (lane_id() == 63) {
         s_wave_sum[wave_id()] = wsum;
         s_wave_flags[wave_id()] = wflags;
-        // A context that owns a tile-row band (multi-GPU) never reads the records of splats that emit nothing
-        // into the band -- RenderGaussians reaches records only through the sorted list -- so a wave whose 64
-        // splats all emit nothing skips its 3 KB of the block (most waves of a narrow band; the arrays are in
-        // Morton order).  With the full grid every record is written as the reference does (N6).
-        s_wave_emits[wave_id()] = (!band || wsum != 0u) ? 1u : 0u;
+        // Which waves write their 3 KB of the block.  RenderGaussians reaches records only through the sorted list, i.e.
+        // those of emitting splats; the reference also stores colour + covariance of every splat that passes the culls
+        // (N6), readable here through gs_debug_read.  Full grid: a wave writes when any of its splats passed the culls
+        // -- a wholly culled wave (a quarter of them at the benchmark pose; the arrays are in Morton order, so culled
+        // splats come in runs) has nothing but zero records to store.  A context that owns a tile-row band: when any of
+        // its splats emits into the band (most waves of a narrow band do not).  wave_wrote tells gs_debug_read which
+        // records are this frame's (the others read back as zero, what a culled splat's scratch holds).
+        const uint32_t wrote = (band ? wsum != 0u : wave_kept) ? 1u : 0u;
+        s_wave_emits[wave_id()] = wrote;
+        sc.wave_wrote[blk * (kProjThreads / 64) + wave_id()] = (uint8_t)wrote;
     }
     __syncthreads();
     {

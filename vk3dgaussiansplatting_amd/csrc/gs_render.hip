@@ -647,6 +647,7 @@ size_t tile_order_words(uint32_t grid_w, uint32_t grid_h) {
     return 2 * all + ((all + kOrderTiles - 1u) / kOrderTiles) * 33u;
 }
 
+#ifdef GS_RENDER_STATS   // tools/probe only: the same kernel with its per-tile counters on
 void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
                          const uint32_t* ranges, uint8_t* rgba, uint4* stats, hipStream_t stream) {
     const uint32_t tiles = fp.rows_owned * fp.grid_w;
@@ -654,6 +655,7 @@ void launch_render_stats(const FrameParams& fp, const SplatRaster* raster, const
     hipLaunchKernelGGL((k_render<true, 4, true>), dim3(tiles), dim3(64), 0, stream, fp, raster, sorted_id,
                        ranges, (const uint32_t*)nullptr, reinterpret_cast<uint32_t*>(rgba), stats);
 }
+#endif
 
 void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint32_t* sorted_id,
                    const uint32_t* ranges, const uint32_t* order, uint8_t* rgba, uint32_t render_mode,

@@ -424,6 +424,7 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
                       hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit,
                       bool drop_depth_payload, bool hi16, float share, int start, uint32_t coarse_pass,
                       const SortParams* params, uint32_t digit_bits) {
+    if (sb.digit_bits != digit_bits) return -1;   // table / seg_sum are sized per digit width (alloc_sort)
     if (digit_bits == 8u)
         return launch_radix_sort8(sb, capacity, num_sort_bits, stream, scatter_events, first_bit, drop_depth_payload, hi16,
                                   share, start, coarse_pass, params);

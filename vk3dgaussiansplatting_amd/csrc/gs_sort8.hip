@@ -366,6 +366,7 @@ void k_scatter8(const SortParams* __restrict__ params, const uint32_t* __restric
 int launch_radix_sort8(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits, hipStream_t stream,
                        hipEvent_t* scatter_events, uint32_t first_bit, bool drop_depth_payload, bool hi16, float share,
                        int start, uint32_t coarse_pass, const SortParams* params) {
+    if (sb.digit_bits != 8u) return -1;           // 4-bit buffers hold 16 x 512 segment words, not 2 x 256 x 512
     if (!params) params = sb.params;
     // Group size by what the list can be expected to hold (the host never reads the element count back): 2048-key groups for
     // short lists -- more workgroups, shorter latency chains -- 4096 for long ones (digit runs twice as long).

@@ -207,126 +207,4 @@ void launch_stream_probe(int kind, const void* src, void* dst, size_t bytes, uin
     }
 }
 
-// ---- hand-off probe (tuning only, gs_sync_probe): what does it cost to hand a small list from one radix stage to the
-//      next -- a kernel boundary per stage, or one persistent launch with a device-wide barrier per stage?  One step =
-//      every workgroup reads `dwords` 16-byte words of ITS slice of `a` written in the previous step by ANOTHER
-//      workgroup (the neighbour: a real cross-workgroup dependency, like a pass reading what the previous pass
-//      scattered) and writes its slice of `b`; a and b swap every step.
-__device__ __forceinline__ void probe_step(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t wg, uint32_t wgs,
-                                           uint32_t per_wg, uint32_t step) {
-    const uint32_t from = (wg + 1u) % wgs;                 // the neighbour's slice
-    for (uint32_t i = threadIdx.x; i < per_wg; i += blockDim.x) {
-        uint4 v = src[(size_t)from * per_wg + i];
-        v.x += step; v.y ^= wg;
-        dst[(size_t)wg * per_wg + i] = v;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_probe_step(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t per_wg, uint32_t step) {
-    probe_step(src, dst, blockIdx.x, gridDim.x, per_wg, step);
-}
-
-// One launch, `steps` steps, a counter barrier between them: every storing wave drains its stores, the workgroup meets,
-// one lane releases (agent scope: the XCD's L2 writes its dirty lines back), arrives, polls the counter with relaxed
-// agent-scope loads and a sleep, acquires (this CU's L1 is invalidated), the workgroup meets again.  Every spin is
-// bounded: a grid that is not wholly resident gives up, flags it and still terminates.
-__global__ __launch_bounds__(256) void k_probe_persistent(uint4* __restrict__ a, uint4* __restrict__ b, uint32_t per_wg, uint32_t steps,
-                                                          uint32_t* __restrict__ counter, uint32_t* __restrict__ timed_out) {
-    uint4* src = a;
-    uint4* dst = b;
-    for (uint32_t s = 0; s < steps; ++s) {
-        probe_step(src, dst, blockIdx.x, gridDim.x, per_wg, s);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t want = (s + 1u) * gridDim.x;
-            uint32_t budget = 400000u;
-            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && --budget) __builtin_amdgcn_s_sleep(2);
-            if (budget == 0u) *timed_out = 1u;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        uint4* t = src; src = dst; dst = t;
-    }
-}
-
-// ---- atomic-rate probe (tuning only, gs_atomic_probe): could a radix Scatter feed the NEXT pass's per-group digit counts with
-//      global atomics instead of a Count launch?  Workgroup w issues `lines` wave instructions of 16 active lanes, each a
-//      non-returning agent-scope add to the 16 consecutive counters of row (w * stride_num / stride_den + k) % rows: with
-//      stride 1/16 sixteen neighbouring workgroups meet on a row, as neighbouring source groups of a pass meet on a destination group.
-__global__ __launch_bounds__(256) void k_probe_atomics(uint32_t* __restrict__ table, uint32_t rows, uint32_t lines, uint32_t stride_num,
-                                                       uint32_t stride_den, uint32_t add) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane >= 16u) return;
-    const uint32_t first = (uint32_t)(((uint64_t)blockIdx.x * stride_num) / stride_den);
-    for (uint32_t k = wave; k < lines; k += 4u) {
-        const uint32_t row = (first + k * 97u) % rows;      // the 16 digits of a group land in 16 runs, i.e. rows far apart
-        if (add) (void)__hip_atomic_fetch_add(&table[(size_t)row * 16u + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else table[(size_t)row * 16u + lane] = k;            // the same addresses with plain stores, for reference
-    }
-}
-void launch_probe_atomics(uint32_t* table, uint32_t rows, uint32_t workgroups, uint32_t lines, uint32_t stride_num, uint32_t stride_den,
-                          uint32_t add, hipStream_t stream) {
-    hipLaunchKernelGGL(k_probe_atomics, dim3(workgroups), dim3(256), 0, stream, table, rows, lines, stride_num, stride_den, add);
-}
-
-// ---- How fast are 256-bin histograms in LDS?  (tuning only: the Count of the 8-bit sorter.)  1024 workgroups of 4 waves;
-//      every lane makes `reps` x 32 updates with digits from a register generator -- no memory loads -- in one of the forms
-//      below, then the counters are summed into out[] so that nothing is optimised away.
-//      kind 0 no LDS (generator only) | 1 ds_add, random digit, one histogram per wave | 2 ds_add, address = lane |
-//      3 ds_add, three digits | 4 plain read-modify-write of the lane's own column of packed byte counters |
-//      5 eight ballots + one ds_add per digit present in the round | 6 like 1 with the returning form
-__global__ __launch_bounds__(256) void k_probe_lds(uint32_t* __restrict__ out, uint32_t kind, uint32_t reps) {
-    __shared__ uint32_t s_h[4][4096];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t* h = s_h[wave];
-    for (uint32_t i = lane; i < 4096u; i += 64u) h[i] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    uint32_t x = (blockIdx.x * 256u + tid) * 2654435761u + 12345u, acc = 0u;
-    for (uint32_t r = 0; r < reps; ++r) {
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            x = x * 1664525u + 1013904223u;
-            const uint32_t d = x >> 24;
-            if (kind == 0u) acc ^= d;
-            else if (kind == 1u) (void)__hip_atomic_fetch_add(&h[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else if (kind == 2u) (void)__hip_atomic_fetch_add(&h[lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else if (kind == 3u) (void)__hip_atomic_fetch_add(&h[d % 3u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else if (kind == 4u) { uint32_t* p = &h[(d >> 2) * 64u + lane]; *p = *p + (1u << (8u * (d & 3u))); }
-            else if (kind == 5u) {
-                uint32_t m_lo = 0xFFFFFFFFu, m_hi = 0xFFFFFFFFu;
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const int32_t sbit = __builtin_amdgcn_sbfe((int32_t)d, (uint32_t)b, 1u);
-                    const uint64_t bal = __ballot(sbit != 0);
-                    m_lo &= ~((uint32_t)bal ^ (uint32_t)sbit);
-                    m_hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)sbit);
-                }
-                const uint64_t same = ((uint64_t)m_hi << 32) | m_lo;
-                if (mbcnt(same) == 0u) (void)__hip_atomic_fetch_add(&h[d], (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else acc += __hip_atomic_fetch_add(&h[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = lane; i < 4096u; i += 64u) acc += h[i];
-    out[blockIdx.x * 256u + tid] = acc;
-}
-void launch_probe_lds(uint32_t* out, uint32_t kind, uint32_t reps, hipStream_t stream) {
-    hipLaunchKernelGGL(k_probe_lds, dim3(1024), dim3(256), 0, stream, out, kind, reps);
-}
-
-void launch_probe_step(const void* src, void* dst, uint32_t workgroups, uint32_t per_wg, uint32_t step, hipStream_t stream) {
-    hipLaunchKernelGGL(k_probe_step, dim3(workgroups), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, per_wg, step);
-}
-void launch_probe_persistent(void* a, void* b, uint32_t workgroups, uint32_t per_wg, uint32_t steps, uint32_t* counter,
-                             uint32_t* timed_out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_probe_persistent, dim3(workgroups), dim3(256), 0, stream, (uint4*)a, (uint4*)b, per_wg, steps, counter, timed_out);
-}
-
 } // namespace gs
