@@ -56,8 +56,9 @@ def parse_args(argv=None):
                     help="radix4 = the contractual nine-stage sort (default); bucket = GS_SORT_TILE_BUCKET; "
                          "splat_first = GS_SORT_RADIX4_SPLAT_FIRST (the same twelve 4-bit passes, the depth ones before "
                          "the splats are replicated into tiles)")
-    ap.add_argument("--render-kernel", default="auto", choices=["auto", "1", "2", "4", "16"],
-                    help="gs_config.render_kernel: auto, 1/2/4 = px per lane with independent waves, 16 = workgroup per tile")
+    ap.add_argument("--render-kernel", default="auto", choices=["auto", "1", "2", "4", "16", "17"],
+                    help="gs_config.render_kernel: auto, 1/2/4 = px per lane with independent waves, 16 / 17 = workgroup per tile "
+                         "(a 16 x 4 strip / an 8 x 8 quadrant per wave)")
     ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2, 3],
                     help="frame slots of the TIMED region (default 1 = a frame's GPU time, like the reference's "
                          "timestamps); the 3-slot throughput is always reported as an extra field")
@@ -76,6 +77,9 @@ def parse_args(argv=None):
     ap.add_argument("--rank-timeout", type=int, default=900,
                     help="N > 1: seconds after which a launch that has not finished is killed (exit code 4); inside a rank "
                          "every collective has a 180 s limit of its own")
+    ap.add_argument("--c-abi-gather", action="store_true",
+                    help="one GPU: also run the C-ABI gather phase (gs_dist_init / gs_gather_strips with a world of one) that "
+                         "N > 1 runs by itself")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: every rank uses cuda:0 and the strip gather goes "
                          "through gloo on the host (RCCL needs one GPU per rank)")
@@ -109,12 +113,22 @@ def launch_ranks(args):
         return 4
 
 
+def _kname(raw):
+    return raw.split("(")[0].replace("void ", "").replace("gs::", "").replace(" ", "")
+
+
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              # SQ pass ("VALU busy from rocprof" for RenderGaussians); one pass, kernel trace only
+              ("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"))
+
+
 def pmc_traffic(args):
-    """HBM bytes per kernel launch, measured in THIS run: two child processes of this script under
+    """Per-kernel hardware counters of a frame, measured in THIS run: child processes of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the two do not fit the TCC counter slots
-    together; FETCH_SIZE is doubled for gfx950 -- MI355X_MICROARCH.md, HBM section), a few frames each, started before
-    this process touches the GPU (fresh children, program directly behind `--`).  Returns {kernel name without
-    spaces: {"launches", "read_bytes", "write_bytes"}} or a string saying why there is no measurement."""
+    together; FETCH_SIZE is doubled for gfx950 -- MI355X_MICROARCH.md, HBM section) and one SQ pass (VALU activity), a
+    few frames each, started before this process touches the GPU (fresh children, program directly behind `--`).
+    Returns {kernel name without spaces: {"launches", "read_bytes", "write_bytes", "trace_us", "valu_busy", ...}} or a
+    string saying why there is no measurement."""
     import csv
     import glob
     import shutil
@@ -129,12 +143,13 @@ def pmc_traffic(args):
     env = dict(os.environ, TMPDIR="/tmp")
     per = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
+        for counters in PMC_PASSES:
+            label = counters[0]
+            out = os.path.join(tmp, label)
             t0 = time.time()
             # a process group of its own: if the profiler gets stuck, the group (rocprofv3 AND the bench child under it) is
             # killed -- ~10 s each normally; never let a stuck profiler cost the run its line
-            proc = subprocess.Popen([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--"] + child,
+            proc = subprocess.Popen([exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--"] + child,
                                     cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
             try:
                 _, err = proc.communicate(timeout=90)
@@ -145,35 +160,49 @@ def pmc_traffic(args):
                 except ProcessLookupError:
                     pass
                 proc.communicate()
-                return f"rocprofv3 --pmc {counter} did not finish within 90 s"
-            r = subprocess.CompletedProcess(proc.args, proc.returncode, None, err)
+                if label.startswith("SQ_"):
+                    log("[bench] the SQ counter pass did not finish within 90 s: no valu_busy")
+                    break
+                return f"rocprofv3 --pmc {label} did not finish within 90 s"
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
+            if proc.returncode != 0 or not files:
+                if label.startswith("SQ_"):                      # informational: the byte counters stand without it
+                    log(f"[bench] the SQ counter pass failed (rc {proc.returncode}): no valu_busy")
+                    break
+                return f"rocprofv3 --pmc {label} failed (rc {proc.returncode}): {err.decode(errors='replace')[-300:]}"
             with open(files[0]) as f:
                 for row in csv.DictReader(f):
-                    k = per.setdefault(row["Kernel_Name"].split("(")[0].replace("void ", "").replace("gs::", "").replace(" ", ""),
-                                       {"FETCH_SIZE": [], "WRITE_SIZE": [], "us": []})
-                    k[counter].append(float(row["Counter_Value"]))
-            # the same run's kernel trace: begin -> end of every launch (what rocprofv3 --stats averages)
-            for tf in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
-                with open(tf) as f:
-                    for row in csv.DictReader(f):
-                        k = per.get(row["Kernel_Name"].split("(")[0].replace("void ", "").replace("gs::", "").replace(" ", ""))
-                        if k is not None:
-                            k["us"].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1000.0)
-            log(f"[bench] rocprofv3 --pmc {counter}: {time.time() - t0:.1f}s")
+                    k = per.setdefault(_kname(row["Kernel_Name"]), {"us": []})
+                    k.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            if not label.startswith("SQ_"):
+                # the same run's kernel trace: begin -> end of every launch (what rocprofv3 --stats averages)
+                for tf in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+                    with open(tf) as f:
+                        for row in csv.DictReader(f):
+                            k = per.get(_kname(row["Kernel_Name"]))
+                            if k is not None:
+                                k["us"].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1000.0)
+            log(f"[bench] rocprofv3 --pmc {' '.join(counters)}: {time.time() - t0:.1f}s")
     except (OSError, subprocess.SubprocessError, KeyError, ValueError) as ex:
         return f"PMC child run failed: {ex!r}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     res = {}
+    mean = lambda v: sum(v) / len(v)
     for k, v in per.items():
-        if v["FETCH_SIZE"] and v["WRITE_SIZE"]:
+        if v.get("FETCH_SIZE") and v.get("WRITE_SIZE"):
             res[k] = {"launches": len(v["FETCH_SIZE"]),
-                      "read_bytes": 2.0 * 1024.0 * sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]),   # KB; x2: gfx950 tallies 128-B requests as 64 B
-                      "write_bytes": 1024.0 * sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]),
-                      "trace_us": sum(v["us"]) / len(v["us"]) if v["us"] else None}
+                      "read_bytes": 2.0 * 1024.0 * mean(v["FETCH_SIZE"]),   # KB; x2: gfx950 tallies 128-B requests as 64 B
+                      "write_bytes": 1024.0 * mean(v["WRITE_SIZE"]),
+                      "trace_us": mean(v["us"]) if v["us"] else None}
+            if v.get("SQ_ACTIVE_INST_VALU") and v.get("GRBM_GUI_ACTIVE"):
+                # VALUBusy = 100 * SQ_ACTIVE_INST_VALU * 4 / SIMDs / cycles: SQ_ACTIVE_INST_* count quad-cycles, 4 x 256
+                # SIMDs, GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (tools/pmc_sq.sh, MI355X_MICROARCH.md)
+                gui = mean(v["GRBM_GUI_ACTIVE"]) / 8.0
+                res[k]["valu_busy"] = 100.0 * mean(v["SQ_ACTIVE_INST_VALU"]) * 4.0 / 1024.0 / gui if gui else None
+                wc = mean(v["SQ_WAVE_CYCLES"]) if v.get("SQ_WAVE_CYCLES") else 0.0
+                if wc and v.get("SQ_WAIT_INST_ANY"):
+                    res[k]["wait_share_of_wave_cycles"] = mean(v["SQ_WAIT_INST_ANY"]) / wc
     return res or "no kernels in the counter files"
 
 
@@ -423,7 +452,7 @@ def main():
 
     # N > 1: the assembled frame must equal what one GPU renders alone (checked once, untimed); the single-GPU
     # render of the same frame is also timed (a few frames), so the line carries its own strong-scaling reference
-    sharded_ok, one_gpu_ms, gather_ms = None, None, None
+    sharded_ok, one_gpu_ms, gather_ms, full = None, None, None, None
     if world > 1:
         with torch.cuda.stream(ring.streams[0]):
             ring.sf.wait(0)
@@ -617,6 +646,64 @@ def main():
                 "note": "same protocol as the headline (one frame slot, image left in HBM); vs_baseline against the same "
                         "README frame (28.499 ms), which was a real capture"}
 
+    # N > 1: the sorters that cut a band's latency floor, as sequential phases every rank enters
+    # together.  Each phase is guarded: a rank whose set-up fails says so in an all_reduce(MIN) and the phase is skipped
+    # EVERYWHERE instead of leaving the others waiting in its collectives.
+    def flag_all(ok):
+        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if args.rehearse else device)
+        tdist.all_reduce(f, op=tdist.ReduceOp.MIN)
+        return bool(int(f.item()))
+
+    def alt_phase(name):
+        ra, err = None, None
+        try:
+            ra = Ring(1, sort=name, owner=owner)
+        except Exception as ex:  # noqa: BLE001
+            err = repr(ex)
+        if not flag_all(err is None):
+            if ra is not None:
+                ra.close()
+            return {"skipped": err or "set-up failed on another rank"}
+        with torch.cuda.stream(ra.streams[0]):
+            ra.sf.wait(0)
+            ra.rs[0].drawDevice(scene, ra.ptrs[0], sync=False, compact_rows=interleaved)
+            strips_a = ra.sf.gather(0)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ra.sf.assemble(strips_a).to(full.device), full)) if rank == 0 else None
+        ms_a = ra.timed(min(args.steps, 200), 10)
+        ra.close()
+        one_a = None
+        if rank == 0:                                  # the same frame on one GPU alone with this sorter
+            rf_ = make(1, sort=name, share=owner)
+            rf_.setStream(torch.cuda.current_stream().cuda_stream)
+            tot_ = []
+            for i in range(13):
+                rf_.drawDevice(scene, full.data_ptr(), sync=True)
+                if i >= 3:
+                    tot_.append(rf_.timings().total_ms)
+            one_a = float(np.mean(tot_))
+            rf_.setStream(None)
+            rf_.cleanup()
+        tdist.barrier()
+        return {"ms_per_step": round(ms_a, 4), "value": round(n / ms_a / 1000.0, 2), "unit": "Msplats/s",
+                "sharded_image_matches_single_gpu": same,
+                "one_gpu_same_frame_ms": round(one_a, 4) if one_a else None,
+                "speedup_vs_one_gpu_same_frame": round(one_a / ms_a, 3) if one_a else None,
+                "speedup_vs_one_gpu_default_sorter": round(one_gpu_ms / ms_a, 3) if one_gpu_ms else None}
+
+    if not args.no_extras and world > 1:
+        alt = {}
+        for name in ("radix8_splat_first", "bucket", "splat_first"):
+            if name != args.sort:
+                try:
+                    alt[name] = alt_phase(name)
+                except Exception as ex:  # noqa: BLE001 -- past the guard: report, the headline is already measured
+                    log(f"[bench] alt sorter phase '{name}' failed on rank {rank}: {ex!r}")
+                    alt[name] = {"error": repr(ex)}
+        extras["alt_sorters"] = alt
+        extras["alt_sorters_note"] = ("the same sharded frame with the opt-in sorters (identical keys, ranges, pixels), timed as the headline "
+                                      "(one frame slot, gather included, slowest rank); the contract's 4-bit passes stay the headline")
+
     # extras run collectives of their own (Ring.timed): with several ranks one rank failing inside an extra would leave
     # the others waiting in it, so they are a one-GPU feature
     if not args.no_extras and world == 1:
@@ -632,8 +719,47 @@ def main():
             extra("fast_render_mode", x_fast_render)
         if args.config == "C":
             extra("hard_cloud", x_hard_cloud)
-    owner.setStream(None)
-    owner.cleanup()
+    # V of SURVEY 8(d) (splats that pass both culls): every one of them has a covariance with the +0.3 dilation in it
+    survivors = None
+    if world == 1 and n <= 12_000_000:
+        try:
+            owner.drawDevice(scene, strip_ptr, sync=True)
+            survivors = int(np.count_nonzero(owner.debugRead(gs.BUF_COV)[:, 0]))
+        except Exception as ex:  # noqa: BLE001 -- informational
+            log(f"[bench] survivor count failed: {ex!r}")
+
+    def x_hbm_resident():
+        # The depth-word Scatter of config C reads + writes 219 MiB per launch: it fits the 256 MiB Infinity Cache, so
+        # part of `roofline.frac` is served on-die.  Config D is the SAME cloud at 3840 x 2160 (E = 33.1 M, 550 MiB per
+        # launch): the same kernel, measured in this run on the same uploaded scene, outside the cache.
+        cfg_d = synth.CONFIGS["D"]
+        assert (cfg_d["n"], cfg_d["mu"], cfg_d["seed"]) == (cfg["n"], cfg["mu"], cfg["seed"])
+        rd = gs.Renderer(cfg_d["width"], cfg_d["height"], device=local_rank, render_mode=mode, record_timings=2, warmup_frames=0,
+                         sort_algorithm=sort_ids[args.sort])
+        rd.init(rm)
+        rd.initForScene(scene, share_with=owner)
+        rd.setStream(torch.cuda.current_stream().cuda_stream)
+        sc_ms, k_d = 0.0, 20
+        for i in range(3 + k_d):
+            rd.drawDevice(scene, None, sync=True)
+            if i >= 3:
+                sc_ms += rd.timings().scatter_ms_avg
+        td = rd.timings()
+        rd.setStream(None)
+        rd.cleanup()
+        sc_ms /= k_d
+        e_d, per_elem = int(td.num_sort_elements), float(td.scatter_bytes_per_elem)
+        gbps = per_elem * e_d / (sc_ms * 1e-3) / 1e9
+        return {"workload": WORKLOADS["D"], "sort_elements": e_d, "kernel": "the depth-word Scatter launches (as roofline.kernel)",
+                "avg_launch_ms": round(sc_ms, 5), "launches_per_frame": int(td.scatter_launches),
+                "bytes_per_launch": per_elem * e_d, "basis": "moved",
+                "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                "infinity_cache_resident": bool(per_elem * e_d < IC_BYTES),
+                "note": "bytes the layout reads + writes per launch (at config C the PMC counters see 1.00 x that figure: "
+                        "roofline.traffic / roofline.moved.bytes_per_launch) over the HIP-event mean of those launches"}
+
+    if not args.no_extras and world == 1 and args.config == "C" and args.sort in ("radix4", "radix8"):
+        extra("hbm_resident", x_hbm_resident)
 
     # per-rank numbers to rank 0
     stats = torch.tensor([e_rank, scat, *buckets, local_rank if not args.rehearse else 0],
@@ -799,6 +925,43 @@ def main():
                 "moved": {"bytes_per_element": moved_tile, "achieved": round(mv, 1),
                           "frac_of_peak": round(mv / HBM_PEAK_GBPS, 4),
                           "frac_of_measured_copy": round(mv / copy_gbps, 4) if copy_gbps else None}}
+        # ---- every stage against its roofline: algorithmic bytes B_init / B_sort / B_ranges / B_render, the
+        #      HBM bytes the PMC counters saw for the stage's kernels per frame, and the stage's bucket (rank 0)
+        tiles_own = int(info.tiles_x) * int(info.rows_owned)
+        px_own = w * min(h, int(info.rows_owned) * 16) if world > 1 else w * h
+        v_alg = survivors if survivors is not None else 0.75 * n
+        n_passes = passes_full + passes_tile
+        stage_defs = {
+            "init_sort_list": (12.0 * n + 252.0 * v_alg + 12.0 * e_rank, "12 N + 252 V + 12 E", float(buckets[0]),
+                               ("k_band_cull", "k_project", "k_scan_blocks", "k_emit", "k_splat_list", "k_sorted_sums")),
+            "radix_sort": (32.0 * n_passes * e_rank, f"32 P E, P = {n_passes}", float(buckets[1]), ("k_count", "k_scatter", "k_scan8")),
+            "find_ranges": (4.0 * e_rank + 8.0 * tiles_own, "4 E + 8 T", float(buckets[2]), ("k_find_ranges", "k_tile_classes", "k_tile_scatter")),
+            "render": (44.0 * e_rank + 8.0 * tiles_own + 4.0 * px_own, "44 E + 8 T + 4 W H", float(buckets[3]), ("k_render",)),
+        }
+        frames_pmc = sum(v["launches"] for k, v in pmc.items() if k.startswith("k_project")) if isinstance(pmc, dict) else 0
+        stages = {}
+        for name, (alg, formula, ms, prefixes) in stage_defs.items():
+            tr = None
+            if frames_pmc:
+                tr = sum(v["launches"] * (v["read_bytes"] + v["write_bytes"]) for k, v in pmc.items() if k.startswith(prefixes)) / frames_pmc
+            st = {"ms": round(ms, 4), "algorithmic_bytes": round(alg), "formula": formula,
+                  "algorithmic_GBps": round(rate(alg, ms), 1), "frac_algorithmic": round(rate(alg, ms) / HBM_PEAK_GBPS, 4),
+                  "pmc_bytes": round(tr) if tr else None,
+                  "pmc_GBps": round(rate(tr, ms), 1) if tr else None,
+                  "frac_pmc": round(rate(tr, ms) / HBM_PEAK_GBPS, 4) if tr else None}
+            if name == "render" and isinstance(pmc, dict):
+                rk = [v for k, v in pmc.items() if k.startswith("k_render") and v.get("valu_busy") is not None]
+                if rk:
+                    st["valu_busy"] = round(sum(v["valu_busy"] * v["launches"] for v in rk) / sum(v["launches"] for v in rk), 1)
+                    st["valu_busy_note"] = ("100 x SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) over the RenderGaussians "
+                                            "launches of a third rocprofv3 --pmc child; the stage is VALU-issue-bound, not HBM-bound")
+            stages[name] = st
+        roofline["stages"] = stages
+        roofline["stages_note"] = ("per stage: SURVEY 8(d)'s algorithmic bytes (N = gaussians, V = splats passing both culls"
+                                   + (f" = {survivors} counted this run" if survivors is not None else " ~ 0.75 N assumed")
+                                   + f", E = {e_rank} sort elements, T = tiles, P = passes) and the HBM bytes rocprofv3 --pmc FETCH_SIZE x2 + "
+                                   "WRITE_SIZE counted for the stage's kernels per frame, each over the stage's bucket of buckets_ms (hipEvents "
+                                   "at the reference's timestamp points) and over the 8 TB/s peak")
         out = {
             "metric": "Msplats/s + total frame ms (InitSortList/RadixSort/FindRanges/Render split)",
             "value": round(value, 2), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
@@ -848,8 +1011,98 @@ def main():
             out["cpu_baseline"] = cpu_baseline(aos, cfg, oracle)
         if world > 1 and sharded_ok is False:
             out["error"] = "the frame assembled from the ranks' strips differs from the frame one GPU renders alone"
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    else:
+        out = None
+
+    # ---- the same gather through the C-ABI (gs_dist_init / gs_gather_strips: RCCL bound by the library itself, grouped
+    #      ncclSend / ncclRecv on the context's stream) -- what a C++ host uses (tools/gsplat_bench.cpp --ranks N).  Last,
+    #      and under a watchdog: no N-GPU box is reachable while this is written, and a communicator of our own that hangs
+    #      must cost the run this block, not its line.
+    def emit_line():
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    if (world > 1 and not args.rehearse and not args.no_extras) or args.c_abi_gather:
+        import ctypes as C
+        import threading
+        from vk3dgaussiansplatting_amd import _lib
+        L = _lib.lib()
+
+        def give_up():
+            log(f"[bench] rank {rank}: the C-ABI gather phase did not finish within 120 s: giving it up")
+            if rank == 0:
+                out["c_abi_gather"] = {"error": "timed out after 120 s (the line above it is complete)"}
+                emit_line()
+            os._exit(0 if sharded_ok is not False else 3)
+        dog = threading.Timer(120.0, give_up)
+        dog.daemon = True
+        dog.start()
+        res = {}
+        try:
+            ident = C.create_string_buffer(_lib.DIST_UNIQUE_ID_BYTES)
+            if rank == 0 and L.gs_dist_unique_id(ident) != 0:
+                raise RuntimeError("gs_dist_unique_id failed")
+            box = [ident.raw if rank == 0 else None]
+            if world > 1:
+                tdist.broadcast_object_list(box, src=0)
+            rc_ = make(0, share=owner)
+            set_rows(rc_, sf_main)
+            st_c = torch.cuda.Stream(device=device)
+            rc_.setStream(st_c.cuda_stream)
+            ok_init = L.gs_dist_init(rc_._ctx.handle, box[0], rank, world) == 0
+            if not ok_init:
+                log(f"[bench] rank {rank}: gs_dist_init: {L.gs_last_error(rc_._ctx.handle).decode()}")
+            if not (flag_all(ok_init) if world > 1 else ok_init):
+                res = {"skipped": "gs_dist_init failed on a rank"}
+            else:
+                strip = sf_main.strips[0]
+                nbytes = strip.numel()
+                gathered = torch.zeros((world,) + tuple(strip.shape), dtype=torch.uint8, device=device) if rank == 0 else None
+
+                def frame_and_gather():
+                    rc_.drawDevice(scene, strip_ptr, sync=False, compact_rows=interleaved)
+                    r_ = L.gs_gather_strips(rc_._ctx.handle, strip.data_ptr(), gathered.data_ptr() if rank == 0 else None, nbytes, 0)
+                    if r_ != 0:
+                        raise RuntimeError(L.gs_last_error(rc_._ctx.handle).decode())
+                torch.cuda.synchronize()
+                for _ in range(3):
+                    frame_and_gather()
+                rc_.synchronize()
+                same = None
+                if rank == 0:
+                    img_c = sf_main.assemble([gathered[r_] for r_ in range(world)])
+                    if full is not None:
+                        same = bool(torch.equal(img_c, full))
+                    else:                                   # one rank: the strip is the frame
+                        same = bool(torch.equal(gathered[0], strip))
+                k_c = min(args.steps, 200)
+                if world > 1:
+                    tdist.barrier()
+                t_c = time.perf_counter()
+                for _ in range(k_c):
+                    frame_and_gather()
+                rc_.synchronize()
+                el_c = torch.tensor([(time.perf_counter() - t_c) / k_c * 1e3], dtype=torch.float64, device=device)
+                if world > 1:
+                    tdist.all_reduce(el_c, op=tdist.ReduceOp.MAX)
+                ms_c = float(el_c.item())
+                res = {"ms_per_step": round(ms_c, 4), "value": round(n / ms_c / 1000.0, 2), "unit": "Msplats/s",
+                       "assembled_frame_matches": same,
+                       "note": "frame + gs_gather_strips on the context's stream, one frame slot, no overlap of the gather with the "
+                               "next frame (the headline double-buffers its strips); slowest rank"}
+                L.gs_dist_destroy(rc_._ctx.handle)
+            rc_.setStream(None)
+            rc_.cleanup()
+        except Exception as ex:  # noqa: BLE001
+            log(f"[bench] rank {rank}: C-ABI gather phase failed: {ex!r}")
+            res = {"error": repr(ex)}
+        dog.cancel()
+        if rank == 0:
+            out["c_abi_gather"] = res
+    owner.setStream(None)
+    owner.cleanup()
+    emit_line()
     if world > 1:
         tdist.barrier()
         tdist.destroy_process_group()

@@ -73,7 +73,8 @@ typedef struct gs_ctx gs_ctx;
 #define GS_RENDER_KERNEL_WAVE_2PX 2u   /* two independent waves per tile, 2 pixels per lane */
 #define GS_RENDER_KERNEL_WAVE_4PX 4u   /* one wave per tile, 4 pixels per lane */
 #define GS_RENDER_KERNEL_WORKGROUP 16u /* one 256-thread workgroup per tile, one pixel per lane (the reference's launch shape);
-                                          its four waves walk the tile's list independently */
+                                          its four waves walk the tile's list independently, each for a 16 x 4 strip */
+#define GS_RENDER_KERNEL_WORKGROUP_8X8 17u /* the same with an 8 x 8 quadrant per wave */
 
 /* Order in which RenderGaussians' tiles are dispatched (same pixels either way). */
 #define GS_TILE_ORDER_LONGEST_FIRST 0u /* by list length, longest first: one small launch behind FindRanges (default) */

@@ -647,6 +647,28 @@ def test_extreme_but_finite_inputs(oracle_mod):
         r.cleanup()
 
 
+@pytest.mark.parametrize("kernel", [gs.GS_RENDER_KERNEL_AUTO, gs.GS_RENDER_KERNEL_WORKGROUP, gs.GS_RENDER_KERNEL_WAVE_2PX,
+                                    gs.GS_RENDER_KERNEL_WAVE_1PX])
+def test_exponent_range_of_the_pinned_exp(oracle_mod, kernel):
+    """The blend loop evaluates the pinned exp in a cheaper form than oracle/gs_oracle.c's gso_exp (one max instead of
+    two clamps, round-to-nearest by a magic add, ldexp as an integer add to the exponent field): same bits wherever the
+    result is used.  Opacities far outside [0, 1] push that claim to its edges -- 1e30 keeps lanes live down to f = -74.6
+    (n = -108 in the exponent add), a negative opacity makes the skip threshold NaN so that EVERY f <= 0 is live,
+    including exponents of -1e10 that only the lower clamp keeps finite -- and the frame must still be the oracle's."""
+    w, h = 208, 120
+    aos = synth.generate(2500, w, h, -2.2, seed=41)
+    rng = np.random.default_rng(3)
+    aos[:, 15] = rng.choice(np.float32([0.9, 1e30, -0.5, 300.0, 3e-3, 1e-30]), aos.shape[0], p=[0.6, 0.01, 0.3, 0.01, 0.04, 0.04])
+    aos[::5, 4:7] *= np.float32(0.02)                      # tiny footprints: exponents of -1e4 .. -1e10 a pixel away
+    sc = make_scene(aos, w, h, pos=(0.2, -0.1, -1.0), yaw=0.1, pitch=-0.05)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    assert np.isfinite(ref["stage1"]["color"]).all()
+    r = make_renderer(sc, w, h, kernel=kernel)
+    img = r.draw(sc)
+    assert_frame_equals_oracle(r, img, ref)
+    r.cleanup()
+
+
 def test_c_abi_call_order_status_codes(small_cloud):
     """Straight through ctypes: wrong call order is reported, never fatal."""
     import ctypes as C
@@ -932,7 +954,7 @@ def test_sort_stress_sortedness(n, sorter):
 
 
 @pytest.mark.parametrize("kernel", [gs.GS_RENDER_KERNEL_WAVE_1PX, gs.GS_RENDER_KERNEL_WAVE_2PX,
-                                    gs.GS_RENDER_KERNEL_WAVE_4PX, gs.GS_RENDER_KERNEL_WORKGROUP])
+                                    gs.GS_RENDER_KERNEL_WAVE_4PX, gs.GS_RENDER_KERNEL_WORKGROUP, gs.GS_RENDER_KERNEL_WORKGROUP_8X8])
 def test_every_render_launch_shape_is_bit_exact(oracle_mod, kernel):
     """gs_config.render_kernel only changes how a tile maps to waves: same pixels as the oracle for the full
     frame (ragged right/bottom tiles), for a tile-row band, with sh modes, and FAST stays within one step."""
@@ -963,7 +985,8 @@ def test_every_render_launch_shape_is_bit_exact(oracle_mod, kernel):
     rf.cleanup()
 
 
-@pytest.mark.parametrize("kernel", [gs.GS_RENDER_KERNEL_WAVE_1PX, gs.GS_RENDER_KERNEL_WAVE_4PX, gs.GS_RENDER_KERNEL_WORKGROUP])
+@pytest.mark.parametrize("kernel", [gs.GS_RENDER_KERNEL_WAVE_1PX, gs.GS_RENDER_KERNEL_WAVE_4PX, gs.GS_RENDER_KERNEL_WORKGROUP,
+                                    gs.GS_RENDER_KERNEL_WORKGROUP_8X8])
 def test_tile_dispatch_order_does_not_change_pixels(oracle_mod, kernel):
     """gs_config.tile_order: longest list first (default, k_tile_order behind FindRanges) and raster order render the
     oracle's frame -- whole frame, a contiguous band and interleaved rows (the order table indexes the OWNED tiles)."""
@@ -1184,7 +1207,7 @@ def test_randomized_frames(oracle_mod):
     # GS_RANDOM_CASES / GS_RANDOM_SEED: a longer or different run of the same generator (one-off soak, not the suite)
     rng = np.random.default_rng(int(os.environ.get("GS_RANDOM_SEED", "20240807")))
     kernels = [gs.GS_RENDER_KERNEL_AUTO, gs.GS_RENDER_KERNEL_WAVE_1PX, gs.GS_RENDER_KERNEL_WAVE_2PX,
-               gs.GS_RENDER_KERNEL_WAVE_4PX, gs.GS_RENDER_KERNEL_WORKGROUP]
+               gs.GS_RENDER_KERNEL_WAVE_4PX, gs.GS_RENDER_KERNEL_WORKGROUP, gs.GS_RENDER_KERNEL_WORKGROUP_8X8]
     for case in range(int(os.environ.get("GS_RANDOM_CASES", "60"))):
         n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 2047, 2048, 2049, 4000, 6000]))
         w, h = int(rng.integers(1, 500)), int(rng.integers(1, 300))

@@ -8,7 +8,7 @@ the synthetic cloud generator used by tests and bench, and the multi-GPU tile-ro
 from . import _lib
 from ._lib import (GS_OK, GS_WARN_OVERFLOW, GS_RENDER_EXACT, GS_RENDER_FAST, GS_SORT_RADIX4,
                    GS_RENDER_KERNEL_AUTO, GS_RENDER_KERNEL_WAVE_1PX, GS_RENDER_KERNEL_WAVE_2PX,
-                   GS_RENDER_KERNEL_WAVE_4PX, GS_RENDER_KERNEL_WORKGROUP,
+                   GS_RENDER_KERNEL_WAVE_4PX, GS_RENDER_KERNEL_WORKGROUP, GS_RENDER_KERNEL_WORKGROUP_8X8,
                    GS_SORT_TILE_BUCKET, GS_SORT_RADIX4_SPLAT_FIRST, GS_SORT_RADIX8, GS_SORT_RADIX8_SPLAT_FIRST,
                    GS_TILE_ORDER_LONGEST_FIRST,
                    GS_TILE_ORDER_RASTER, GsplatLibraryMissing,

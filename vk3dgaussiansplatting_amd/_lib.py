@@ -25,7 +25,7 @@ GS_ERR_NO_DEVICE = -6
 GS_RENDER_EXACT = 0
 GS_RENDER_FAST = 1
 GS_RENDER_KERNEL_AUTO, GS_RENDER_KERNEL_WAVE_1PX, GS_RENDER_KERNEL_WAVE_2PX = 0, 1, 2
-GS_RENDER_KERNEL_WAVE_4PX, GS_RENDER_KERNEL_WORKGROUP = 4, 16
+GS_RENDER_KERNEL_WAVE_4PX, GS_RENDER_KERNEL_WORKGROUP, GS_RENDER_KERNEL_WORKGROUP_8X8 = 4, 16, 17
 GS_TILE_ORDER_LONGEST_FIRST, GS_TILE_ORDER_RASTER = 0, 1
 GS_SORT_RADIX4 = 0
 GS_SORT_TILE_BUCKET = 1

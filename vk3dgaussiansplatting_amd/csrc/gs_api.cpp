@@ -434,7 +434,7 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
     if (cfg.render_mode > GS_RENDER_FAST) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown render_mode");
     if (cfg.render_kernel != GS_RENDER_KERNEL_AUTO && cfg.render_kernel != GS_RENDER_KERNEL_WAVE_1PX &&
         cfg.render_kernel != GS_RENDER_KERNEL_WAVE_2PX && cfg.render_kernel != GS_RENDER_KERNEL_WAVE_4PX &&
-        cfg.render_kernel != GS_RENDER_KERNEL_WORKGROUP)
+        cfg.render_kernel != GS_RENDER_KERNEL_WORKGROUP && cfg.render_kernel != GS_RENDER_KERNEL_WORKGROUP_8X8)
         return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown render_kernel");
     if (cfg.tile_order > GS_TILE_ORDER_RASTER) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown tile_order");
     int count = 0;

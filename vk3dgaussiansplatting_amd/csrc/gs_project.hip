@@ -485,7 +485,10 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
         // splats come in runs) has nothing but zero records to store.  A context that owns a tile-row band: when any of
         // its splats emits into the band (most waves of a narrow band do not).  wave_wrote tells gs_debug_read which
         // records are this frame's (the others read back as zero, what a culled splat's scratch holds).
-        const uint32_t wrote = (band ? wsum != 0u : wave_kept) ? 1u : 0u;
+#ifndef GS_PROJECT_WRITE_ALL
+#define GS_PROJECT_WRITE_ALL 0      /* tuning: 1 = a full-grid frame stores every wave's records, as before round 4 */
+#endif
+        const uint32_t wrote = (band ? wsum != 0u : (GS_PROJECT_WRITE_ALL || wave_kept)) ? 1u : 0u;
         s_wave_emits[wave_id()] = wrote;
         sc.wave_wrote[blk * (kProjThreads / 64) + wave_id()] = (uint8_t)wrote;
     }

@@ -112,6 +112,56 @@ __device__ __forceinline__ v2f exp_pinned2(v2f x) {
     return (v2f){__builtin_ldexpf(p.x, (int)n.x), __builtin_ldexpf(p.y, (int)n.y)};
 }
 
+// exp_pinned2 for the blend loop, same bits with 14 instead of 22 instructions per pair.  What differs is only HOW the
+// same values are produced:
+//   * the two clamps of gso_exp (t > -126 ? t : -126; t < 126 ? t : 126) are one v_max_f32 per component: the upper
+//     clamp cannot trigger where the result is used (a live lane has f <= 0, so t <= 0), and IEEE maxnum(NaN, -126) is
+//     -126, which is what `NaN > -126 ? NaN : -126` gives;
+//   * n = rint(t) as (t + 1.5 * 2^23) - 1.5 * 2^23 (round to nearest even, exact for |t| <= 126);
+//   * ldexp(p, n) as an integer add of n to p's exponent field -- the low bits of t + 1.5 * 2^23 ARE n, and
+//     (bits << 23) keeps exactly n << 23 (mod 2^32): p lies in [0.70, 1.42] and n >= -126, where n = -126 only comes
+//     with r >= 0, i.e. p >= 1, so the exponent field never reaches 0 and the product is exact like ldexp's.
+// Lanes whose exponent failed the f tests compute garbage here; blend_entry never looks at it.
+__device__ __forceinline__ v2f exp_pinned2_live(v2f x) {
+    v2f t = x * (v2f){0x1.715476p+0f, 0x1.715476p+0f};
+    t.x = __builtin_fmaxf(t.x, -126.0f);
+    t.y = __builtin_fmaxf(t.y, -126.0f);
+    const v2f magic = {12582912.0f, 12582912.0f};
+    const v2f tn = t + magic;
+    const v2f n = tn - magic;
+    const v2f r = t - n;
+    v2f p = {0x1.42059ap-13f, 0x1.42059ap-13f};
+    p = __builtin_elementwise_fma(p, r, (v2f){0x1.5f3e12p-10f, 0x1.5f3e12p-10f});
+    p = __builtin_elementwise_fma(p, r, (v2f){0x1.3b2d40p-7f, 0x1.3b2d40p-7f});
+    p = __builtin_elementwise_fma(p, r, (v2f){0x1.c6aeeap-5f, 0x1.c6aeeap-5f});
+    p = __builtin_elementwise_fma(p, r, (v2f){0x1.ebfbdcp-3f, 0x1.ebfbdcp-3f});
+    p = __builtin_elementwise_fma(p, r, (v2f){0x1.62e430p-1f, 0x1.62e430p-1f});
+    p = __builtin_elementwise_fma(p, r, (v2f){1.0f, 1.0f});
+    return (v2f){__uint_as_float(__float_as_uint(p.x) + (__float_as_uint(tn.x) << 23)),
+                 __uint_as_float(__float_as_uint(p.y) + (__float_as_uint(tn.y) << 23))};
+}
+
+__device__ __forceinline__ float exp_pinned_live(float x) {            // the scalar form of exp_pinned2_live
+    const float t = __builtin_fmaxf(x * 0x1.715476p+0f, -126.0f);
+    const float tn = t + 12582912.0f;
+    const float r = t - (tn - 12582912.0f);
+    float p = 0x1.42059ap-13f;
+    p = __builtin_fmaf(p, r, 0x1.5f3e12p-10f);
+    p = __builtin_fmaf(p, r, 0x1.3b2d40p-7f);
+    p = __builtin_fmaf(p, r, 0x1.c6aeeap-5f);
+    p = __builtin_fmaf(p, r, 0x1.ebfbdcp-3f);
+    p = __builtin_fmaf(p, r, 0x1.62e430p-1f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    return __uint_as_float(__float_as_uint(p) + (__float_as_uint(tn) << 23));
+}
+#ifdef GS_RENDER_EXP_CLAMPS
+#define GS_EXP1 exp_pinned
+#define GS_EXP2 exp_pinned2
+#else
+#define GS_EXP1 exp_pinned_live
+#define GS_EXP2 exp_pinned2_live
+#endif
+
 struct Fetched {
     float4 a, b, c;   // raw SplatRaster
     bool valid;
@@ -134,11 +184,11 @@ __device__ __forceinline__ Fetched fetch_splat(const SplatRaster* __restrict__ r
     return f;
 }
 
-// True when no pixel of the rectangle [x0, x0 + 15] x [y0, y0 + rows_m1] can reach the exponent fthr for the
+// True when no pixel of the rectangle [x0, x0 + cols_m1] x [y0, y0 + rows_m1] can reach the exponent fthr for the
 // conic (ix, iy, iz) centred at (sx, sy).  See stage_splat.
 __device__ __forceinline__ bool rect_unreachable(float sx, float sy, float ix, float iy, float iz, float fthr,
-                                                 float x0, float y0, float rows_m1) {
-    const float u0 = sx - (x0 + 15.0f), u1 = sx - x0;                               // u range (u0 <= u1)
+                                                 float x0, float y0, float rows_m1, float cols_m1 = 15.0f) {
+    const float u0 = sx - (x0 + cols_m1), u1 = sx - x0;                             // u range (u0 <= u1)
     const float v0 = y0 - sy, v1 = y0 + rows_m1 - sy;                               // v range
     bool reject = false;
     if (ix > 0.0f && iz > 0.0f && !(u0 <= 0.0f && u1 >= 0.0f && v0 <= 0.0f && v1 >= 0.0f)) {
@@ -166,7 +216,7 @@ __device__ __forceinline__ bool rect_unreachable(float sx, float sy, float ix, f
 // exponent below which alpha < 1/255 is certain, and an exact rejection of splats that cannot touch the pixel
 // rectangle [tile_x0, tile_x0 + 15] x [tile_y0, tile_y0 + rows_m1].  Returns false when the splat can be dropped;
 // fthr goes to the slot beside alpha (nxt.c.y).
-__device__ __forceinline__ bool stage_splat(Fetched& nxt, float tile_x0, float tile_y0, float rows_m1) {
+__device__ __forceinline__ bool stage_splat(Fetched& nxt, float tile_x0, float tile_y0, float rows_m1, float cols_m1 = 15.0f) {
     bool keep = false;
     if (nxt.valid) {
         const float sx = nxt.a.x, sy = nxt.a.y;
@@ -186,7 +236,7 @@ __device__ __forceinline__ bool stage_splat(Fetched& nxt, float tile_x0, float t
         // closed-form clamped minimiser.  If -q_min/2, widened by a generous bound on the fp32 error of the
         // per-pixel f, is below the skip threshold, every pixel would `continue` (:127): dropping the splat is
         // unobservable.
-        keep = !rect_unreachable(sx, sy, ix, iy, iz, fthr, tile_x0, tile_y0, rows_m1);
+        keep = !rect_unreachable(sx, sy, ix, iy, iz, fthr, tile_x0, tile_y0, rows_m1, cols_m1);
     }
     return keep;
 }
@@ -310,7 +360,7 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
                 for (int q = 0; q < 2; ++q) {
                     const int k0 = 2 * q, k1 = 2 * q + 1;
                     if (!__any(need[k0] || need[k1])) continue;
-                    const v2f alpha = (v2f){ga, ga} * exp_pinned2((v2f){f[k0], f[k1]});      // :124
+                    const v2f alpha = (v2f){ga, ga} * GS_EXP2((v2f){f[k0], f[k1]});          // :124
                     const bool act0 = need[k0] && !(alpha.x < 1.0f / 255.0f);                // :127
                     const bool act1 = need[k1] && !(alpha.y < 1.0f / 255.0f);
                     const v2f Tv = {T[k0], T[k1]};
@@ -337,7 +387,7 @@ __global__ __launch_bounds__(64) void k_render(const FrameParams fp,
             for (int k = 0; k < PX; ++k) {
                 if (PX > 1 && !__any(need[k])) continue;
                 float alpha;
-                if constexpr (EXACT) alpha = ga * exp_pinned(f[k]);    // :124
+                if constexpr (EXACT) alpha = ga * GS_EXP1(f[k]);       // :124
                 else alpha = ga * __builtin_amdgcn_exp2f(f[k] * 0x1.715476p+0f);
                 const bool act = need[k] && !(alpha < 1.0f / 255.0f);  // :127
                 const float wgt = T[k] * alpha;                        // :131
@@ -419,40 +469,44 @@ __device__ __forceinline__ void blend_entry(bool need, float alpha, float cr, fl
     T = (act && !fin) ? next_t : T;                                    // :142
 }
 
-// Two list entries (slots ja, jb of the staged batch; jb == ja and two == false for a single one) against one pixel per
-// lane: their exponents, the pinned exp and alpha are evaluated side by side in the two halves of packed fp32
-// instructions (v_pk_mul / v_pk_add / v_pk_fma are IEEE per component, so each half goes through exactly the scalar
-// operation sequence of RenderGaussians.comp:119-124), then the two blends run one after the other in list order
-// (:127-142 is a chain through T).  `two` is wave-uniform.
+// Two list entries (the pair `pair` of the staged batch; two == false when the batch ends on a single one: the second
+// half of the pair's slots then holds stale values that nothing looks at) against one pixel per lane: their exponents,
+// the pinned exp and alpha are evaluated side by side in the two halves of packed fp32 instructions (v_pk_mul /
+// v_pk_add / v_pk_fma are IEEE per component, so each half goes through exactly the scalar operation sequence of
+// RenderGaussians.comp:119-124), then the two blends run one after the other in list order (:127-142 is a chain
+// through T).  `two` is wave-uniform.  The batch lies in LDS pair-interleaved -- {sx_a, sx_b, sy_a, sy_b}, {ix_a, ix_b,
+// iy_a, iy_b}, {iz_a, iz_b, alpha_a, alpha_b}, {thr_a, thr_b, r_a, r_b}, {g_a, g_b, b_a, b_b} -- so that five 16-byte
+// reads deliver every operand as the register pair a packed instruction wants (entry-major slots cost ten v_mov per
+// step to build those pairs: 8 % of the loop).
+constexpr int kPairQuads = 5;
 template <bool EXACT>
-__device__ __forceinline__ void blend_pair(const float4 (*batch)[3], int ja, int jb, bool two, float fpx, float fpy,
+__device__ __forceinline__ void blend_pair(const float4* pairs, int pair, bool two, float fpx, float fpy,
                                            float& col0, float& col1, float& col2, float& T, bool& done) {
-    const float4 a0 = batch[ja][0], a1 = batch[ja][1];
-    const float2 a2 = *reinterpret_cast<const float2*>(&batch[ja][2]);
-    const float4 b0 = batch[jb][0], b1 = batch[jb][1];
-    const float2 b2 = *reinterpret_cast<const float2*>(&batch[jb][2]);
-    const v2f ex = (v2f){a0.x, b0.x} - (v2f){fpx, fpx};                          // :119
-    const v2f ey = -((v2f){a0.y, b0.y} - (v2f){fpy, fpy});                       // :119-120
-    const v2f ixv = {a0.z, b0.z}, iyv = {a0.w, b0.w}, izv = {a1.x, b1.x};
+    const float4* q = pairs + pair * kPairQuads;
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const v2f ex = (v2f){q0.x, q0.y} - (v2f){fpx, fpx};                          // :119
+    const v2f ey = -((v2f){q0.z, q0.w} - (v2f){fpy, fpy});                       // :119-120
+    const v2f ixv = {q1.x, q1.y}, iyv = {q1.z, q1.w}, izv = {q2.x, q2.y};
     v2f f;
     if constexpr (EXACT) {
         f = (v2f){-0.5f, -0.5f} * (ixv * ex * ex + izv * ey * ey) - iyv * ex * ey;   // :123
     } else {
-        const v2f q = __builtin_elementwise_fma(ixv * ex, ex, izv * ey * ey);
-        f = __builtin_elementwise_fma((v2f){-0.5f, -0.5f}, q, -(iyv * ey * ex));
+        const v2f qq = __builtin_elementwise_fma(ixv * ex, ex, izv * ey * ey);
+        f = __builtin_elementwise_fma((v2f){-0.5f, -0.5f}, qq, -(iyv * ey * ex));
     }
-    const bool live_a = !(f.x > 0.0f) && !(f.x < a2.y);
-    const bool live_b = two && !(f.y > 0.0f) && !(f.y < b2.y);
-    if (!__any(!done && (live_a || live_b))) return;                   // nobody in these rows can pass :127
+    const bool live_a = !(f.x > 0.0f) && !(f.x < q3.x);
+    const bool live_b = two && !(f.y > 0.0f) && !(f.y < q3.y);
+    if (__builtin_amdgcn_ballot_w64(!done && (live_a || live_b)) == 0ull) return;   // nobody in these rows can pass :127
+    const float4 q4 = q[4];
     v2f alpha;
     if constexpr (EXACT) {
-        alpha = (v2f){a2.x, b2.x} * exp_pinned2(f);                    // :124
+        alpha = (v2f){q2.z, q2.w} * GS_EXP2(f);                        // :124
     } else {
         const v2f t = f * (v2f){0x1.715476p+0f, 0x1.715476p+0f};
-        alpha = (v2f){a2.x, b2.x} * (v2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        alpha = (v2f){q2.z, q2.w} * (v2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
     }
-    blend_entry<EXACT>(!done && live_a, alpha.x, a1.y, a1.z, a1.w, col0, col1, col2, T, done);
-    blend_entry<EXACT>(!done && live_b, alpha.y, b1.y, b1.z, b1.w, col0, col1, col2, T, done);
+    blend_entry<EXACT>(!done && live_a, alpha.x, q3.z, q4.x, q4.z, col0, col1, col2, T, done);
+    blend_entry<EXACT>(!done && live_b, alpha.y, q3.w, q4.y, q4.w, col0, col1, col2, T, done);
 }
 
 // One 256-thread workgroup per tile, one pixel per lane -- the reference's own launch shape (RenderGaussians.comp:
@@ -464,14 +518,16 @@ __device__ __forceinline__ void blend_pair(const float4 (*batch)[3], int ja, int
 // which is what the shared 256-entry batch of the shader (and of this kernel until round 3) costs on long lists
 // (profiles/r03_render_variants.txt: sharing the first 1, 2, 3, 4 or all batches loses 3 / 7 / 12 / 18 / 27 % on the
 // capture-like cloud and 15 - 22 % on the uniform one, although every entry is then gathered four times).
-template <bool EXACT>
+// QUAD: wave w owns the 8 x 8 quadrant (w & 1, w >> 1) of the tile instead of the 16 x 4 strip w -- 20 % less perimeter,
+// so fewer list entries survive a wave's rectangle test (gs_config.render_kernel = GS_RENDER_KERNEL_WORKGROUP_8X8).
+template <bool EXACT, bool QUAD>
 __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
                                                     const SplatRaster* __restrict__ raster,
                                                     const uint32_t* __restrict__ sorted_id,
                                                     const uint32_t* __restrict__ ranges,
                                                     const uint32_t* __restrict__ order,
                                                     uint32_t* __restrict__ rgba) {
-    __shared__ float4 s_batch[256][3];     // {sx, sy, inv.x, inv.y}, {inv.z, r, g, b}, {a, skip threshold, -, -}; 64 slots per wave
+    __shared__ float4 s_batch[4][32 * kPairQuads];   // per wave: 32 pairs of staged entries, pair-interleaved (blend_pair)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tile_in_band = order ? order[blockIdx.x] : blockIdx.x;   // longest lists first (k_tile_classes, k_tile_scatter)
@@ -481,25 +537,31 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
     const uint32_t tile_index = ty * fp.grid_w + tx;                   // :74-76
     const uint32_t start = ranges[tile_index * 2 + 0];                 // :77
     const uint32_t end = ranges[tile_index * 2 + 1];
-    const uint32_t py = ty * kTile + (uint32_t)wave * 4u + (uint32_t)(lane >> 4);
-    const uint32_t px = tx * kTile + (uint32_t)(lane & 15);
+    // this lane's pixel inside the tile, and the first row / column of the wave's rectangle
+    const uint32_t wy0 = QUAD ? (uint32_t)(wave >> 1) * 8u : (uint32_t)wave * 4u, wx0 = QUAD ? (uint32_t)(wave & 1) * 8u : 0u;
+    const uint32_t ly = wy0 + (QUAD ? (uint32_t)(lane >> 3) : (uint32_t)(lane >> 4));
+    const uint32_t py = ty * kTile + ly;
+    const uint32_t px = tx * kTile + wx0 + (QUAD ? (uint32_t)(lane & 7) : (uint32_t)(lane & 15));
     const float fpx = (float)px, fpy = (float)py;                      // integer pixel coords (R1)
-    const float tile_x0 = (float)(tx * kTile), wave_y0 = (float)(ty * kTile + (uint32_t)wave * 4u);
+    const float tile_x0 = (float)(tx * kTile + wx0), wave_y0 = (float)(ty * kTile + wy0);
+    constexpr float kRowsM1 = QUAD ? 7.0f : 3.0f, kColsM1 = QUAD ? 7.0f : 15.0f;
 
     float col0 = 0.0f, col1 = 0.0f, col2 = 0.0f, T = 1.0f;
     bool done = !(px < fp.width && py < fp.height);                    // never stored (:147)
     if (!__all(done)) {
-        float4 (*wbatch)[3] = s_batch + wave * 64;                     // this wave's quarter of the buffer
+        float4* wbatch = s_batch[wave];                                // this wave's quarter of the buffer
         Fetched nxt = fetch_splat(raster, sorted_id, start + lane, end);
         for (uint32_t i = start; i < end; i += 64) {                   // :81
-            const bool keep = stage_splat(nxt, tile_x0, wave_y0, 3.0f);
+            const bool keep = stage_splat(nxt, tile_x0, wave_y0, kRowsM1, kColsM1);
             const uint64_t kmask = __ballot(keep);
             const int n = (int)__popcll(kmask);
             if (keep) {
                 const uint32_t slot = mbcnt(kmask);                    // order-preserving compaction
-                wbatch[slot][0] = nxt.a;
-                wbatch[slot][1] = nxt.b;
-                *reinterpret_cast<float2*>(&wbatch[slot][2]) = make_float2(nxt.c.x, nxt.c.y);
+                float* w = reinterpret_cast<float*>(wbatch + (slot >> 1) * kPairQuads) + (slot & 1u);
+                w[0] = nxt.a.x; w[2] = nxt.a.y;                        // screen position
+                w[4] = nxt.a.z; w[6] = nxt.a.w; w[8] = nxt.b.x;        // inverse 2x2 covariance
+                w[10] = nxt.c.x; w[12] = nxt.c.y;                      // alpha, skip threshold
+                w[14] = nxt.b.y; w[16] = nxt.b.z; w[18] = nxt.b.w;     // colour
             }
             // one wave writes and reads these slots and the DS operations of a wave execute in order: no barrier
             // instruction, only fences that keep the compiler from moving the reads below above the writes (:109)
@@ -510,8 +572,7 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
             bool finished = false;
 #pragma unroll 1
             for (int j = 0; j < n; j += 2) {                           // :112, two entries per step
-                const bool two = j + 1 < n;
-                blend_pair<EXACT>(wbatch, j, two ? j + 1 : j, two, fpx, fpy, col0, col1, col2, T, done);
+                blend_pair<EXACT>(wbatch, j >> 1, j + 1 < n, fpx, fpy, col0, col1, col2, T, done);
                 if (__all(done)) { finished = true; break; }           // this wave's rows are finished
             }
             if (finished) break;
@@ -526,22 +587,20 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
         v |= (uint32_t)(clampf(col0, 0.0f, 1.0f) * 255.0f + 0.5f);
         v |= (uint32_t)(clampf(col1, 0.0f, 1.0f) * 255.0f + 0.5f) << 8;
         v |= (uint32_t)(clampf(col2, 0.0f, 1.0f) * 255.0f + 0.5f) << 16;
-        const uint32_t out_y = fp.compact_out ? krow * kTile + (uint32_t)wave * 4u + (uint32_t)(lane >> 4) : py;
+        const uint32_t out_y = fp.compact_out ? krow * kTile + ly : py;
         rgba[(size_t)out_y * fp.width + px] = v;
     }
 }
 
-// Launch shape (gs_config.render_kernel; every shape gives the same pixels).  AUTO picks by the number of tiles to
-// render, from these measurements on MI355X (round 3, exact mode, ms, longest-first order; 1 / 2 / 4 px per lane with
-// independent one-wave workgroups, then the workgroup per tile; tools/render_probe.py, profiles/r03_render_variants.txt):
-//    920 tiles (config A)                 0.051 / 0.072 /  --   / 0.041
-//   3600 tiles (config B)                 0.099 / 0.102 /  --   / 0.086
-//   8160 tiles (config C, uniform)        0.320 / 0.346 / 0.278 / 0.193
-//   8160 tiles (config C-hard, capture)   0.622 / 0.793 / 1.523 / 0.577
-//  32400 tiles (config D)                 0.647 / 0.574 /  --   / 0.589
-// The workgroup per tile wins or ties everywhere: one launch slot per tile instead of two or four, and its blend loop
-// takes two entries per step.  Only a 4K frame's 32 k tiles come out 2-7 % ahead with two pixels per lane (half as many
-// gathers and rectangle tests per tile).
+// Launch shape (gs_config.render_kernel; every shape gives the same pixels).  AUTO = the workgroup per tile with an
+// 8 x 8 quadrant per wave, from these measurements on MI355X (round 4, exact mode, render bucket in ms, longest-first
+// order; two pixels per lane with independent one-wave workgroups | workgroup per tile with 16 x 4 strips | with 8 x 8
+// quadrants; tools/render_probe.py, profiles/r04_render_variants.txt):
+//   8160 tiles (config C, uniform)        0.342 / 0.180 / 0.174
+//   8160 tiles (config C-hard, capture)   0.831 / 0.534 / 0.500
+//  32400 tiles (config D)                 0.557 / 0.537 / 0.516
+// A quadrant has 20 % less perimeter than a strip, so fewer list entries survive a wave's rectangle test (3 - 7 % of
+// the bucket); one launch slot per tile instead of two or four, and the blend loop takes two entries per step.
 void launch_find_ranges(const FrameParams& fp, const uint32_t* sorted_tile, const SortParams* params,
                         uint32_t* ranges, hipStream_t stream) {
     uint32_t blocks = (fp.capacity / 4u + 255u) / 256u;
@@ -663,15 +722,16 @@ void launch_render(const FrameParams& fp, const SplatRaster* raster, const uint3
     const uint32_t tiles = fp.rows_owned * fp.grid_w;
     if (tiles == 0) return;
     uint32_t* out = reinterpret_cast<uint32_t*>(rgba);
-    const uint32_t px = render_kernel != 0u ? render_kernel : tiles < 20000u ? 16u : 2u;
+    const uint32_t px = render_kernel != 0u ? render_kernel : 17u;
 #define GS_LAUNCH_RENDER(EXACT, PX)                                                                   \
     hipLaunchKernelGGL((k_render<EXACT, PX, false>), dim3(tiles * (4 / PX)), dim3(64), 0, stream, fp, \
                        raster, sorted_id, ranges, order, out, (uint4*)nullptr)
-    if (px == 16) {   // workgroup-per-tile kernel
-        if (render_mode == 0u)
-            hipLaunchKernelGGL((k_render_wg<true>), dim3(tiles), dim3(256), 0, stream, fp, raster, sorted_id, ranges, order, out);
-        else
-            hipLaunchKernelGGL((k_render_wg<false>), dim3(tiles), dim3(256), 0, stream, fp, raster, sorted_id, ranges, order, out);
+    if (px == 16 || px == 17) {   // workgroup-per-tile kernel: four 16 x 4 strips, or four 8 x 8 quadrants
+#define GS_LAUNCH_WG(EXACT, QUAD) \
+    hipLaunchKernelGGL((k_render_wg<EXACT, QUAD>), dim3(tiles), dim3(256), 0, stream, fp, raster, sorted_id, ranges, order, out)
+        if (render_mode == 0u) { if (px == 17) GS_LAUNCH_WG(true, true); else GS_LAUNCH_WG(true, false); }
+        else { if (px == 17) GS_LAUNCH_WG(false, true); else GS_LAUNCH_WG(false, false); }
+#undef GS_LAUNCH_WG
     } else if (render_mode == 0u) {
         if (px == 1) GS_LAUNCH_RENDER(true, 1);
         else if (px == 2) GS_LAUNCH_RENDER(true, 2);
