@@ -199,9 +199,10 @@ int gs_upload_gaussians(gs_ctx* ctx, const void* aos336, uint32_t n);
  * gs_upload_gaussians / gs_load_ply on one of them leaves the others rendering the arrays they hold. */
 int gs_share_scene(gs_ctx* ctx, gs_ctx* owner);
 
-/* ResourceManager::loadGaussians (ResourceManager.cpp:167-300): binary little-endian .ply with the
- * INRIA property names -> records (axis flips, exp, quaternion permutation, sigmoid, SH repack,
- * Morton order) -> upload. */
+/* ResourceManager::loadGaussians (ResourceManager.cpp:167-300): .ply with the INRIA property names -> records
+ * (axis flips, exp, quaternion permutation, sigmoid, SH repack, Morton order) -> upload.  binary_little_endian is the
+ * fast path (two sweeps over 16 MB chunks: 2.3 s for a 1.45 GB Garden-size file); binary_big_endian and ascii are
+ * accepted, ascii being tokenised twice (slow path).  The path must name a seekable file. */
 int gs_load_ply(gs_ctx* ctx, const char* path);
 /* The same conversion without a context: writes up to max_records records to aos336_out (may be
  * NULL to query) and the record count to n_out. */

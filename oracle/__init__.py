@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
         L.gso_num_sort_bits.argtypes = [u32]; L.gso_num_sort_bits.restype = u32
         L.gso_tan_half_fov.argtypes = [C.c_float]; L.gso_tan_half_fov.restype = C.c_float
         L.gso_exp.argtypes = [C.c_float]; L.gso_exp.restype = C.c_float
+        L.gso_exp_live_mismatches.argtypes = [C.c_float, C.c_float, u32, C.POINTER(C.c_float)]; L.gso_exp_live_mismatches.restype = u64
         L.gso_init_sort_list.argtypes = [PP, vp, u32, u32, vp, vp, vp, vp, vp, vp]
         L.gso_init_sort_list.restype = u64
         L.gso_sort_stable.argtypes = [vp, vp, vp, u32]
@@ -150,6 +151,12 @@ def exp(x):
     for i in range(flat_in.size):
         flat_out[i] = L.gso_exp(float(flat_in[i]))
     return out
+
+
+def exp_live_mismatches(lo, hi, stride=1):
+    """(count, first) of floats in [lo, hi] (every stride-th bit pattern, + specials) where the blend loop's evaluation of the pinned exp differs from gso_exp."""
+    first = C.c_float(0.0)
+    return int(lib().gso_exp_live_mismatches(float(lo), float(hi), int(stride), C.byref(first))), float(first.value)
 
 
 def camera_matrices(pos, yaw, pitch, aspect, near=0.1, far=100.0):

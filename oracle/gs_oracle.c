@@ -140,6 +140,52 @@ float gso_exp(float x) {
     return ldexpf(p, (int)n);
 }
 
+/* The form the HIP blend loop evaluates gso_exp in (csrc/gs_render.hip, exp_pinned_live): one max in place of the two
+ * clamps, n = rint(t) by adding and subtracting 1.5 * 2^23, ldexp as an integer add of n to the exponent field (the low
+ * bits of t + 1.5 * 2^23 are n).  Stated here ONLY so that a test can compare it with gso_exp over every float of the
+ * domain the loop uses it on (x <= 0 and NaN): gso_exp_live_mismatches walks the floats in [lo, hi] by bit pattern
+ * (every stride-th one). */
+static float gso_exp_live(float x) {
+    float t = fmaxf(x * 0x1.715476p+0f, -126.0f);
+    float tn = t + 12582912.0f;
+    float n = tn - 12582912.0f;
+    float r = t - n;
+    float p = 0x1.42059ap-13f;
+    p = fmaf(p, r, 0x1.5f3e12p-10f);
+    p = fmaf(p, r, 0x1.3b2d40p-7f);
+    p = fmaf(p, r, 0x1.c6aeeap-5f);
+    p = fmaf(p, r, 0x1.ebfbdcp-3f);
+    p = fmaf(p, r, 0x1.62e430p-1f);
+    p = fmaf(p, r, 1.0f);
+    uint32_t pb, tb;
+    memcpy(&pb, &p, 4); memcpy(&tb, &tn, 4);
+    pb += tb << 23;
+    memcpy(&p, &pb, 4);
+    return p;
+}
+uint64_t gso_exp_live_mismatches(float lo, float hi, uint32_t stride, float* first_bad) {
+    /* lo <= hi <= 0: negative floats are ordered by DEscending bit pattern */
+    uint32_t a, b;
+    uint64_t bad = 0;
+    memcpy(&a, &hi, 4); memcpy(&b, &lo, 4);
+    if (hi == 0.0f) a = 0x80000000u;                 /* -0: the first pattern of the negative range */
+    for (uint64_t bits = a; bits <= b; bits += stride ? stride : 1u) {
+        const uint32_t u = (uint32_t)bits;
+        float x, e0, e1;
+        memcpy(&x, &u, 4);
+        e0 = gso_exp(x); e1 = gso_exp_live(x);
+        if (memcmp(&e0, &e1, 4) != 0) { if (!bad && first_bad) *first_bad = x; ++bad; }
+    }
+    {   /* +0, NaN (a lane whose exponent is NaN counts as live: both forms must send it to 2^-126), -inf */
+        const float specials[4] = {0.0f, NAN, -NAN, -INFINITY};
+        for (int i = 0; i < 4; ++i) {
+            float e0 = gso_exp(specials[i]), e1 = gso_exp_live(specials[i]);
+            if (memcmp(&e0, &e1, 4) != 0) { if (!bad && first_bad) *first_bad = specials[i]; ++bad; }
+        }
+    }
+    return bad;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Stage 1: InitSortList                                                                      */
 /* ------------------------------------------------------------------------------------------ */

@@ -77,6 +77,9 @@ uint32_t gso_capacity(uint32_t n, uint32_t num_tiles);         /* Renderer.cpp:7
 uint32_t gso_num_sort_bits(uint32_t num_tiles);                /* RadixSort.cpp:203-204 */
 float    gso_tan_half_fov(float fov_y);                        /* Common.glsl:53, host-folded */
 float    gso_exp(float x);                                     /* pinned exp, see header */
+/* number of floats x in [lo, hi] (every stride-th bit pattern; lo <= hi <= 0; plus +0, NaNs, -inf) for which the cheaper evaluation the HIP blend loop
+ * uses differs from gso_exp(x) in any bit; *first_bad = the first such x */
+uint64_t gso_exp_live_mismatches(float lo, float hi, uint32_t stride, float* first_bad);
 
 /* Stage 1: InitSortList.comp:82-151 in the canonical (ascending splat index) order.
  * color/cov are [n][4]; entries of culled splats are left untouched (N6).  lists have

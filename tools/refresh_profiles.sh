@@ -20,7 +20,10 @@ if [ "${1:-}" = "--install" ]; then
   e=$(python -c "import json;print(json.loads(open('profiles/${r}_bench_configC.json').read())['config']['sort_elements'])")
   python tools/pmc_scatter_json.py "$src/traffic.json" "profiles/${r}_pmc_scatter.json" "$e" > /dev/null
   cp $src/pmc_sq.txt profiles/${r}_pmc_sq_frame_configC.txt
-  for c in C D; do cp $src/band_$c.txt profiles/${r}_band_cost_config$c.txt; cp $src/band_${c}_sf.txt profiles/${r}_band_cost_config${c}_splat_first.txt; done
+  for c in C D; do cp $src/band_$c.txt profiles/${r}_band_cost_config$c.txt; cp $src/band_${c}_sf.txt profiles/${r}_band_cost_config${c}_splat_first.txt;
+    [ -s $src/band_${c}_bucket.txt ] && cp $src/band_${c}_bucket.txt profiles/${r}_band_cost_config${c}_bucket.txt; done
+  [ -s $src/rehearse_2.json ] && tail -1 $src/rehearse_2.json > profiles/${r}_bench_rehearse_2ranks.json
+  [ -s $src/rehearse_4.json ] && tail -1 $src/rehearse_4.json > profiles/${r}_bench_rehearse_4ranks.json
   [ -s $src/readme_shapes.json ] && cp $src/readme_shapes.json profiles/${r}_readme_shapes.json
   s8=gpurun_out/refresh8
   if [ -d $s8 ]; then
@@ -69,7 +72,7 @@ if [ "${1:-}" = "--radix8" ]; then
 fi
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
 out=gpurun_out/refresh; mkdir -p $out
-timeout -k 10 500 python bench.py > $out/bench_C.json 2> $out/bench_C.err || { echo "bench C failed"; tail -5 $out/bench_C.err; exit 1; }
+timeout -k 10 500 python bench.py --c-abi-gather > $out/bench_C.json 2> $out/bench_C.err || { echo "bench C failed"; tail -5 $out/bench_C.err; exit 1; }
 for c in A B D Chard E; do timeout -k 10 500 python bench.py --config $c > $out/bench_$c.json 2> $out/bench_$c.err || echo "FAIL bench $c"; done
 timeout -k 10 400 python bench.py --sort splat_first --no-cpu-baseline > $out/bench_C_sf.json 2> $out/bench_C_sf.err || echo "FAIL bench splat_first"
 # the profiled runs measure nothing themselves (--no-pmc: no nested rocprofv3 children)
@@ -84,7 +87,10 @@ EXTRA_ARGS=--no-pmc tools/pmc_sq.sh > $out/pmc_sq.txt 2>&1
 for c in C D; do
   timeout -k 10 250 python tools/band_cost.py $c > $out/band_$c.txt 2>&1
   timeout -k 10 250 python tools/band_cost.py $c splat_first > $out/band_${c}_sf.txt 2>&1
+  timeout -k 10 250 python tools/band_cost.py $c bucket > $out/band_${c}_bucket.txt 2>&1
 done
+# the N > 1 code path of bench.py on this one GPU (gloo gather on the host: timings mean nothing, the blocks of the line do)
+for g in 2 4; do timeout -k 10 900 python bench.py --gpus $g --rehearse --steps 60 --warmup 10 > $out/rehearse_$g.json 2> $out/rehearse_$g.err || echo "FAIL rehearse $g"; done
 timeout -k 10 600 python tools/readme_shapes.py --frames 200 > $out/readme_shapes.json 2> $out/readme_shapes.err || echo "FAIL readme shapes"
 python - <<'PY'
 import json, glob

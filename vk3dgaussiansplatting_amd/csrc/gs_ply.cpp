@@ -126,7 +126,10 @@ int read_header(std::ifstream& in, PlyHeader& h, std::string& err) {
 }
 
 // Walks the rows of the first element once, front to back, in chunks of a few MB (a Garden-size file is 1.4 GB):
-// fn(row index, the first `want` of the 59 values).
+// fn(row index, the first `want` of the 59 values).  The converter makes two such sweeps (positions -> Morton order, then
+// every row into its slot), so the file must be seekable, and an ASCII file is tokenised twice in full: ASCII is the
+// SLOW PATH (about twice the single-pass time; trained models are written binary_little_endian, the format the sweeps
+// are built for -- a row is then 59 floats copied out of a 16 MB chunk).
 template <typename Fn>
 int for_each_row(std::ifstream& in, const PlyHeader& h, int want, std::string& err, Fn&& fn) {
     in.clear();

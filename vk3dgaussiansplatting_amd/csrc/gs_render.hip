@@ -446,31 +446,47 @@ finish:
     }
 }
 
-// RenderGaussians.comp:127-142 for one pixel and one list entry whose alpha is known: the `continue` on alpha < 1/255,
-// the colour add, add-then-test transmittance.  `need` = the pixel is live and the exponent passed the f tests.
-template <bool EXACT>
-__device__ __forceinline__ void blend_entry(bool need, float alpha, float cr, float cg, float cb, float& col0, float& col1,
-                                            float& col2, float& T, bool& done) {
-    const bool act = need && !(alpha < 1.0f / 255.0f);                 // :127
+// Lane predicates of the workgroup kernel live as 64-bit wave masks in scalar registers: a comparison already leaves its
+// result there, combining masks is scalar work that issues beside the vector instructions, and a select reads the mask
+// directly (inverse ballot: no instruction).  Kept as per-lane bools the compiler parked `done` in a vector register
+// and rebuilt masks from it every step (six vector instructions of ~90 per pair of entries).
+__device__ __forceinline__ uint64_t mask_of(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ float sel(uint64_t m, float a, float b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : b; }
+
+// RenderGaussians.comp:127-142 for one pixel per lane and one list entry whose alpha is known: the `continue` on
+// alpha < 1/255, the colour add, add-then-test transmittance.  `need` = lanes that are live and whose exponent passed the
+// f tests.  FINITE (wave-uniform: every colour of the staged batch is finite): the colour add runs unconditionally
+// with the weight forced to zero on the lanes that skip -- col + 0 * c == col bit for bit when c is finite (colours are
+// max(x, 0), never negative) -- three selects less per entry; a batch with a non-finite colour takes the select form,
+// where a skipped lane's colour is not touched at all, as in the shader.
+template <bool EXACT, bool FINITE>
+__device__ __forceinline__ void blend_entry(uint64_t need, float alpha, float cr, float cg, float cb, float& col0, float& col1,
+                                            float& col2, float& T, uint64_t& done) {
+    const uint64_t act = need & ~mask_of(alpha < 1.0f / 255.0f);      // :127
     const float wgt = T * alpha;                                       // :131
-    if constexpr (EXACT) {
-        col0 = act ? col0 + wgt * cr : col0;
-        col1 = act ? col1 + wgt * cg : col1;
-        col2 = act ? col2 + wgt * cb : col2;
-    } else {
-        const float w0 = act ? wgt : 0.0f;
+    if constexpr (!EXACT) {
+        const float w0 = sel(act, wgt, 0.0f);
         col0 = __builtin_fmaf(w0, cr, col0);
         col1 = __builtin_fmaf(w0, cg, col1);
         col2 = __builtin_fmaf(w0, cb, col2);
+    } else if constexpr (FINITE) {
+        const float w0 = sel(act, wgt, 0.0f);
+        col0 = col0 + w0 * cr;
+        col1 = col1 + w0 * cg;
+        col2 = col2 + w0 * cb;
+    } else {
+        col0 = sel(act, col0 + wgt * cr, col0);
+        col1 = sel(act, col1 + wgt * cg, col1);
+        col2 = sel(act, col2 + wgt * cb, col2);
     }
     const float next_t = T * (1.0f - alpha);                           // :133
-    const bool fin = act && next_t < 0.0001f;                          // :136-140, colour already added
-    done = done || fin;
-    T = (act && !fin) ? next_t : T;                                    // :142
+    const uint64_t fin = act & mask_of(next_t < 0.0001f);              // :136-140, colour already added
+    done |= fin;
+    T = sel(act & ~fin, next_t, T);                                    // :142
 }
 
 // Two list entries (the pair `pair` of the staged batch; two == false when the batch ends on a single one: the second
-// half of the pair's slots then holds stale values that nothing looks at) against one pixel per lane: their exponents,
+// half of the pair's slots then holds stale values -- and a zero colour -- that nothing looks at) against one pixel per lane: their exponents,
 // the pinned exp and alpha are evaluated side by side in the two halves of packed fp32 instructions (v_pk_mul /
 // v_pk_add / v_pk_fma are IEEE per component, so each half goes through exactly the scalar operation sequence of
 // RenderGaussians.comp:119-124), then the two blends run one after the other in list order (:127-142 is a chain
@@ -479,9 +495,9 @@ __device__ __forceinline__ void blend_entry(bool need, float alpha, float cr, fl
 // reads deliver every operand as the register pair a packed instruction wants (entry-major slots cost ten v_mov per
 // step to build those pairs: 8 % of the loop).
 constexpr int kPairQuads = 5;
-template <bool EXACT>
+template <bool EXACT, bool FINITE>
 __device__ __forceinline__ void blend_pair(const float4* pairs, int pair, bool two, float fpx, float fpy,
-                                           float& col0, float& col1, float& col2, float& T, bool& done) {
+                                           float& col0, float& col1, float& col2, float& T, uint64_t& done) {
     const float4* q = pairs + pair * kPairQuads;
     const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     const v2f ex = (v2f){q0.x, q0.y} - (v2f){fpx, fpx};                          // :119
@@ -494,9 +510,9 @@ __device__ __forceinline__ void blend_pair(const float4* pairs, int pair, bool t
         const v2f qq = __builtin_elementwise_fma(ixv * ex, ex, izv * ey * ey);
         f = __builtin_elementwise_fma((v2f){-0.5f, -0.5f}, qq, -(iyv * ey * ex));
     }
-    const bool live_a = !(f.x > 0.0f) && !(f.x < q3.x);
-    const bool live_b = two && !(f.y > 0.0f) && !(f.y < q3.y);
-    if (__builtin_amdgcn_ballot_w64(!done && (live_a || live_b)) == 0ull) return;   // nobody in these rows can pass :127
+    const uint64_t live_a = mask_of(!(f.x > 0.0f)) & mask_of(!(f.x < q3.x));
+    const uint64_t live_b = two ? mask_of(!(f.y > 0.0f)) & mask_of(!(f.y < q3.y)) : 0ull;
+    if (((live_a | live_b) & ~done) == 0ull) return;                   // nobody in these rows can pass :127
     const float4 q4 = q[4];
     v2f alpha;
     if constexpr (EXACT) {
@@ -505,8 +521,8 @@ __device__ __forceinline__ void blend_pair(const float4* pairs, int pair, bool t
         const v2f t = f * (v2f){0x1.715476p+0f, 0x1.715476p+0f};
         alpha = (v2f){q2.z, q2.w} * (v2f){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
     }
-    blend_entry<EXACT>(!done && live_a, alpha.x, q3.z, q4.x, q4.z, col0, col1, col2, T, done);
-    blend_entry<EXACT>(!done && live_b, alpha.y, q3.w, q4.y, q4.w, col0, col1, col2, T, done);
+    blend_entry<EXACT, FINITE>(live_a & ~done, alpha.x, q3.z, q4.x, q4.z, col0, col1, col2, T, done);
+    blend_entry<EXACT, FINITE>(live_b & ~done, alpha.y, q3.w, q4.y, q4.w, col0, col1, col2, T, done);
 }
 
 // One 256-thread workgroup per tile, one pixel per lane -- the reference's own launch shape (RenderGaussians.comp:
@@ -547,14 +563,16 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
     constexpr float kRowsM1 = QUAD ? 7.0f : 3.0f, kColsM1 = QUAD ? 7.0f : 15.0f;
 
     float col0 = 0.0f, col1 = 0.0f, col2 = 0.0f, T = 1.0f;
-    bool done = !(px < fp.width && py < fp.height);                    // never stored (:147)
-    if (!__all(done)) {
+    uint64_t done = mask_of(!(px < fp.width && py < fp.height));       // never stored (:147); a whole wave: 64 lanes
+    if (done != ~0ull) {
         float4* wbatch = s_batch[wave];                                // this wave's quarter of the buffer
         Fetched nxt = fetch_splat(raster, sorted_id, start + lane, end);
         for (uint32_t i = start; i < end; i += 64) {                   // :81
             const bool keep = stage_splat(nxt, tile_x0, wave_y0, kRowsM1, kColsM1);
             const uint64_t kmask = __ballot(keep);
             const int n = (int)__popcll(kmask);
+            // every staged colour finite (always, for a scene that is): the blend may add 0 * colour on skipping lanes
+            const bool finite = mask_of(keep && !(fabsf(nxt.b.y) < INFINITY && fabsf(nxt.b.z) < INFINITY && fabsf(nxt.b.w) < INFINITY)) == 0ull;
             if (keep) {
                 const uint32_t slot = mbcnt(kmask);                    // order-preserving compaction
                 float* w = reinterpret_cast<float*>(wbatch + (slot >> 1) * kPairQuads) + (slot & 1u);
@@ -562,6 +580,10 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
                 w[4] = nxt.a.z; w[6] = nxt.a.w; w[8] = nxt.b.x;        // inverse 2x2 covariance
                 w[10] = nxt.c.x; w[12] = nxt.c.y;                      // alpha, skip threshold
                 w[14] = nxt.b.y; w[16] = nxt.b.z; w[18] = nxt.b.w;     // colour
+                // a batch that ends on a single entry: the other half of its pair is never blended (`two` is false), but
+                // the finite form multiplies its colour by a zero weight -- give it a colour that keeps 0 * c == 0
+                // (the slots may hold anything, uninitialised LDS included)
+                if ((n & 1) && slot == (uint32_t)n - 1u) { w[15] = 0.0f; w[17] = 0.0f; w[19] = 0.0f; }
             }
             // one wave writes and reads these slots and the DS operations of a wave execute in order: no barrier
             // instruction, only fences that keep the compiler from moving the reads below above the writes (:109)
@@ -570,10 +592,18 @@ __global__ __launch_bounds__(256) void k_render_wg(const FrameParams fp,
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             nxt = fetch_splat(raster, sorted_id, i + 64 + lane, end);  // prefetch next batch
             bool finished = false;
+            if (finite) {
 #pragma unroll 1
-            for (int j = 0; j < n; j += 2) {                           // :112, two entries per step
-                blend_pair<EXACT>(wbatch, j >> 1, j + 1 < n, fpx, fpy, col0, col1, col2, T, done);
-                if (__all(done)) { finished = true; break; }           // this wave's rows are finished
+                for (int j = 0; j < n; j += 2) {                       // :112, two entries per step
+                    blend_pair<EXACT, true>(wbatch, j >> 1, j + 1 < n, fpx, fpy, col0, col1, col2, T, done);
+                    if (done == ~0ull) { finished = true; break; }     // this wave's rows are finished
+                }
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < n; j += 2) {
+                    blend_pair<EXACT, false>(wbatch, j >> 1, j + 1 < n, fpx, fpy, col0, col1, col2, T, done);
+                    if (done == ~0ull) { finished = true; break; }
+                }
             }
             if (finished) break;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // ... nor the next batch's writes above these reads (:84)
