@@ -1,11 +1,11 @@
 """Prints the measurement tables of DESIGN.md (sections 4c, 5, 6) as markdown from what profiles/ holds for a round, so that
 the document can follow a profile refresh without retyping numbers.
 
-    python tools/design_tables.py [r03]
+    python tools/design_tables.py [r04]
 """
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P = os.path.join(ROOT, "profiles", R + "_")
 
 
@@ -40,6 +40,16 @@ print("\nconfig C extras:", {k: C[k]["ms_per_step"] for k in ("alt_sorter", "fas
 print("roofline:", {k: r[k] for k in ("achieved", "frac", "traffic", "avg_launch_ms", "basis")}, "kernel_trace", r["kernel_trace"],
       "stage", {k: r["stage"][k] for k in ("ms", "traffic", "achieved", "frac")}, "algorithmic", r["algorithmic"]["frac"],
       "copy", r["measured_copy_GBps"], r["measured_copy_at_pass_footprint_GBps"])
+if "stages" in r:
+    print("\n## section 5: every stage against its roofline (config C)")
+    for k, v in r["stages"].items():
+        print(f"| {k} | {v['formula']} | {v['algorithmic_bytes'] / 1e6:.0f} MB | {v['pmc_bytes'] / 1e6 if v['pmc_bytes'] else float('nan'):.0f} MB | {v['ms']:.4f} | "
+              f"{v['algorithmic_GBps'] / 1e3:.2f} TB/s = {v['frac_algorithmic']:.2f} | {(v['pmc_GBps'] or 0) / 1e3:.2f} TB/s = {v['frac_pmc']} |"
+              + (f" VALU busy {v['valu_busy']} %" if "valu_busy" in v else ""))
+if "hbm_resident" in C:
+    print("hbm_resident:", {k: C["hbm_resident"].get(k) for k in ("sort_elements", "avg_launch_ms", "bytes_per_launch", "achieved", "frac")})
+if "c_abi_gather" in C:
+    print("c_abi_gather:", {k: C["c_abi_gather"].get(k) for k in ("ms_per_step", "assembled_frame_matches")})
 print("cpu_baseline:", C["cpu_baseline"]["ms_per_frame"], C["cpu_baseline"]["value"], C["cpu_baseline"]["buckets_ms"],
       C["cpu_baseline"]["all_cores"]["ms_per_frame"], C["cpu_baseline"]["all_cores"]["value"])
 for k in ("splat_first", "radix8", "radix8_splat_first"):
@@ -77,4 +87,4 @@ for c in "CD":
         print(f"| {c} | {R_}{', interleaved' if k == 'interleaved' else ''} | {x['rows']} | {E} | {x['init']:.3f} | {x['sort']:.3f} | {x['ranges']:.3f} | {x['render']:.3f} | {x['frame']:.3f} |")
 for c in "CD":
     print(f"| {c} | " + " | ".join(" / ".join(f"{band(c, s)[(R_, 'band mid')]['frame']:.3f}" for R_ in (1, 2, 4, 8)) + f" ({band(c, s)[(8, 'band mid')]['sort']:.3f})"
-                                  for s in ("_splat_first", "_radix8", "_radix8_splat_first")) + " |")
+                                  for s in ("_splat_first", "_radix8", "_radix8_splat_first", "_bucket") if os.path.exists(P + f"band_cost_config{c}{s}.txt")) + " |")
