@@ -1,13 +1,16 @@
 """Parity ENVELOPE: how far the outputs of the reference's shader text move between legal evaluations of it.
 
 The nine main() bodies of the reference's compute shaders (their own text, compiled as C++ over the reference's vendored
-glm by oracle/ref_main_xcheck.cpp, authoring container only) are run four ways on three scenes:
+glm by oracle/ref_main_xcheck.cpp, authoring container only) are run five ways on five scenes:
 
   contract    the numeric contract of oracle/gs_oracle.h imposed (mat4 * vec4 left to right, normalize = v / sqrt(dot),
               the pinned exp): what ref_main_*.npz hold and what the oracle and the HIP path reproduce bit for bit;
   native      nothing imposed: glm's own mat4 * vec4 association, glm's normalize (v * inversesqrt), libm expf;
   native_fma  native, compiled with -O2 -ffp-contract=fast -mfma (every a * b + c the compiler sees is fused);
-  gpu_like    native_fma with exp(x) = exp2f(x * log2 e), the expansion GPU shader compilers use.
+  gpu_like    native_fma with exp(x) = exp2f(x * log2 e), the expansion GPU shader compilers use;
+  gpu_like_rcp  gpu_like compiled with -freciprocal-math as well: a / b may become a * (1 / b) -- Vulkan bounds a
+              division to 2.5 ULP, and `ndc.xyz /= ndc.w` (InitSortList.comp:99, Common.glsl:84) is three divisions by
+              one w (10 of the harness's 19 division instructions turn into reciprocal multiplies).
 
   small   : the 600 splats of small_scene.npz under its camera (SH mode 0)
   dense   : make_main_xcheck.dense_inputs() -- 2,500 large, mostly opaque splats, lists of up to 296 entries
@@ -31,7 +34,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-VARIANTS = ("contract", "native", "native_fma", "gpu_like")
+VARIANTS = ("contract", "native", "native_fma", "gpu_like", "gpu_like_rcp")
 EXE = {v: os.path.join(ROOT, "oracle", "_ref", "ref_main_xcheck" + ("" if v == "contract" else "_" + v)) for v in VARIANTS}
 
 
@@ -124,7 +127,7 @@ def apply_sparse(base, idx, val):
     return out.reshape(base.shape)
 
 
-def run_scene(name, inputs, workers=4):
+def run_scene(name, inputs, workers=5):
     """The four dumps of one scene (the harness is single-threaded: the variants run side by side)."""
     from concurrent.futures import ThreadPoolExecutor
     mm = _load("make_main_xcheck")

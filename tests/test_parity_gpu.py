@@ -253,7 +253,7 @@ def test_parity_envelope(scene):
     """The HIP frame against the OTHER legal evaluations of the reference's shader text (tests/golden/ref_envelope.npz,
     make_envelope.py; no oracle code runs): the frame, the per-splat depth keys, tile boxes and emit flags of the HIP
     path must hash to the contract's dump, and every variant -- glm's native association and normalize with libm's expf,
-    the same with fused multiply-adds, and with exp = exp2(x log2 e) -- has the same emitting splats, the same tile
+    the same with fused multiply-adds, with exp = exp2(x log2 e), with reciprocal multiplies for divisions -- has the same emitting splats, the same tile
     boxes, the same element count and sorted order, depth keys within 192 (1.5 units in the last place of the float
     they are converted from) and every channel of every pixel within ONE 8-bit step of the HIP frame."""
     import hashlib
