@@ -9,6 +9,8 @@ vendored glm by oracle/ref_main_xcheck.cpp, authoring container only -- produce 
 
   configA : BASELINE config A at full size -- 100,000 splats @ 640 x 360, E = 246,569, 3,853 Count workgroups, eleven
           passes of the reference's radix shaders (ref_main_configA.npz; the records come from synth, hash asserted)
+  configB : BASELINE config B at full size (--config-b, ~20 min) -- the Train-7k shape, 559,263 splats @ 1280 x 720,
+          E = 3,481,782 -- as hashes only (ref_main_configB.npz)
 
 A CROSS-CHECK of the restatements against the shader text, not a pin of GLSL arithmetic (header of
 oracle/ref_main_xcheck.cpp).
@@ -70,19 +72,37 @@ def dense_inputs():
 CONFIG_A_AOS_SHA256 = "dc8b5f6239df17ab4f9dc09a83e860baaa22eb380054d4b055e6eb47d62f3d3d"
 
 
-def config_a_inputs(rotated=False):
-    """BASELINE config A (100,000 splats @ 640 x 360) out of the package's own generator; the records are NOT stored in
-    the fixture -- their hash is, and the tests assert it."""
+CONFIG_B_AOS_SHA256 = "0640216e5cd32a2d574b43012c48f52106399aef61eeef09bd111032ed04415a"
+
+
+def config_inputs(name, rotated=False):
+    """A BASELINE config (A: 100,000 splats @ 640 x 360; B: the Train-7k shape, 559,263 @ 1280 x 720) out of the package's
+    own generator; the records are NOT stored in the fixture -- their hash is, and the tests assert it."""
     import hashlib
     sys.path.insert(0, ROOT)
     import oracle
     from vk3dgaussiansplatting_amd import synth
-    aos, cfg = synth.generate_config("A")
-    assert hashlib.sha256(aos.tobytes()).hexdigest() == CONFIG_A_AOS_SHA256, "synth.generate_config('A') changed"
+    aos, cfg = synth.generate_config(name)
+    want = {"A": CONFIG_A_AOS_SHA256, "B": CONFIG_B_AOS_SHA256}[name]
+    assert hashlib.sha256(aos.tobytes()).hexdigest() == want, f"synth.generate_config({name!r}) changed"
     w, h = cfg["width"], cfg["height"]
     pos = np.array([0.3, -0.1, -1.5] if rotated else [0.0, 0.0, 0.0], np.float32)
     view, proj = oracle.camera_matrices(pos, 0.15 if rotated else 0.0, -0.08 if rotated else 0.0, w / h)
     return aos, view, proj, pos, w, h
+
+
+def config_a_inputs(rotated=False):
+    return config_inputs("A", rotated)
+
+
+def hashes_fixture(o, aos_sha):
+    """Hash-only fixture of a dump (config B: the arrays themselves would be tens of MB): counter, capacity, SHA-256 of the
+    emitted list, the sorted list, the ranges, colours, covariances and the frame."""
+    import hashlib
+    sha = lambda a: np.array(hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest())
+    return dict(counter=o["counter"], capacity=o["capacity"], list_sha256=sha(o["list"]), sorted_sha256=sha(o["sorted"]),
+                ranges_sha256=sha(o["ranges"]), color_sha256=sha(o["color"]), cov_sha256=sha(o["cov"]), rgba_sha256=sha(o["rgba"]),
+                aos_sha256=np.array(aos_sha))
 
 
 def config_a_fixture(o):
@@ -124,4 +144,9 @@ if __name__ == "__main__":
         o = run(*config_a_inputs(), 0)
         path = os.path.join(GOLDEN, "ref_main_configA.npz")
         np.savez_compressed(path, **config_a_fixture(o))
+        print("wrote", path, os.path.getsize(path), "bytes; E =", int(o["counter"]))
+    if "--config-b" in sys.argv:            # ~20 min: 54,404 Count workgroups x 11 passes x 2 subgroup sizes, 3,600 tiles of 256 fibers
+        o = run(*config_inputs("B"), 0)
+        path = os.path.join(GOLDEN, "ref_main_configB.npz")
+        np.savez_compressed(path, **hashes_fixture(o, CONFIG_B_AOS_SHA256))
         print("wrote", path, os.path.getsize(path), "bytes; E =", int(o["counter"]))

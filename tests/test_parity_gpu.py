@@ -727,6 +727,15 @@ def test_cpp_driver_runs(tmp_path):
                            capture_output=True, text=True, timeout=300, env=env)
         assert p.returncode == 0 and "frame + gather" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
         assert open(other, "rb").read() == data
+    # "fork first, touch the GPU afterwards": with --ranks 3 the host forks two children before its first GPU call (the
+    # library is linked, so its static initialisers have run by then); GSPLAT_BENCH_FORK_TEST lets all three render the whole
+    # frame on this box's one device, without a communicator -- every process must come up and write the same file
+    other = str(tmp_path / "frame_fork.ppm")
+    p = subprocess.run([exe, "--synthetic", "50000", "--res", "640x360", "--warmup", "2", "--frames", "5", "--ppm", other, "--ranks", "3"],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, GSPLAT_BENCH_FORK_TEST="1"))
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2000:])
+    for name in (other, other.replace(".ppm", ".1.ppm"), other.replace(".ppm", ".2.ppm")):
+        assert open(name, "rb").read() == data, name
 
 
 @pytest.mark.parametrize("with_torch", [False, True])

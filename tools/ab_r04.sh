@@ -1,12 +1,10 @@
 #!/bin/bash
-# round-4 A/B batch (one gpurun call): render-related GPU tests, then RenderGaussians of the working tree against build_variants/lib_prev.so
+# round-4 check batch (one gpurun call): the whole GPU suite, the tuning probes out of tools/probe, the C++ host's sharded path
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
-o=gpurun_out/r04_ab2; mkdir -p $o
-timeout -k 10 900 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k "kernel or exponent or envelope or extreme or config_c or config_a or dispatch or randomized or golden or zero_det or fast" > $o/tests.log 2>&1; echo "tests rc $?"; tail -3 $o/tests.log
-for c in C Chard D A; do
-  for lib in "" build_variants/lib_prev.so; do
-    echo "== $c ${lib:-default}" >> $o/render.txt
-    GS_LIB_OVERRIDE=${lib:+$PWD/$lib} timeout -k 10 300 python tools/render_probe.py $c --frames 60 --kernels 17 --no-stats >> $o/render.txt 2>> $o/render.err || echo FAILED >> $o/render.txt
-  done
-done
-grep -E "==|longest" $o/render.txt | cut -c1-200
+o=gpurun_out/r04_check2; mkdir -p $o
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $o/tests.log 2>&1; echo "tests rc $?"; tail -3 $o/tests.log
+timeout -k 10 200 python tools/sync_probe.py > $o/sync_probe.txt 2>&1; echo "sync probe rc $?"; tail -4 $o/sync_probe.txt
+timeout -k 10 200 python tools/atomic_probe.py > $o/atomic_probe.txt 2>&1; echo "atomic probe rc $?"; tail -3 $o/atomic_probe.txt
+timeout -k 10 200 python tools/render_stats.py > $o/render_stats.txt 2>&1; echo "render stats rc $?"; tail -3 $o/render_stats.txt
+GSPLAT_BENCH_DIST=1 timeout -k 10 200 vk3dgaussiansplatting_amd/csrc/gsplat_bench --synthetic 2000000 --res 1920x1080 --warmup 20 --frames 100 --ranks 1 > $o/cpp_ranks1.txt 2>&1; echo "gsplat_bench --ranks 1 rc $?"; cat $o/cpp_ranks1.txt
+timeout -k 10 200 vk3dgaussiansplatting_amd/csrc/gsplat_bench --synthetic 2000000 --res 1920x1080 --warmup 20 --frames 100 > $o/cpp_plain.txt 2>&1; tail -12 $o/cpp_plain.txt

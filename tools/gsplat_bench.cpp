@@ -97,7 +97,10 @@ int main(int argc, char** argv) {
     // one process per GPU, forked before any GPU call (nothing above this line touches HIP); rank 0 stays the parent
     std::vector<int> id_fds;                 // rank 0: write ends towards ranks 1 .. R-1; rank r: its read end
     std::vector<pid_t> children;
-    const bool sharded = ranks > 1 || interleaved || std::getenv("GSPLAT_BENCH_DIST") != nullptr;   // the last two: the R = 1 form of the path
+    // GSPLAT_BENCH_FORK_TEST (tests only): R processes that all render the WHOLE frame on device 0, no communicator --
+    // what a one-GPU box can check of "fork first, touch the GPU afterwards"
+    const bool fork_test = std::getenv("GSPLAT_BENCH_FORK_TEST") != nullptr;
+    const bool sharded = !fork_test && (ranks > 1 || interleaved || std::getenv("GSPLAT_BENCH_DIST") != nullptr);   // the last two: the R = 1 form of the path
     if (ranks > 1) {
         std::vector<int> wr;
         for (int r = 1; r < ranks && rank == 0; ++r) {
@@ -112,7 +115,7 @@ int main(int argc, char** argv) {
     }
 
     gs_config cfg; gs_default_config(&cfg);
-    cfg.device_ordinal = rank;
+    cfg.device_ordinal = fork_test ? 0 : rank;
     cfg.render_mode = fast ? GS_RENDER_FAST : GS_RENDER_EXACT;
     cfg.sort_algorithm = sort == "splat_first" ? GS_SORT_RADIX4_SPLAT_FIRST : sort == "bucket" ? GS_SORT_TILE_BUCKET
                        : sort == "radix8" ? GS_SORT_RADIX8 : sort == "radix8_splat_first" ? GS_SORT_RADIX8_SPLAT_FIRST : GS_SORT_RADIX4;
@@ -183,6 +186,10 @@ int main(int argc, char** argv) {
     printf("Msplats/s: %.1f\n", info.num_gaussians / avg[4] / 1000.0);
     printf("waitForFence ms: %.4f\nrecordCommandBuffer ms: %.4f\npresent ms: %.4f\nCPU frame time ms: %.4f\n",
            havg[0], havg[1], havg[2], havg[3]);
+    if (fork_test && !ppm.empty() && rank > 0) {                                          // every process its own file: frame.ppm -> frame.1.ppm
+        const size_t dot = ppm.rfind('.');
+        ppm.insert(dot == std::string::npos ? ppm.size() : dot, "." + std::to_string(rank));
+    }
     if (!ppm.empty()) {
         std::vector<uint8_t> img((size_t)w * h * 4);
         gs_debug_read(ctx, GS_BUF_IMAGE, img.data(), img.size());
@@ -190,5 +197,7 @@ int main(int argc, char** argv) {
             fprintf(stderr, "cannot write %s\n", ppm.c_str());
     }
     gs_destroy(ctx);
-    return 0;
+    int rc_children = 0;
+    for (pid_t pid : children) { int st = 0; waitpid(pid, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc_children = 1; }
+    return rc_children;
 }
