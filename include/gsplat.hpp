@@ -86,6 +86,26 @@ public:
         return rc;
     }
 
+    // The frame on R GPUs, one process per GPU (no reference counterpart; INTEGRATION.md "N GPUs from the same C++ host"):
+    // init(cfg with device_ordinal = rank) -> initDist(id from distUniqueId() on one rank, rank, world) -> initForScene ->
+    // shardRows -> drawSharded on every rank every frame; rank 0 gets the whole frame in rgbaOut, the others pass nullptr.
+    static int distUniqueId(void* id128) { return gs_dist_unique_id(id128); }
+    int initDist(const void* id128, int rank, int world) {
+        const int rc = gs_dist_init(ctx_, id128, rank, world);
+        if (rc != GS_OK) error_ = gs_last_error(ctx_);
+        return rc;
+    }
+    int shardRows(bool interleaved = false) {
+        const int rc = gs_dist_shard_rows(ctx_, interleaved ? 1u : 0u);
+        if (rc != GS_OK) error_ = gs_last_error(ctx_);
+        return rc;
+    }
+    int drawSharded(const float* view, const float* proj, const float* camPos, uint32_t shMode, uint8_t* rgbaOut) {
+        const int rc = gs_render_sharded(ctx_, view, proj, camPos, shMode, rgbaOut);
+        if (rc < 0) error_ = gs_last_error(ctx_);
+        return rc;
+    }
+
     // Renderer::cleanup (Renderer.cpp:230-270).  gs_destroy always frees the context (gsplat.h), so the handle is
     // dropped before the call and never touched afterwards.
     int cleanup() {

@@ -193,6 +193,32 @@ def test_config_a_through_the_reference_shader_text(oracle_mod):
     assert np.array_equal(r["image"], x["rgba"])
 
 
+def test_config_b_through_the_reference_shader_text(oracle_mod):
+    """BASELINE config B -- the Train-7k shape, 559,263 splats @ 1280 x 720, E = 3,481,782, capacity 2^23 -- through the
+    reference's own shader text under the numeric contract (make_main_xcheck.py --config-b: 54,404 Count workgroups, eleven
+    passes, twice; FindRanges over 8.4 M slots; 3,600 tiles of 256 fibers: 17 minutes, so the dump is kept as hashes only --
+    tests/golden/ref_main_configB.npz -- and regenerated only with GS_ENVELOPE_FULL=1).  The oracle reproduces every hash:
+    emitted list, sorted list, ranges, colour, covariance, frame."""
+    import hashlib
+    mm = _load_golden_script("make_main_xcheck")
+    x = np.load(os.path.join(GOLDEN, "ref_main_configB.npz"))
+    aos, view, proj, pos, w, h = mm.config_inputs("B")
+    assert hashlib.sha256(aos.tobytes()).hexdigest() == str(x["aos_sha256"])
+    if _reference_harness_present() and os.environ.get("GS_ENVELOPE_FULL") == "1":
+        fresh = mm.hashes_fixture(mm.run(aos, view, proj, pos, w, h, 0), mm.CONFIG_B_AOS_SHA256)
+        for k in x.files:
+            assert np.asarray(fresh[k]).tobytes() == np.asarray(x[k]).tobytes(), k
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    r = oracle_mod.full_pipeline(oracle_mod.make_params(w, h, view, proj, pos, sh_mode=0), aos)
+    e, s1 = r["e"], r["stage1"]
+    assert s1["counter"] == int(x["counter"]) == 3481782 and s1["capacity"] == int(x["capacity"]) == 1 << 23
+    assert sha(np.stack([s1["tile"][:e], s1["depth"][:e], s1["id"][:e]], axis=1).astype(np.uint32)) == str(x["list_sha256"])
+    assert sha(np.stack([r["tile"][:e], r["depth"][:e], r["id"][:e]], axis=1).astype(np.uint32)) == str(x["sorted_sha256"])
+    assert sha(r["ranges"].astype(np.uint32)) == str(x["ranges_sha256"])
+    assert sha(s1["color"]) == str(x["color_sha256"]) and sha(s1["cov"]) == str(x["cov_sha256"])
+    assert sha(r["image"]) == str(x["rgba_sha256"])
+
+
 # What the parity envelope measured (tests/golden/make_envelope.py, profiles/r04_parity_envelope.txt): per scene the
 # largest figures over the four non-contract evaluations of the reference's text.
 ENVELOPE_BOUNDS = {   # scene: (max fraction of emitting splats whose depth key moves, max |key difference|, channel values that move)

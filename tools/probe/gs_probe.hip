@@ -138,6 +138,16 @@ void launch_probe_persistent(void* a, void* b, uint32_t workgroups, uint32_t per
 }
 
 
+// ---- LDS poison (tools/soak.py): LDS is not cleared between workgroups, so a kernel that reads a slot it never wrote
+//      sees whatever the previous tenant left there -- usually a plausible float of the same kernel, which hides the bug.
+//      Every CU gets workgroups that fill the 64 KB a static allocation may take with `pattern` (NaNs, all ones).
+__global__ __launch_bounds__(256) void k_lds_poison(uint32_t pattern, uint32_t* __restrict__ sink) {
+    __shared__ uint32_t s_all[16384];
+    for (uint32_t i = threadIdx.x; i < 16384u; i += 256u) s_all[i] = pattern;
+    __syncthreads();
+    if (s_all[(threadIdx.x * 61u) & 16383u] != pattern) sink[0] = 1u;      // keeps the stores alive
+}
+
 } // namespace gs
 
 using namespace gs;
@@ -261,6 +271,20 @@ int gs_atomic_probe(gs_ctx* c, uint32_t workgroups, uint32_t lines, uint32_t row
     if (table) (void)hipFree(table);
     if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_atomic_probe: ") + hipGetErrorString(e));
     *us_per_launch = ms * 1000.0f / (float)iters;
+    return GS_OK;
+}
+
+// tools/soak.py: fills the LDS of every CU with `pattern` on the context's stream (2048 workgroups of 64 KB: every CU hosts
+// several in turn, two at a time).
+int gs_lds_poison(gs_ctx* c, uint32_t pattern) {
+    if (!c) return GS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t* sink = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&sink, 4));
+    hipLaunchKernelGGL(k_lds_poison, dim3(2048), dim3(256), 0, c->stream, pattern, sink);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    (void)hipFree(sink);
+    if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_lds_poison: ") + hipGetErrorString(e));
     return GS_OK;
 }
 

@@ -17,4 +17,5 @@ def load() -> C.CDLL:
     P.gs_atomic_probe.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.POINTER(C.c_float)]
     P.gs_lds_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
     P.gs_debug_render_stats.argtypes = [C.c_void_p] * 5
+    P.gs_lds_poison.argtypes = [C.c_void_p, C.c_uint32]
     return P

@@ -1,10 +1,16 @@
 """Soak: render the same frame thousands of times and require every image to be bit-identical to the first
-(catches rare races in the LDS protocols of the sort / render kernels).  usage: soak.py [config] [frames]"""
+(catches rare races in the LDS protocols of the sort / render kernels).  Every 97th frame the LDS of all CUs is
+filled with NaNs / all ones first (tools/probe, gs_lds_poison): a kernel that reads an LDS slot it never wrote --
+round 4's blend loop did, for one build -- normally finds a plausible float of its previous tenant there and passes.
+usage: soak.py [config] [frames]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import vk3dgaussiansplatting_amd as gs
 from vk3dgaussiansplatting_amd import synth
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import probe_lib
+P = probe_lib.load()
 name = sys.argv[1] if len(sys.argv) > 1 else "C"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 aos, cfg = synth.generate_config(name)
@@ -13,8 +19,8 @@ rm = gs.ResourceManager(); rm.setGaussians(aos)
 sc = gs.Scene(rm, aspect_ratio=w / h); cam = sc.getCamera(); cam.setPosition((0, 0, 0)); cam.setRotation(0, 0); cam.recalculate()
 dev = torch.device("cuda:0")
 wts = torch.arange(1, w * h + 1, device=dev, dtype=torch.int64) * 2654435761 % 1000003
-for sort in (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET, gs.GS_SORT_RADIX4_SPLAT_FIRST):
-    for kernel in (gs.GS_RENDER_KERNEL_AUTO, gs.GS_RENDER_KERNEL_WAVE_4PX):
+for sort in (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET, gs.GS_SORT_RADIX4_SPLAT_FIRST, gs.GS_SORT_RADIX8_SPLAT_FIRST):
+    for kernel in (gs.GS_RENDER_KERNEL_AUTO, gs.GS_RENDER_KERNEL_WORKGROUP, gs.GS_RENDER_KERNEL_WAVE_4PX):
         r = gs.Renderer(w, h, record_timings=0, warmup_frames=0, sort_algorithm=sort, render_kernel=kernel)
         r.init(rm); r.initForScene(sc)
         img = torch.zeros((h, w), dtype=torch.int32, device=dev)
@@ -25,6 +31,8 @@ for sort in (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET, gs.GS_SORT_RADIX4_SPLAT_
         t0 = time.time()
         with torch.cuda.stream(side):
             for f in range(frames):
+                if f % 97 == 1:
+                    assert P.gs_lds_poison(r._ctx.handle, 0x7FC00000 if (f // 97) % 2 == 0 else 0xFFFFFFFF) == 0
                 r.drawDevice(sc, img.data_ptr(), sync=False)
                 sums.append((img.view(-1).to(torch.int64) * wts).sum())
         torch.cuda.synchronize()
