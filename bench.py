@@ -758,8 +758,37 @@ def main():
                 "note": "bytes the layout reads + writes per launch (at config C the PMC counters see 1.00 x that figure: "
                         "roofline.traffic / roofline.moved.bytes_per_launch) over the HIP-event mean of those launches"}
 
+    def x_sharded_workload_on_one_gpu():
+        # `--gpus N` with N > 1 times config D, the 4K frame BASELINE.json names for the tile-row shard -- the SAME cloud as
+        # config C at four times the pixels.  A scaling series that starts with this one-GPU line therefore needs the 4K frame
+        # on one GPU as its base, not the headline: here it is, timed like the headline (one frame slot, image left in HBM)
+        cfg_d = synth.CONFIGS["D"]
+        assert (cfg_d["n"], cfg_d["mu"], cfg_d["seed"]) == (cfg["n"], cfg["mu"], cfg["seed"])
+        wd, hd = cfg_d["width"], cfg_d["height"]
+        rd = gs.Renderer(wd, hd, device=local_rank, render_mode=mode, record_timings=0, warmup_frames=0, sort_algorithm=sort_ids[args.sort])
+        rd.init(rm)
+        rd.initForScene(scene, share_with=owner)
+        img_d = torch.empty((hd, wd, 4), dtype=torch.uint8, device=device)
+        rd.setStream(torch.cuda.current_stream().cuda_stream)
+        k_d = min(args.steps, 200)
+        for _ in range(10):
+            rd.drawDevice(scene, img_d.data_ptr(), sync=False)
+        torch.cuda.synchronize()
+        t_b = time.perf_counter()
+        for _ in range(k_d):
+            rd.drawDevice(scene, img_d.data_ptr(), sync=False)
+        torch.cuda.synchronize()
+        ms_d = (time.perf_counter() - t_b) / k_d * 1e3
+        rd.setStream(None)
+        rd.cleanup()
+        return {"workload": WORKLOADS["D"], "ms_per_step": round(ms_d, 4), "value": round(n / ms_d / 1000.0, 2), "unit": "Msplats/s",
+                "note": "what `python bench.py --gpus N` shards for N > 1, on this one GPU: the base of a strong-scaling series over "
+                        "that frame (the N > 1 lines repeat it as one_gpu_same_frame_ms, measured on their rank 0)"}
+
     if not args.no_extras and world == 1 and args.config == "C" and args.sort in ("radix4", "radix8"):
         extra("hbm_resident", x_hbm_resident)
+    if not args.no_extras and world == 1 and args.config == "C":
+        extra("sharded_workload_on_one_gpu", x_sharded_workload_on_one_gpu)
 
     # per-rank numbers to rank 0
     stats = torch.tensor([e_rank, scat, *buckets, local_rank if not args.rehearse else 0],
@@ -1005,6 +1034,7 @@ def main():
             out["gather_ms"] = round(gather_ms, 4) if gather_ms is not None else None
             out["gather_note"] = "one gather of the RGBA8 strips to rank 0 alone (strips already rendered), mean of 20, slowest rank"
             out["one_gpu_same_frame_ms"] = round(one_gpu_ms, 4) if one_gpu_ms else None
+            out["one_gpu_same_frame_value"] = round(n / one_gpu_ms / 1000.0, 2) if one_gpu_ms else None   # Msplats/s: the series' base
             out["speedup_vs_one_gpu_same_frame"] = round(one_gpu_ms / ms_per_step, 3) if one_gpu_ms else None
         if world == 1 and not args.no_cpu_baseline:
             import oracle

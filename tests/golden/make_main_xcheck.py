@@ -73,17 +73,18 @@ CONFIG_A_AOS_SHA256 = "dc8b5f6239df17ab4f9dc09a83e860baaa22eb380054d4b055e6eb47d
 
 
 CONFIG_B_AOS_SHA256 = "0640216e5cd32a2d574b43012c48f52106399aef61eeef09bd111032ed04415a"
+CONFIG_C_AOS_SHA256 = "ac6f8feeaf46d100b6d0528b8158433906db2feecd46eed330dda06bbee878d5"
 
 
 def config_inputs(name, rotated=False):
-    """A BASELINE config (A: 100,000 splats @ 640 x 360; B: the Train-7k shape, 559,263 @ 1280 x 720) out of the package's
-    own generator; the records are NOT stored in the fixture -- their hash is, and the tests assert it."""
+    """A BASELINE config (A: 100,000 splats @ 640 x 360; B: the Train-7k shape, 559,263 @ 1280 x 720; C: the Garden-30k
+    shape, 5,834,784 @ 1920 x 1080) out of the package's own generator; the records are NOT stored in the fixture -- their hash is, and the tests assert it."""
     import hashlib
     sys.path.insert(0, ROOT)
     import oracle
     from vk3dgaussiansplatting_amd import synth
     aos, cfg = synth.generate_config(name)
-    want = {"A": CONFIG_A_AOS_SHA256, "B": CONFIG_B_AOS_SHA256}[name]
+    want = {"A": CONFIG_A_AOS_SHA256, "B": CONFIG_B_AOS_SHA256, "C": CONFIG_C_AOS_SHA256}[name]
     assert hashlib.sha256(aos.tobytes()).hexdigest() == want, f"synth.generate_config({name!r}) changed"
     w, h = cfg["width"], cfg["height"]
     pos = np.array([0.3, -0.1, -1.5] if rotated else [0.0, 0.0, 0.0], np.float32)
@@ -149,4 +150,9 @@ if __name__ == "__main__":
         o = run(*config_inputs("B"), 0)
         path = os.path.join(GOLDEN, "ref_main_configB.npz")
         np.savez_compressed(path, **hashes_fixture(o, CONFIG_B_AOS_SHA256))
+        print("wrote", path, os.path.getsize(path), "bytes; E =", int(o["counter"]))
+    if "--config-c" in sys.argv:            # the headline config: hours of fibers, ~6 GB
+        o = run(*config_inputs("C"), 0)
+        path = os.path.join(GOLDEN, "ref_main_configC.npz")
+        np.savez_compressed(path, **hashes_fixture(o, CONFIG_C_AOS_SHA256))
         print("wrote", path, os.path.getsize(path), "bytes; E =", int(o["counter"]))
