@@ -240,9 +240,11 @@ int gs_get_scene_info(const gs_ctx* ctx, gs_scene_info* out);
  *   gs_dist_unique_id : ncclGetUniqueId -- call on ONE rank, hand the GS_DIST_UNIQUE_ID_BYTES bytes to the others by
  *                       any means (pipe, file, MPI, torch.distributed broadcast);
  *   gs_dist_init      : ncclCommInitRank for this context's GPU; collective over all `world` ranks;
- *   gs_gather_strips  : strip_dev = this rank's `bytes` bytes on the device; gathered_dev = world * bytes bytes on
- *                       the root's device (rank r's strip at offset r * bytes; ignored on other ranks, may be NULL
- *                       there).  Asynchronous: ordered on the context's stream, wait with gs_synchronize;
+ *   gs_gather_strips  : strip_dev = this rank's `bytes` bytes on the device (the SAME `bytes` and `root` on every
+ *                       rank: strips are padded to one size); gathered_dev = world * bytes bytes on the root's device
+ *                       (rank r's strip at offset r * bytes; ignored on other ranks, may be NULL there).  Every rank must
+ *                       call it, in the same order as the others.  Asynchronous: ordered on the context's stream, wait
+ *                       with gs_synchronize;
  *   gs_dist_destroy   : ncclCommDestroy (gs_destroy does it too). */
 #define GS_DIST_UNIQUE_ID_BYTES 128
 int gs_dist_unique_id(void* id_out);
@@ -256,7 +258,8 @@ int gs_dist_destroy(gs_ctx* ctx);
  *   gs_render_sharded  : every rank calls it with the same camera: the rank's rows are rendered into its strip, the
  *                        strips gathered on rank 0 and the whole frame copied to rgba_out there (HOST, height*width*4
  *                        bytes as in gs_render; ignored on the other ranks, may be NULL).  Synchronous.  The frame is
- *                        bit-identical to the one GPU frame of gs_render. */
+ *                        bit-identical to the one GPU frame of gs_render.  A rank whose own frame fails still takes part
+ *                        in the exchange before it returns its error, so the others are not left waiting. */
 int gs_dist_shard_rows(gs_ctx* ctx, uint32_t interleaved);
 int gs_render_sharded(gs_ctx* ctx, const float view[16], const float proj[16], const float cam_pos[3],
                       uint32_t sh_mode, uint8_t* rgba_out);

@@ -134,15 +134,9 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
-def _one_hip_runtime() -> None:
-    """A process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so (+ HSA runtime) with
-    the same SONAME as the /opt/rocm copy this library links, and the dynamic loader hands every later request for that
-    SONAME the copy that came first: torch first -> this library runs on torch's runtime (the configuration every GPU
-    test runs in); this library first -> torch later finds the system libamdhip64 beside its own HSA runtime and
-    reports "No HIP GPUs are available".  So, when torch is installed but not imported yet, its libamdhip64 is mapped
-    before ours -- no `import torch`, just the one shared object -- and a later `import torch` (dist.ShardedFrame on
-    a cuda device, bench.py) works in either order.  GS_HIP_RUNTIME=system keeps the /opt/rocm runtime for processes
-    that will never import torch."""
+def _preload_torch_bundled(soname: str, why: str) -> None:
+    """Maps <torch>/lib/<soname> with RTLD_GLOBAL when torch is installed but not imported yet -- no `import torch`, just the
+    one shared object -- so that a library requested later under the same SONAME resolves to the copy torch will use."""
     import importlib.util
     import sys
     if "torch" in sys.modules or os.environ.get("GS_HIP_RUNTIME") == "system":
@@ -153,13 +147,24 @@ def _one_hip_runtime() -> None:
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", soname)
     if os.path.exists(bundled):
         try:
             C.CDLL(bundled, mode=C.RTLD_GLOBAL)
         except OSError as ex:   # a broken wheel must not take the library down with it
             import warnings
-            warnings.warn(f"could not pre-load {bundled} ({ex}); importing torch after this point may fail to see the GPU")
+            warnings.warn(f"could not pre-load {bundled} ({ex}); {why}")
+
+
+def _one_hip_runtime() -> None:
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so (+ HSA runtime) with
+    the same SONAME as the /opt/rocm copy this library links, and the dynamic loader hands every later request for that
+    SONAME the copy that came first: torch first -> this library runs on torch's runtime (the configuration every GPU
+    test runs in); this library first -> torch later finds the system libamdhip64 beside its own HSA runtime and
+    reports "No HIP GPUs are available".  So, when torch is installed but not imported yet, its libamdhip64 is mapped
+    before ours, and a later `import torch` (dist.ShardedFrame on a cuda device, bench.py) works in either order.
+    GS_HIP_RUNTIME=system keeps the /opt/rocm runtime for processes that will never import torch."""
+    _preload_torch_bundled("libamdhip64.so", "importing torch after this point may fail to see the GPU")
 
 
 def lib() -> C.CDLL:
@@ -257,19 +262,4 @@ def _check_hip_runtime(L) -> None:
 def preload_rccl() -> None:
     """gs_dist_init binds RCCL by SONAME (librccl.so.1).  In a process that will import torch later, map the copy the
     PyTorch wheel bundles first, so that both sides end up on ONE RCCL over ONE HIP runtime."""
-    import importlib.util
-    import sys
-    if "torch" in sys.modules or os.environ.get("GS_HIP_RUNTIME") == "system":
-        return
-    try:
-        spec = importlib.util.find_spec("torch")
-    except (ImportError, ValueError):
-        spec = None
-    if spec is None or not spec.submodule_search_locations:
-        return
-    bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
-    if os.path.exists(bundled):
-        try:
-            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+    _preload_torch_bundled("librccl.so", "gs_dist_init will bind the system RCCL")

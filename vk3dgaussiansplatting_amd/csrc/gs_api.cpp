@@ -21,6 +21,7 @@
 using namespace gs;
 
 static thread_local std::string g_create_error;
+void gsi_set_create_error(const std::string& msg) { g_create_error = msg; }
 
 namespace {
 

@@ -86,6 +86,9 @@ struct gs_ctx {
 };
 
 
+// Text for gs_last_error(NULL) from translation units that have no context at hand (gs_dist.cpp); hidden: not an export.
+__attribute__((visibility("hidden"))) void gsi_set_create_error(const std::string& msg);
+
 namespace gs {
 
 inline FrameParams make_frame_params(const gs_ctx* c, const float* view, const float* proj,

@@ -16,6 +16,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <functional>
+#include <mutex>
 #include <string>
 
 namespace {
@@ -33,14 +35,12 @@ struct Rccl {
     std::string error;
 };
 
-Rccl& rccl() {
-    static Rccl r;
-    if (r.handle || !r.error.empty()) return r;
+void bind_rccl(Rccl& r) {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (r.handle) break;
     }
-    if (!r.handle) { r.error = std::string("cannot load librccl.so.1: ") + dlerror(); return r; }
+    if (!r.handle) { r.error = std::string("cannot load librccl.so.1: ") + dlerror(); return; }
     bool ok = true;
     auto bind = [&](auto& fn, const char* sym) {
         fn = reinterpret_cast<std::decay_t<decltype(fn)>>(dlsym(r.handle, sym));
@@ -55,6 +55,12 @@ Rccl& rccl() {
     bind(r.Recv, "ncclRecv");
     bind(r.GetErrorString, "ncclGetErrorString");
     if (!ok) { dlclose(r.handle); r.handle = nullptr; }
+}
+
+Rccl& rccl() {                       // bound once per process, whichever context asks first (contexts may live on other threads)
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, bind_rccl, std::ref(r));
     return r;
 }
 
@@ -72,9 +78,10 @@ extern "C" {
 int gs_dist_unique_id(void* id_out) {
     if (!id_out) return GS_ERR_INVALID;
     Rccl& r = rccl();
-    if (!r.handle) return GS_ERR_HIP;
+    if (!r.handle) { gsi_set_create_error("gs_dist_unique_id: " + r.error); return GS_ERR_HIP; }   // gs_last_error(NULL)
     ncclUniqueId id;
-    if (r.GetUniqueId(&id) != ncclSuccess) return GS_ERR_HIP;
+    const ncclResult_t rc = r.GetUniqueId(&id);
+    if (rc != ncclSuccess) { gsi_set_create_error(std::string("gs_dist_unique_id: ") + r.GetErrorString(rc)); return GS_ERR_HIP; }
     std::memcpy(id_out, &id, sizeof(id));
     return GS_OK;
 }
@@ -159,9 +166,14 @@ int gs_render_sharded(gs_ctx* c, const float view[16], const float proj[16], con
     uint8_t* target = static_cast<uint8_t*>(c->dist_strip);
     if (!c->dist_interleaved) target -= (size_t)c->row_begin * 16u * c->width * 4u;
     int rc = c->rows_owned ? gs_render_device_async(c, view, proj, cam_pos, sh_mode, target) : GS_OK;
-    if (rc < 0) return rc;
+    // a rank whose frame failed still takes part in the exchange (with whatever its strip holds) -- leaving now would leave
+    // the other ranks waiting in theirs -- and reports its error afterwards
+    const std::string render_error = rc < 0 ? c->last_error : std::string();
+    const int rc_render = rc;
     rc = gs_gather_strips(c, c->dist_strip, c->dist_gathered, c->dist_strip_bytes, 0);
     if (rc < 0) return rc;
+    if (rc_render < 0) { (void)hipStreamSynchronize(c->stream); return fail(c, rc_render, render_error); }
+    rc = rc_render;
     const size_t frame_bytes = (size_t)c->width * c->height * 4u;
     hipError_t e = hipSuccess;
     if (root && c->dist_interleaved) {
