@@ -219,6 +219,33 @@ def test_config_b_through_the_reference_shader_text(oracle_mod):
     assert sha(r["image"]) == str(x["rgba_sha256"])
 
 
+def test_config_c_through_the_reference_shader_text(oracle_mod):
+    """BASELINE config C -- the headline: the Garden-30k shape, 5,834,784 splats @ 1920 x 1080, E = 13,121,624, capacity
+    2^24 -- through the reference's own shader text under the numeric contract (make_main_xcheck.py --config-c: 205,026 Count
+    workgroups x twelve passes x two subgroup sizes, FindRanges over 16.8 M slots, 8,160 tiles of 256 fibers; hours on
+    one core, hashes only: tests/golden/ref_main_configC.npz).  The threaded oracle stages reproduce every hash.  The cloud
+    alone takes 40 s to generate, so this test runs with GS_ENVELOPE_FULL=1 only; the HIP path is compared with the same
+    hashes in the GPU suite, which also compares it with the oracle at this config."""
+    import hashlib
+    path = os.path.join(GOLDEN, "ref_main_configC.npz")
+    if not os.path.exists(path):
+        pytest.skip("ref_main_configC.npz not generated")
+    if os.environ.get("GS_ENVELOPE_FULL") != "1":
+        pytest.skip("set GS_ENVELOPE_FULL=1 (40 s of cloud generation + a config-C frame on the CPU)")
+    mm = _load_golden_script("make_main_xcheck")
+    x = np.load(path)
+    aos, view, proj, pos, w, h = mm.config_inputs("C")
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    r = oracle_mod.full_pipeline(oracle_mod.make_params(w, h, view, proj, pos, sh_mode=0), aos)
+    e, s1 = r["e"], r["stage1"]
+    assert s1["counter"] == int(x["counter"]) == 13121624 and s1["capacity"] == int(x["capacity"]) == 1 << 24
+    assert sha(np.stack([s1["tile"][:e], s1["depth"][:e], s1["id"][:e]], axis=1).astype(np.uint32)) == str(x["list_sha256"])
+    assert sha(np.stack([r["tile"][:e], r["depth"][:e], r["id"][:e]], axis=1).astype(np.uint32)) == str(x["sorted_sha256"])
+    assert sha(r["ranges"].astype(np.uint32)) == str(x["ranges_sha256"])
+    assert sha(s1["color"]) == str(x["color_sha256"]) and sha(s1["cov"]) == str(x["cov_sha256"])
+    assert sha(r["image"]) == str(x["rgba_sha256"])
+
+
 # What the parity envelope measured (tests/golden/make_envelope.py, profiles/r04_parity_envelope.txt): per scene the
 # largest figures over the four non-contract evaluations of the reference's text.
 ENVELOPE_BOUNDS = {   # scene: (max fraction of emitting splats whose depth key moves, max |key difference|, channel values that move)

@@ -271,6 +271,31 @@ def test_config_a_through_the_reference_shader_text(sort):
     r.cleanup()
 
 
+def test_config_c_through_the_reference_shader_text():
+    """BASELINE config C, the headline (Garden-30k shape, E = 13,121,624) against the hashes of what the reference's own
+    shader text produces for it (tests/golden/ref_main_configC.npz: hours of fibers in the authoring container; no oracle
+    code runs): emitted list, sorted list, ranges, covariance and all 2,073,600 pixels."""
+    import hashlib
+    path = os.path.join(GOLDEN, "ref_main_configC.npz")
+    if not os.path.exists(path):
+        pytest.skip("ref_main_configC.npz not generated")
+    mm = _golden_script("make_main_xcheck")
+    x = np.load(path)
+    aos, view, proj, pos, w, h = mm.config_inputs("C")
+    sc = _scene_from_matrices(aos, view, proj, pos, w, h)
+    r = make_renderer(sc, w, h)
+    img = r.draw(sc)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(img) == str(x["rgba_sha256"])
+    assert r.timings().emitted_elements == int(x["counter"]) and r.sceneInfo().capacity == int(x["capacity"])
+    ids, tiles, depth = r.debugRead(gs.BUF_SORTED_ID), r.debugRead(gs.BUF_SORTED_TILE), r.debugRead(gs.BUF_SORTED_DEPTH)
+    assert sha(np.stack([tiles, depth, ids], axis=1).astype(np.uint32)) == str(x["sorted_sha256"])
+    assert sha(r.debugRead(gs.BUF_RANGES).astype(np.uint32)) == str(x["ranges_sha256"])
+    assert sha(r.debugRead(gs.BUF_COV)) == str(x["cov_sha256"])
+    assert sha(_emitted_list(r, sc).astype(np.uint32)) == str(x["list_sha256"])
+    r.cleanup()
+
+
 @pytest.mark.parametrize("sort", [gs.GS_SORT_RADIX4, gs.GS_SORT_RADIX8_SPLAT_FIRST])
 def test_config_b_through_the_reference_shader_text(sort):
     """BASELINE config B (the Train-7k shape, E = 3,481,782) against the hashes of what the reference's own shader text
