@@ -202,7 +202,8 @@ int gs_share_scene(gs_ctx* ctx, gs_ctx* owner);
 /* ResourceManager::loadGaussians (ResourceManager.cpp:167-300): .ply with the INRIA property names -> records
  * (axis flips, exp, quaternion permutation, sigmoid, SH repack, Morton order) -> upload.  binary_little_endian is the
  * fast path (two sweeps over 16 MB chunks: 2.3 s for a 1.45 GB Garden-size file); binary_big_endian and ascii are
- * accepted, ascii being tokenised twice (slow path).  The path must name a seekable file. */
+ * accepted; ascii is tokenised twice (chunked std::from_chars: about 0.3 GB of text per second over both sweeps).  The path
+ * must name a seekable file. */
 int gs_load_ply(gs_ctx* ctx, const char* path);
 /* The same conversion without a context: writes up to max_records records to aos336_out (may be
  * NULL to query) and the record count to n_out. */

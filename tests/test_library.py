@@ -178,6 +178,53 @@ def test_ply_conversion(tmp_path, fmt):
     assert np.allclose(got[:, ~exact], want[:, ~exact], rtol=2e-7, atol=0)
 
 
+def test_ply_ascii_tokens_across_chunk_boundaries(tmp_path):
+    """The ASCII reader walks the file in chunks and parses numbers in place (std::from_chars): a token cut by the end
+    of a chunk is carried over.  With 97-byte chunks (GS_PLY_ASCII_CHUNK, a test knob; 16 MB in production) every row
+    of this file is cut several times -- exponents, explicit plus signs, CRLF line ends, numbers packed several rows to a
+    line and one per line: the records must equal those of the same table read from the binary file; a non-number and
+    a file that ends early are reported, not parsed."""
+    import subprocess, sys, textwrap
+    rng = np.random.default_rng(9)
+    n = 203
+    table = (rng.normal(size=(n, len(PLY_PROPS))) * np.float32(10.0) ** rng.integers(-6, 6, (n, len(PLY_PROPS)))).astype(np.float32)
+    binary, text = str(tmp_path / "b.ply"), str(tmp_path / "a.ply")
+    _write_ply(binary, table)
+    hdr = "ply\nformat ascii 1.0\nelement vertex %d\n" % n + "".join(f"property float {p}\n" for p in PLY_PROPS) + "end_header\n"
+    toks = []
+    for v in table.reshape(-1):
+        t = "%.9e" % float(v) if rng.random() < 0.5 else repr(float(v))
+        toks.append("+" + t if v > 0 and rng.random() < 0.3 else t)
+    seps = rng.choice(np.array([" ", "\n", "\r\n", "  \t", "\n\n"]), len(toks), p=[0.6, 0.15, 0.1, 0.1, 0.05])
+    open(text, "w", newline="").write(hdr + "".join(t + s_ for t, s_ in zip(toks, seps)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        import vk3dgaussiansplatting_amd as gs
+        rm = gs.ResourceManager(); rm.loadGaussians(sys.argv[1]); np.save(sys.argv[2], rm.getGaussians())
+    """)
+    from conftest import ROOT
+    env = dict(os.environ, GS_PLY_ASCII_CHUNK="97", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = {}
+    for name, path in (("binary", binary), ("ascii", text)):
+        dst = str(tmp_path / f"{name}.npy")
+        subprocess.run([sys.executable, "-c", code, path, dst], check=True, env=env)
+        out[name] = np.load(dst)
+    assert out["ascii"].shape == (n, 84) and out["ascii"].tobytes() == out["binary"].tobytes()
+    L = _lib.lib()
+    cnt = C.c_uint32()
+    os.environ["GS_PLY_ASCII_CHUNK"] = "97"
+    try:
+        bad = str(tmp_path / "bad.ply")
+        open(bad, "w").write(hdr + " ".join(toks[:500]) + " 1.0.0 " + " ".join(toks[501:]))
+        rec = np.zeros((n, 84), np.float32)
+        assert L.gs_convert_ply(bad.encode(), rec.ctypes.data, n, C.byref(cnt)) == _lib.GS_ERR_FORMAT and b"not a number" in L.gs_ply_last_error()
+        short = str(tmp_path / "short.ply")
+        open(short, "w").write(hdr + " ".join(toks[:-3]))
+        assert L.gs_convert_ply(short.encode(), rec.ctypes.data, n, C.byref(cnt)) == _lib.GS_ERR_FORMAT and b"truncated" in L.gs_ply_last_error()
+    finally:
+        del os.environ["GS_PLY_ASCII_CHUNK"]
+
+
 @pytest.mark.parametrize("which", ["mixed", "oneside"])
 def test_ply_loader_cross_check(tmp_path, which):
     """CROSS-CHECK of the conversions of ResourceManager::loadGaussians (ResourceManager.cpp:167-300): tests/golden/ref_ply.npz
