@@ -178,6 +178,33 @@ def test_ply_conversion(tmp_path, fmt):
     assert np.allclose(got[:, ~exact], want[:, ~exact], rtol=2e-7, atol=0)
 
 
+def test_rccl_binds_by_soname_without_a_gpu():
+    """gs_dist.cpp binds RCCL with dlopen("librccl.so.1") at first use, not at link time: libgsplat_hip.so must not name
+    librccl among its dependencies, and gs_dist_unique_id (ncclGetUniqueId: no GPU needed) must work in a process that
+    never linked it -- two ids in a row, different; the context-taking calls refuse a NULL context.  In a child process
+    (this one stays free of RCCL)."""
+    import subprocess, sys, textwrap
+    deps = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "librccl" not in deps and "libamdhip64" in deps
+    code = textwrap.dedent("""
+        import ctypes as C
+        from vk3dgaussiansplatting_amd import _lib
+        _lib.preload_rccl()
+        L = _lib.lib()
+        a, b = C.create_string_buffer(_lib.DIST_UNIQUE_ID_BYTES), C.create_string_buffer(_lib.DIST_UNIQUE_ID_BYTES)
+        assert L.gs_dist_unique_id(a) == 0 and L.gs_dist_unique_id(b) == 0, L.gs_last_error(None)
+        assert a.raw != b.raw and any(a.raw)
+        assert L.gs_dist_unique_id(None) == _lib.GS_ERR_INVALID
+        assert L.gs_dist_init(None, a, 0, 1) == _lib.GS_ERR_INVALID and L.gs_gather_strips(None, 1, 1, 16, 0) == _lib.GS_ERR_INVALID
+        assert L.gs_dist_shard_rows(None, 0) == _lib.GS_ERR_INVALID and L.gs_dist_destroy(None) == _lib.GS_ERR_INVALID
+        assert any("librccl" in ln for ln in open("/proc/self/maps"))
+        print("rccl-bound")
+    """)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0 and "rccl-bound" in p.stdout, (p.stdout[-300:], p.stderr[-1500:])
+
+
 def test_ply_ascii_tokens_across_chunk_boundaries(tmp_path):
     """The ASCII reader walks the file in chunks and parses numbers in place (std::from_chars): a token cut by the end
     of a chunk is carried over.  With 97-byte chunks (GS_PLY_ASCII_CHUNK, a test knob; 16 MB in production) every row
