@@ -206,6 +206,15 @@ def pmc_traffic(args):
     return res or "no kernels in the counter files"
 
 
+def all_ranks_ok(tdist, ok, device="cpu"):
+    """The guard of an optional phase: every rank says whether ITS set-up worked; the phase runs only if all did -- one rank's
+    failure skips it everywhere instead of leaving the others waiting in its collectives."""
+    import torch
+    f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    tdist.all_reduce(f, op=tdist.ReduceOp.MIN)
+    return bool(int(f.item()))
+
+
 def dry_run(args, world, rank):
     """The N-rank plumbing without a GPU: process group (gloo), ShardedFrame strips, gather, assembly -- every rank
     fills its strip with a value that names (step, rank) and rank 0 checks each assembled frame."""
@@ -234,11 +243,21 @@ def dry_run(args, world, rank):
                 for row in rows:
                     ok = ok and bool((img[row * 16:min(row * 16 + 16, h)] == (7 * f + r) % 251).all())
     elapsed = time.perf_counter() - t0
+    # the guard protocol of the optional phases (alt_sorters, c_abi_gather): GS_BENCH_DRY_FAIL_RANK=r makes rank r's set-up
+    # "fail"; every rank must then skip the phase -- and none may be left waiting in its gather
+    guarded = None
     if world > 1:
+        mine_ok = os.environ.get("GS_BENCH_DRY_FAIL_RANK") != str(rank)
+        if all_ranks_ok(tdist, mine_ok):
+            sf.strips[0].fill_(200 + rank)
+            strips = sf.gather(0)
+            guarded = {"ran": True, "ok": bool(rank != 0 or all(int(strips[r][0, 0, 0]) == 200 + r for r in range(world)))}
+        else:
+            guarded = {"skipped": "set-up failed on this rank" if not mine_ok else "set-up failed on another rank"}
         tdist.barrier()
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
-                          "rows": args.rows, "assembled_frames_ok": ok,
+                          "rows": args.rows, "assembled_frames_ok": ok, "guarded_phase": guarded,
                           "gloo_ranks": tdist.get_world_size() if world > 1 else 1}), flush=True)
     if world > 1:
         tdist.destroy_process_group()
@@ -650,9 +669,7 @@ def main():
     # together.  Each phase is guarded: a rank whose set-up fails says so in an all_reduce(MIN) and the phase is skipped
     # EVERYWHERE instead of leaving the others waiting in its collectives.
     def flag_all(ok):
-        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if args.rehearse else device)
-        tdist.all_reduce(f, op=tdist.ReduceOp.MIN)
-        return bool(int(f.item()))
+        return all_ranks_ok(tdist, ok, "cpu" if args.rehearse else device)
 
     def alt_phase(name):
         ra, err = None, None

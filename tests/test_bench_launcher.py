@@ -31,6 +31,24 @@ def test_bench_launches_its_own_ranks(n, rows):
     assert j["n_gpus"] == n and j["gloo_ranks"] == n and j["assembled_frames_ok"] is True and j["rows"] == rows
 
 
+@pytest.mark.parametrize("fail_rank", [None, 0, 1])
+def test_guarded_phase_is_skipped_everywhere_when_one_rank_fails(fail_rank):
+    """The optional phases of the N > 1 line (alt_sorters, c_abi_gather) are guarded by an all_reduce(MIN) of a per-rank
+    "set-up ok" flag: with a failure injected on rank 0 or 1 every rank skips the phase's gather and the run still ends
+    with its line and exit code 0; without one the phase runs."""
+    env = _env()
+    if fail_rank is not None:
+        env["GS_BENCH_DRY_FAIL_RANK"] = str(fail_rank)
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "2"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    if fail_rank is None:
+        assert j["guarded_phase"] == {"ran": True, "ok": True}
+    else:
+        assert "skipped" in j["guarded_phase"] and ("this rank" in j["guarded_phase"]["skipped"]) == (fail_rank == 0)
+
+
 def test_bench_refuses_a_launch_of_another_size():
     env = _env()
     env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
