@@ -277,8 +277,6 @@ def test_config_c_through_the_reference_shader_text():
     code runs): emitted list, sorted list, ranges, covariance and all 2,073,600 pixels."""
     import hashlib
     path = os.path.join(GOLDEN, "ref_main_configC.npz")
-    if not os.path.exists(path):
-        pytest.skip("ref_main_configC.npz not generated")
     mm = _golden_script("make_main_xcheck")
     x = np.load(path)
     aos, view, proj, pos, w, h = mm.config_inputs("C")
