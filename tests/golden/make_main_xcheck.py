@@ -84,7 +84,7 @@ def config_inputs(name, rotated=False):
     import oracle
     from vk3dgaussiansplatting_amd import synth
     aos, cfg = synth.generate_config(name)
-    want = {"A": CONFIG_A_AOS_SHA256, "B": CONFIG_B_AOS_SHA256, "C": CONFIG_C_AOS_SHA256}[name]
+    want = {"A": CONFIG_A_AOS_SHA256, "B": CONFIG_B_AOS_SHA256, "C": CONFIG_C_AOS_SHA256, "D": CONFIG_C_AOS_SHA256}[name]   # D = C's cloud at 4K
     assert hashlib.sha256(aos.tobytes()).hexdigest() == want, f"synth.generate_config({name!r}) changed"
     w, h = cfg["width"], cfg["height"]
     pos = np.array([0.3, -0.1, -1.5] if rotated else [0.0, 0.0, 0.0], np.float32)
@@ -154,5 +154,10 @@ if __name__ == "__main__":
     if "--config-c" in sys.argv:            # the headline config: hours of fibers, ~6 GB
         o = run(*config_inputs("C"), 0)
         path = os.path.join(GOLDEN, "ref_main_configC.npz")
+        np.savez_compressed(path, **hashes_fixture(o, CONFIG_C_AOS_SHA256))
+        print("wrote", path, os.path.getsize(path), "bytes; E =", int(o["counter"]))
+    if "--config-d" in sys.argv:            # config C's cloud at 3840 x 2160 (E = 33.1 M): about three hours, ~8 GB
+        o = run(*config_inputs("D"), 0)
+        path = os.path.join(GOLDEN, "ref_main_configD.npz")
         np.savez_compressed(path, **hashes_fixture(o, CONFIG_C_AOS_SHA256))
         print("wrote", path, os.path.getsize(path), "bytes; E =", int(o["counter"]))

@@ -271,6 +271,32 @@ def test_config_a_through_the_reference_shader_text(sort):
     r.cleanup()
 
 
+def test_config_d_through_the_reference_shader_text():
+    """BASELINE config D -- the 4K frame of the tile-row shard: config C's cloud at 3840 x 2160, E = 33.1 M, capacity 2^26 --
+    against the hashes of what the reference's own shader text produces for it (tests/golden/ref_main_configD.npz: about
+    three hours of fibers in the authoring container; no oracle code runs): emitted list, sorted list, ranges, covariance
+    and all 8.3 M pixels.  Skipped until that fixture has been generated."""
+    import hashlib
+    path = os.path.join(GOLDEN, "ref_main_configD.npz")
+    if not os.path.exists(path):
+        pytest.skip("ref_main_configD.npz not generated (make_main_xcheck.py --config-d, ~3 h)")
+    mm = _golden_script("make_main_xcheck")
+    x = np.load(path)
+    aos, view, proj, pos, w, h = mm.config_inputs("D")
+    sc = _scene_from_matrices(aos, view, proj, pos, w, h)
+    r = make_renderer(sc, w, h)
+    img = r.draw(sc)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(img) == str(x["rgba_sha256"])
+    assert r.timings().emitted_elements == int(x["counter"]) and r.sceneInfo().capacity == int(x["capacity"])
+    ids, tiles, depth = r.debugRead(gs.BUF_SORTED_ID), r.debugRead(gs.BUF_SORTED_TILE), r.debugRead(gs.BUF_SORTED_DEPTH)
+    assert sha(np.stack([tiles, depth, ids], axis=1).astype(np.uint32)) == str(x["sorted_sha256"])
+    assert sha(r.debugRead(gs.BUF_RANGES).astype(np.uint32)) == str(x["ranges_sha256"])
+    assert sha(r.debugRead(gs.BUF_COV)) == str(x["cov_sha256"])
+    assert sha(_emitted_list(r, sc).astype(np.uint32)) == str(x["list_sha256"])
+    r.cleanup()
+
+
 def test_config_c_through_the_reference_shader_text():
     """BASELINE config C, the headline (Garden-30k shape, E = 13,121,624) against the hashes of what the reference's own
     shader text produces for it (tests/golden/ref_main_configC.npz: hours of fibers in the authoring container; no oracle
