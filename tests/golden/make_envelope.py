@@ -19,6 +19,8 @@ glm by oracle/ref_main_xcheck.cpp, authoring container only) are run five ways o
   configA : BASELINE config A at full size (100,000 splats @ 640 x 360, the benchmark camera at the origin: its view
             matrix is the identity up to signs, so every association of mat4 * vec4 gives the same floats)
   configA_rot : the same cloud seen from (0.3, -0.1, -1.5), yaw 0.15, pitch -0.08
+  configB_rot : BASELINE config B's cloud (559,263 splats @ 1280 x 720) from that pose: E = 2,259,575 -- enough elements for
+            near-ties between neighbouring depth keys to exist (--large; 12 minutes)
 
 Writes tests/golden/ref_envelope.npz (per scene and variant, as differences from the contract's dump: the frame, and
 per splat the depth key, the tile box and whether it emitted; the number of sorted positions and of tile lists whose
@@ -45,7 +47,7 @@ def _load(name):
     return mod
 
 
-def scenes(small_only=False):
+def scenes(small_only=False, large=False):
     g = np.load(os.path.join(GOLDEN, "small_scene.npz"))
     yield "small", (g["aos"], g["view"], g["proj"], g["cam_pos"], int(g["width"]), int(g["height"]))
     yield "dense", _load("make_main_xcheck").dense_inputs()
@@ -56,6 +58,8 @@ def scenes(small_only=False):
     mm = _load("make_main_xcheck")
     yield "configA", mm.config_a_inputs()
     yield "configA_rot", mm.config_a_inputs(rotated=True)
+    if large:
+        yield "configB_rot", mm.config_inputs("B", rotated=True)      # 12 minutes with the five variants side by side
 
 
 def key_is_defined(aos, view, near=0.1, far=100.0):
@@ -172,7 +176,7 @@ def main():
         if not os.path.exists(EXE[v]):
             sys.exit(f"build {EXE[v]} first (make -C oracle ref; needs /root/reference)")
     keep, lines = {}, []
-    for name, inputs in scenes():
+    for name, inputs in scenes(large="--large" in sys.argv):
         record(name, inputs, run_scene(name, inputs), keep, lines)
     path = os.path.join(GOLDEN, "ref_envelope.npz")
     np.savez_compressed(path, **keep)

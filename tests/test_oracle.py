@@ -245,8 +245,17 @@ def test_config_c_through_the_reference_shader_text(oracle_mod):
 
 # What the parity envelope measured (tests/golden/make_envelope.py, profiles/r04_parity_envelope.txt): per scene the
 # largest figures over the four non-contract evaluations of the reference's text.
-ENVELOPE_BOUNDS = {   # scene: (max fraction of emitting splats whose depth key moves, max |key difference|, channel values that move)
-    "small": (0.24, 192, 1), "dense": (0.16, 128, 1), "extreme": (0.29, 192, 0), "configA": (0.0, 0, 14), "configA_rot": (0.16, 128, 126)}
+#   keys: fraction of emitting splats whose depth key moves | dkey: largest |key difference| | moved: channel values that move
+#   (all by one step) | boxes: splats whose tile box differs | e_delta: |E - E_contract| | sorted: sorted positions whose splat
+#   differs (None: the lists differ in length) | lists: tile lists that differ
+ENVELOPE_BOUNDS = {
+    "small": dict(keys=0.24, dkey=192, moved=1, boxes=0, e_delta=0, sorted=0, lists=0),
+    "dense": dict(keys=0.16, dkey=128, moved=1, boxes=0, e_delta=0, sorted=0, lists=0),
+    "extreme": dict(keys=0.29, dkey=192, moved=0, boxes=0, e_delta=0, sorted=0, lists=0),
+    "configA": dict(keys=0.0, dkey=0, moved=14, boxes=0, e_delta=0, sorted=0, lists=0),
+    "configA_rot": dict(keys=0.16, dkey=128, moved=126, boxes=0, e_delta=0, sorted=0, lists=0),
+    "configB_rot": dict(keys=0.16, dkey=128, moved=470, boxes=1, e_delta=2, sorted=42, lists=21),
+}
 
 
 @pytest.mark.parametrize("scene", list(ENVELOPE_BOUNDS))
@@ -255,21 +264,28 @@ def test_parity_envelope(oracle_mod, scene):
     HIP path) implement?  tests/golden/ref_envelope.npz holds what the nine main() bodies produce when nothing is
     imposed on them -- glm's own mat4 * vec4 association and normalize, libm's expf (`native`), the same with every
     a * b + c fused (`native_fma`), with exp(x) = exp2(x log2 e) on top (`gpu_like`), and with divisions turned into
-    reciprocal multiplies as well (`gpu_like_rcp`) -- as differences from the contract's dump, for five scenes up to BASELINE config A at full size.  Measured and asserted here against the
-    oracle's own output: the set of emitting splats, every tile box, the element count and the ENTIRE sorted order are
-    the same in every variant; depth keys move in 14-29 % of the splats under a rotated camera, by at most 1.5 units in
-    the last place of the float they are converted from (|d key| <= 192); no channel of any pixel moves by more than ONE
-    8-bit step, and at most 126 of 691,200 channel values move at all.  That is the support north_star's "keys
-    bit-exact, pixels within 1 ULP of the reference renderer" can get in this container: the keys are exact against
-    the contract only; order, ranges and +-1 step hold across every evaluation measured.  Where the reference is mounted
-    the three small scenes are regenerated and compared first (GS_ENVELOPE_FULL=1: config A too, ~3 min)."""
+    reciprocal multiplies as well (`gpu_like_rcp`) -- as differences from the contract's dump, for six scenes up to
+    BASELINE config A at full size and config B's cloud under a rotated camera (E = 2.26 M).  Measured and asserted here
+    against the oracle's own output:
+      * depth keys move in 14-29 % of the splats under a rotated camera, by at most 1.5 units in the last place of the
+        float they are converted from (|d key| <= 192);
+      * up to a quarter of a million elements nothing else moves: emitting splats, tile boxes, E, the whole sorted order;
+      * at 2.26 M elements near-ties exist: 13-21 adjacent pairs of the sorted list swap (26-42 positions, <= 21 of 3,600
+        tile lists), and with reciprocal divisions ONE splat of 384,665 gets another tile box (E changes by 2, so every
+        later tile range shifts);
+      * no channel of any pixel moves by more than ONE 8-bit step in any variant on any scene (<= 470 of 2.76 M values).
+    So north_star's "keys and tile ranges bit-exact" is a statement about the numeric contract, not about every GLSL
+    implementation; "pixels within 1 step" holds across every evaluation measured.  Where the reference is mounted the
+    three small scenes are regenerated and compared first (GS_ENVELOPE_FULL=1: the config A scenes too, ~3 min;
+    configB_rot only through make_envelope.py --large)."""
     import hashlib
     me = _load_golden_script("make_envelope")
     z = np.load(os.path.join(GOLDEN, "ref_envelope.npz"))
-    inputs = dict(me.scenes())[scene] if scene.startswith("configA") else dict(me.scenes(small_only=True))[scene]
+    big = scene.startswith("config")
+    inputs = dict(me.scenes(small_only=not big, large=scene == "configB_rot"))[scene]
     aos, view, proj, pos, w, h = inputs
     n, grid_w = aos.shape[0], (w + 15) // 16
-    if _reference_harness_present() and (not scene.startswith("configA") or os.environ.get("GS_ENVELOPE_FULL") == "1"):
+    if _reference_harness_present() and (not big or (os.environ.get("GS_ENVELOPE_FULL") == "1" and scene != "configB_rot")):
         keep, lines = {}, []
         me.record(scene, inputs, me.run_scene(scene, inputs), keep, lines)
         for k, v in keep.items():
@@ -281,21 +297,27 @@ def test_parity_envelope(oracle_mod, scene):
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
     assert [sha(r["image"]), sha(key), sha(box), sha(em)] == list(z[f"{scene}_contract_sha256"]), "oracle != contract dump"
     assert e == int(z[f"{scene}_counter"])
-    frac_max, dkey_max, moved_max = ENVELOPE_BOUNDS[scene]
-    worst = [0.0, 0, 0]
+    bound = ENVELOPE_BOUNDS[scene]
+    worst = dict(keys=0.0, dkey=0, moved=0, boxes=0, e_delta=0, sorted=0, lists=0)
     for v in me.VARIANTS[1:]:
-        assert int(z[f"{scene}_{v}_counter"]) == e                                   # same number of sort elements
-        assert z[f"{scene}_{v}_emits_idx"].size == 0 and z[f"{scene}_{v}_box_idx"].size == 0   # same culls, same tile boxes
-        assert int(z[f"{scene}_{v}_sorted_positions_differ"]) == 0 and int(z[f"{scene}_{v}_tile_lists_differ"]) == 0
+        assert z[f"{scene}_{v}_emits_idx"].size == 0                                  # the same splats pass the culls and emit
+        srt = int(z[f"{scene}_{v}_sorted_positions_differ"])
         vkey = me.apply_sparse(key, z[f"{scene}_{v}_key_idx"], z[f"{scene}_{v}_key_val"])
         dk = np.abs(vkey.astype(np.int64) - key.astype(np.int64))
         img = me.apply_sparse(r["image"], z[f"{scene}_{v}_rgba_idx"], z[f"{scene}_{v}_rgba_val"])
         d = np.abs(img.astype(np.int16) - r["image"].astype(np.int16))
         assert d.max(initial=0) <= 1, (scene, v)                                     # north_star's tolerance
-        worst = [max(worst[0], (dk != 0).sum() / max(em.sum(), 1)), max(worst[1], int(dk.max(initial=0))), max(worst[2], int((d != 0).sum()))]
-    assert worst[0] <= frac_max and worst[1] <= dkey_max and worst[2] <= moved_max, worst
+        got = dict(keys=(dk != 0).sum() / max(em.sum(), 1), dkey=int(dk.max(initial=0)), moved=int((d != 0).sum()),
+                   boxes=int(z[f"{scene}_{v}_box_idx"].size > 0) if bound["boxes"] <= 1 else 0,
+                   e_delta=abs(int(z[f"{scene}_{v}_counter"]) - e), sorted=max(srt, 0), lists=int(z[f"{scene}_{v}_tile_lists_differ"]))
+        if z[f"{scene}_{v}_box_idx"].size:     # one splat's box = up to four u16 that differ
+            got["boxes"] = len(set((z[f"{scene}_{v}_box_idx"] // 4).tolist()))
+        assert srt >= 0 or got["e_delta"] > 0                                        # -1 only when the lists differ in length
+        worst = {k: max(worst[k], got[k]) for k in worst}
+    for k in worst:
+        assert worst[k] <= bound[k], (k, worst[k], bound[k])
     if scene != "configA":
-        assert worst[1] == dkey_max and worst[2] == moved_max, worst                 # the table in DESIGN.md is what was measured
+        assert (worst["dkey"], worst["moved"], worst["sorted"], worst["boxes"]) == (bound["dkey"], bound["moved"], bound["sorted"], bound["boxes"]), worst
 
 
 def test_camera_matrices_match_reference_glm(oracle_mod, ref_golden):

@@ -344,18 +344,20 @@ def test_config_b_through_the_reference_shader_text(sort):
     r.cleanup()
 
 
-@pytest.mark.parametrize("scene", ["small", "dense", "extreme", "configA", "configA_rot"])
+@pytest.mark.parametrize("scene", ["small", "dense", "extreme", "configA", "configA_rot", "configB_rot"])
 def test_parity_envelope(scene):
     """The HIP frame against the OTHER legal evaluations of the reference's shader text (tests/golden/ref_envelope.npz,
     make_envelope.py; no oracle code runs): the frame, the per-splat depth keys, tile boxes and emit flags of the HIP
     path must hash to the contract's dump, and every variant -- glm's native association and normalize with libm's expf,
-    the same with fused multiply-adds, with exp = exp2(x log2 e), with reciprocal multiplies for divisions -- has the same emitting splats, the same tile
-    boxes, the same element count and sorted order, depth keys within 192 (1.5 units in the last place of the float
-    they are converted from) and every channel of every pixel within ONE 8-bit step of the HIP frame."""
+    the same with fused multiply-adds, with exp = exp2(x log2 e), with reciprocal multiplies for divisions -- has the same
+    emitting splats, depth keys within 192 (1.5 units in the last place of the float they are converted from) and every
+    channel of every pixel within ONE 8-bit step of the HIP frame; up to 250 k elements also the same tile boxes, element
+    count and sorted order, at 2.26 M elements (configB_rot) at most 42 sorted positions and one tile box differ."""
     import hashlib
     me = _golden_script("make_envelope")
     z = np.load(os.path.join(GOLDEN, "ref_envelope.npz"))
-    aos, view, proj, pos, w, h = dict(me.scenes(small_only=not scene.startswith("configA")))[scene]
+    big = scene.startswith("config")
+    aos, view, proj, pos, w, h = dict(me.scenes(small_only=not big, large=scene == "configB_rot"))[scene]
     sc = _scene_from_matrices(aos, view, proj, pos, w, h)
     r = make_renderer(sc, w, h)
     img = r.draw(sc)
@@ -364,10 +366,13 @@ def test_parity_envelope(scene):
     r.cleanup()
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
     assert [sha(img), sha(key), sha(box), sha(em)] == list(z[f"{scene}_contract_sha256"])
+    assert e == int(z[f"{scene}_counter"])
+    large = scene == "configB_rot"
     for v in me.VARIANTS[1:]:
-        assert int(z[f"{scene}_{v}_counter"]) == e == int(z[f"{scene}_counter"])
-        assert z[f"{scene}_{v}_emits_idx"].size == 0 and z[f"{scene}_{v}_box_idx"].size == 0
-        assert int(z[f"{scene}_{v}_sorted_positions_differ"]) == 0 and int(z[f"{scene}_{v}_tile_lists_differ"]) == 0
+        assert z[f"{scene}_{v}_emits_idx"].size == 0
+        assert abs(int(z[f"{scene}_{v}_counter"]) - e) <= (2 if large else 0)
+        assert len(set((z[f"{scene}_{v}_box_idx"] // 4).tolist())) <= (1 if large else 0)
+        assert int(z[f"{scene}_{v}_sorted_positions_differ"]) <= (42 if large else 0) and int(z[f"{scene}_{v}_tile_lists_differ"]) <= (21 if large else 0)
         vkey = me.apply_sparse(key, z[f"{scene}_{v}_key_idx"], z[f"{scene}_{v}_key_val"])
         assert np.abs(vkey.astype(np.int64) - key.astype(np.int64)).max(initial=0) <= 192
         vimg = me.apply_sparse(img, z[f"{scene}_{v}_rgba_idx"], z[f"{scene}_{v}_rgba_val"])
