@@ -770,6 +770,26 @@ def test_exponent_range_of_the_pinned_exp(oracle_mod, kernel):
     r.cleanup()
 
 
+@pytest.mark.parametrize("kernel", [gs.GS_RENDER_KERNEL_AUTO, gs.GS_RENDER_KERNEL_WORKGROUP, gs.GS_RENDER_KERNEL_WAVE_2PX])
+def test_infinite_colours_take_the_select_form(oracle_mod, kernel):
+    """The blend loop adds `0 * colour` on lanes that skip an entry -- the same bits as not adding when the colour is
+    finite.  SH coefficients near FLT_MAX make some splats' colour +inf (no NaN): a batch that stages such an entry must
+    fall back to the select form, where a skipping lane's colour is not touched (0 * inf would be NaN): the frame stays
+    the oracle's."""
+    w, h = 208, 120
+    aos = synth.generate(2500, w, h, -2.2, seed=43)
+    for i in (0, 2, 6, 12):                                 # dc and three bands whose basis is positive in front of the camera
+        aos[::17, 12 + 4 * i:15 + 4 * i] = np.float32(3.4e38)
+    sc = make_scene(aos, w, h, pos=(0.2, -0.1, -1.0), yaw=0.1, pitch=-0.05)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    col = ref["stage1"]["color"]
+    assert np.isinf(col).sum() > 20 and not np.isnan(col).any()
+    r = make_renderer(sc, w, h, kernel=kernel)
+    img = r.draw(sc)
+    assert_frame_equals_oracle(r, img, ref)
+    r.cleanup()
+
+
 def test_c_abi_call_order_status_codes(small_cloud):
     """Straight through ctypes: wrong call order is reported, never fatal."""
     import ctypes as C
