@@ -253,13 +253,14 @@ int gs_dist_init(gs_ctx* ctx, const void* unique_id, int rank, int world);
 int gs_gather_strips(gs_ctx* ctx, const void* strip_dev, void* gathered_dev, size_t bytes, int root);
 int gs_dist_destroy(gs_ctx* ctx);
 /* The same for a host that holds no device memory of its own -- Renderer::draw on R GPUs (Renderer.cpp:297-515):
- *   gs_dist_shard_rows : after gs_set_resolution + gs_dist_init; rank r of R takes its tile rows (contiguous band of
+ *   gs_dist_shard_rows : after gs_set_resolution + gs_dist_init (again after every gs_set_resolution); rank r of R takes its tile rows (contiguous band of
  *                        ceil(Ty / R) rows, or rows r, r + R, ... when interleaved != 0) and the library allocates the
  *                        strip (and, on rank 0, the gather buffer);
  *   gs_render_sharded  : every rank calls it with the same camera: the rank's rows are rendered into its strip, the
  *                        strips gathered on rank 0 and the whole frame copied to rgba_out there (HOST, height*width*4
  *                        bytes as in gs_render; ignored on the other ranks, may be NULL).  Synchronous.  The frame is
- *                        bit-identical to the one GPU frame of gs_render.  A rank whose own frame fails still takes part
+ *                        bit-identical to the one GPU frame of gs_render; gs_get_timings afterwards describes this rank's
+ *                        own rows (with record_timings on).  A rank whose own frame fails still takes part
  *                        in the exchange before it returns its error, so the others are not left waiting. */
 int gs_dist_shard_rows(gs_ctx* ctx, uint32_t interleaved);
 int gs_render_sharded(gs_ctx* ctx, const float view[16], const float proj[16], const float cam_pos[3],

@@ -904,6 +904,14 @@ def test_c_abi_sharded_frame_single_rank(with_torch):
                 assert L.gs_render_sharded(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0, img.ctypes.data) == 0, L.gs_last_error(ctx)
                 assert np.array_equal(img, ref), interleaved
         assert L.gs_render_sharded(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0, None) == _lib.GS_ERR_INVALID   # the root needs the image
+        tm = _lib.GsTimings()
+        assert L.gs_get_timings(ctx, C.byref(tm)) == 0 and tm.num_sort_elements > 1000      # filled by gs_render_sharded
+        # a new resolution drops the strips: shard again
+        assert L.gs_set_resolution(ctx, w, h) == 0
+        assert L.gs_render_sharded(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0, img.ctypes.data) == _lib.GS_ERR_INVALID
+        assert L.gs_dist_shard_rows(ctx, 1) == 0
+        img[:] = 0
+        assert L.gs_render_sharded(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0, img.ctypes.data) == 0 and np.array_equal(img, ref)
         if WITH_TORCH:
             strip = torch.randint(0, 256, (272 * 3840 * 4,), dtype=torch.uint8, device="cuda")
             out = torch.zeros_like(strip)

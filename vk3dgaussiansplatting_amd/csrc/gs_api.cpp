@@ -80,6 +80,9 @@ void free_resolution(gs_ctx* c) {
     drop_sort_graph(c);
     free_sort(c->sort);
     free_dev(c->ranges); free_dev(c->tile_order); free_dev(c->framebuffer);
+    // the strips of a sharded frame are sized by the resolution: gs_dist_shard_rows must be called again
+    free_dev(c->dist_strip); free_dev(c->dist_gathered); free_dev(c->dist_image);
+    c->dist_strip_bytes = 0;
     c->capacity = 0; c->width = c->height = 0;
     c->have_frame = false;
 }
@@ -385,6 +388,9 @@ int finish_frame(gs_ctx* c) {
 }
 
 } // namespace
+
+// gs_dist.cpp: the buckets and the element count of the frame gs_render_sharded has just waited for (hidden: not an export)
+int gsi_finish_frame(gs_ctx* c) { return finish_frame(c); }
 
 extern "C" {
 

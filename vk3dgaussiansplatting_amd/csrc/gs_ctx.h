@@ -88,6 +88,8 @@ struct gs_ctx {
 
 // Text for gs_last_error(NULL) from translation units that have no context at hand (gs_dist.cpp); hidden: not an export.
 __attribute__((visibility("hidden"))) void gsi_set_create_error(const std::string& msg);
+// Renderer.cpp:458-475 for a frame enqueued with gs_render_device_async: wait, read the timestamps, fill gs_get_timings.
+__attribute__((visibility("hidden"))) int gsi_finish_frame(gs_ctx* c);
 
 namespace gs {
 

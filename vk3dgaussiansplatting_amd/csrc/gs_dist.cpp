@@ -194,7 +194,8 @@ int gs_render_sharded(gs_ctx* c, const float view[16], const float proj[16], con
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(c, GS_ERR_HIP, std::string("gs_render_sharded: ") + hipGetErrorString(e));
-    return rc;
+    // gs_get_timings: this rank's own rows (the gather is not part of the reference's buckets); GS_WARN_OVERFLOW as in gs_render
+    return c->rows_owned ? gsi_finish_frame(c) : rc;
 }
 
 int gs_dist_destroy(gs_ctx* c) {
