@@ -21,6 +21,8 @@ glm by oracle/ref_main_xcheck.cpp, authoring container only) are run five ways o
   configA_rot : the same cloud seen from (0.3, -0.1, -1.5), yaw 0.15, pitch -0.08
   configB_rot : BASELINE config B's cloud (559,263 splats @ 1280 x 720) from that pose: E = 2,259,575 -- enough elements for
             near-ties between neighbouring depth keys to exist (--large; 12 minutes)
+  configC_rot : the headline cloud (5,834,784 splats @ 1920 x 1080) from that pose: E = 11,470,723 (run by hand: an hour with
+            the five variants side by side, 5 GB each; the per-splat key differences -- 630 k of them -- are not kept)
 
 Writes tests/golden/ref_envelope.npz (per scene and variant, as differences from the contract's dump: the frame, and
 per splat the depth key, the tile box and whether it emitted; the number of sorted positions and of tile lists whose
@@ -60,6 +62,8 @@ def scenes(small_only=False, large=False):
     yield "configA_rot", mm.config_a_inputs(rotated=True)
     if large:
         yield "configB_rot", mm.config_inputs("B", rotated=True)      # 12 minutes with the five variants side by side
+    if large == "C":
+        yield "configC_rot", mm.config_inputs("C", rotated=True)      # an hour, 5 GB per variant; key differences not kept
 
 
 def key_is_defined(aos, view, near=0.1, far=100.0):

@@ -255,6 +255,8 @@ ENVELOPE_BOUNDS = {
     "configA": dict(keys=0.0, dkey=0, moved=14, boxes=0, e_delta=0, sorted=0, lists=0),
     "configA_rot": dict(keys=0.16, dkey=128, moved=126, boxes=0, e_delta=0, sorted=0, lists=0),
     "configB_rot": dict(keys=0.16, dkey=128, moved=470, boxes=1, e_delta=2, sorted=42, lists=21),
+    # the headline cloud under the rotated camera (E = 11.47 M; key differences not kept; GS_ENVELOPE_FULL=1: a minute and a half)
+    "configC_rot": dict(keys=0.0, dkey=0, moved=2896, boxes=19, e_delta=5, sorted=0, lists=227),
 }
 
 
@@ -273,7 +275,9 @@ def test_parity_envelope(oracle_mod, scene):
       * at 2.26 M elements near-ties exist: 13-21 adjacent pairs of the sorted list swap (26-42 positions, <= 21 of 3,600
         tile lists), and with reciprocal divisions ONE splat of 384,665 gets another tile box (E changes by 2, so every
         later tile range shifts);
-      * no channel of any pixel moves by more than ONE 8-bit step in any variant on any scene (<= 470 of 2.76 M values).
+      * at the headline's scale (config C's cloud under that camera, E = 11.47 M; GS_ENVELOPE_FULL=1) 13-19 of 3.96 M
+        splats change their tile box and 210-227 of 8,160 tile lists differ;
+      * no channel of any pixel moves by more than ONE 8-bit step in any variant on any scene (<= 2,896 of 6.2 M values).
     So north_star's "keys and tile ranges bit-exact" is a statement about the numeric contract, not about every GLSL
     implementation; "pixels within 1 step" holds across every evaluation measured.  Where the reference is mounted the
     three small scenes are regenerated and compared first (GS_ENVELOPE_FULL=1: the config A scenes too, ~3 min;
@@ -282,10 +286,12 @@ def test_parity_envelope(oracle_mod, scene):
     me = _load_golden_script("make_envelope")
     z = np.load(os.path.join(GOLDEN, "ref_envelope.npz"))
     big = scene.startswith("config")
-    inputs = dict(me.scenes(small_only=not big, large=scene == "configB_rot"))[scene]
+    if scene == "configC_rot" and os.environ.get("GS_ENVELOPE_FULL") != "1":
+        pytest.skip("set GS_ENVELOPE_FULL=1 (a config-C frame on the CPU); the GPU suite runs this scene")
+    inputs = dict(me.scenes(small_only=not big, large={"configB_rot": True, "configC_rot": "C"}.get(scene, False)))[scene]
     aos, view, proj, pos, w, h = inputs
     n, grid_w = aos.shape[0], (w + 15) // 16
-    if _reference_harness_present() and (not big or (os.environ.get("GS_ENVELOPE_FULL") == "1" and scene != "configB_rot")):
+    if _reference_harness_present() and (not big or (os.environ.get("GS_ENVELOPE_FULL") == "1" and scene.startswith("configA"))):
         keep, lines = {}, []
         me.record(scene, inputs, me.run_scene(scene, inputs), keep, lines)
         for k, v in keep.items():
@@ -302,8 +308,11 @@ def test_parity_envelope(oracle_mod, scene):
     for v in me.VARIANTS[1:]:
         assert z[f"{scene}_{v}_emits_idx"].size == 0                                  # the same splats pass the culls and emit
         srt = int(z[f"{scene}_{v}_sorted_positions_differ"])
-        vkey = me.apply_sparse(key, z[f"{scene}_{v}_key_idx"], z[f"{scene}_{v}_key_val"])
-        dk = np.abs(vkey.astype(np.int64) - key.astype(np.int64))
+        if f"{scene}_{v}_key_idx" in z.files:
+            vkey = me.apply_sparse(key, z[f"{scene}_{v}_key_idx"], z[f"{scene}_{v}_key_val"])
+            dk = np.abs(vkey.astype(np.int64) - key.astype(np.int64))
+        else:
+            dk = np.zeros(1, np.int64)                                                # configC_rot: 630 k key differences, not kept
         img = me.apply_sparse(r["image"], z[f"{scene}_{v}_rgba_idx"], z[f"{scene}_{v}_rgba_val"])
         d = np.abs(img.astype(np.int16) - r["image"].astype(np.int16))
         assert d.max(initial=0) <= 1, (scene, v)                                     # north_star's tolerance
@@ -312,12 +321,13 @@ def test_parity_envelope(oracle_mod, scene):
                    e_delta=abs(int(z[f"{scene}_{v}_counter"]) - e), sorted=max(srt, 0), lists=int(z[f"{scene}_{v}_tile_lists_differ"]))
         if z[f"{scene}_{v}_box_idx"].size:     # one splat's box = up to four u16 that differ
             got["boxes"] = len(set((z[f"{scene}_{v}_box_idx"] // 4).tolist()))
-        assert srt >= 0 or got["e_delta"] > 0                                        # -1 only when the lists differ in length
+        assert srt >= 0 or got["e_delta"] > 0 or got["boxes"] > 0                    # -1 only when the lists hold other (tile, splat) pairs
         worst = {k: max(worst[k], got[k]) for k in worst}
     for k in worst:
         assert worst[k] <= bound[k], (k, worst[k], bound[k])
     if scene != "configA":
         assert (worst["dkey"], worst["moved"], worst["sorted"], worst["boxes"]) == (bound["dkey"], bound["moved"], bound["sorted"], bound["boxes"]), worst
+    # a swapped near-tie or a moved box shows up as a tile list that differs; `sorted` only counts when the lists have one length
 
 
 def test_camera_matrices_match_reference_glm(oracle_mod, ref_golden):

@@ -344,7 +344,7 @@ def test_config_b_through_the_reference_shader_text(sort):
     r.cleanup()
 
 
-@pytest.mark.parametrize("scene", ["small", "dense", "extreme", "configA", "configA_rot", "configB_rot"])
+@pytest.mark.parametrize("scene", ["small", "dense", "extreme", "configA", "configA_rot", "configB_rot", "configC_rot"])
 def test_parity_envelope(scene):
     """The HIP frame against the OTHER legal evaluations of the reference's shader text (tests/golden/ref_envelope.npz,
     make_envelope.py; no oracle code runs): the frame, the per-splat depth keys, tile boxes and emit flags of the HIP
@@ -352,12 +352,13 @@ def test_parity_envelope(scene):
     the same with fused multiply-adds, with exp = exp2(x log2 e), with reciprocal multiplies for divisions -- has the same
     emitting splats, depth keys within 192 (1.5 units in the last place of the float they are converted from) and every
     channel of every pixel within ONE 8-bit step of the HIP frame; up to 250 k elements also the same tile boxes, element
-    count and sorted order, at 2.26 M elements (configB_rot) at most 42 sorted positions and one tile box differ."""
+    count and sorted order; at 2.26 M elements (configB_rot) at most 42 sorted positions and one tile box differ, at
+    11.47 M (configC_rot: the headline cloud under that camera) at most 19 tile boxes of 3.96 M and 227 of 8,160 tile lists."""
     import hashlib
     me = _golden_script("make_envelope")
     z = np.load(os.path.join(GOLDEN, "ref_envelope.npz"))
     big = scene.startswith("config")
-    aos, view, proj, pos, w, h = dict(me.scenes(small_only=not big, large=scene == "configB_rot"))[scene]
+    aos, view, proj, pos, w, h = dict(me.scenes(small_only=not big, large={"configB_rot": True, "configC_rot": "C"}.get(scene, False)))[scene]
     sc = _scene_from_matrices(aos, view, proj, pos, w, h)
     r = make_renderer(sc, w, h)
     img = r.draw(sc)
@@ -367,14 +368,15 @@ def test_parity_envelope(scene):
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
     assert [sha(img), sha(key), sha(box), sha(em)] == list(z[f"{scene}_contract_sha256"])
     assert e == int(z[f"{scene}_counter"])
-    large = scene == "configB_rot"
+    e_delta, boxes, positions, lists = {"configB_rot": (2, 1, 42, 21), "configC_rot": (5, 19, 0, 227)}.get(scene, (0, 0, 0, 0))
     for v in me.VARIANTS[1:]:
         assert z[f"{scene}_{v}_emits_idx"].size == 0
-        assert abs(int(z[f"{scene}_{v}_counter"]) - e) <= (2 if large else 0)
-        assert len(set((z[f"{scene}_{v}_box_idx"] // 4).tolist())) <= (1 if large else 0)
-        assert int(z[f"{scene}_{v}_sorted_positions_differ"]) <= (42 if large else 0) and int(z[f"{scene}_{v}_tile_lists_differ"]) <= (21 if large else 0)
-        vkey = me.apply_sparse(key, z[f"{scene}_{v}_key_idx"], z[f"{scene}_{v}_key_val"])
-        assert np.abs(vkey.astype(np.int64) - key.astype(np.int64)).max(initial=0) <= 192
+        assert abs(int(z[f"{scene}_{v}_counter"]) - e) <= e_delta
+        assert len(set((z[f"{scene}_{v}_box_idx"] // 4).tolist())) <= boxes
+        assert int(z[f"{scene}_{v}_sorted_positions_differ"]) <= positions and int(z[f"{scene}_{v}_tile_lists_differ"]) <= lists
+        if f"{scene}_{v}_key_idx" in z.files:                  # configC_rot: 630 k key differences, not kept
+            vkey = me.apply_sparse(key, z[f"{scene}_{v}_key_idx"], z[f"{scene}_{v}_key_val"])
+            assert np.abs(vkey.astype(np.int64) - key.astype(np.int64)).max(initial=0) <= 192
         vimg = me.apply_sparse(img, z[f"{scene}_{v}_rgba_idx"], z[f"{scene}_{v}_rgba_val"])
         assert np.abs(vimg.astype(np.int16) - img.astype(np.int16)).max(initial=0) <= 1
 
