@@ -861,6 +861,33 @@ def test_cpp_driver_runs(tmp_path):
         assert open(name, "rb").read() == data, name
 
 
+@pytest.mark.parametrize("ranks,rows", [(3, "contiguous"), (3, "interleaved"), (4, "interleaved"), (2, "contiguous")])
+def test_cpp_host_several_ranks_over_a_mock_rccl(tmp_path, ranks, rows):
+    """The multi-rank logic of csrc/gs_dist.cpp on the one GPU of a test box.  RCCL refuses two ranks on one device, so
+    tools/mock_rccl builds a stand-in librccl.so.1 (named pipes between the processes, staged through the host) and puts
+    it first on LD_LIBRARY_PATH: gs_dist.cpp's dlopen binds it, and tools/gsplat_bench.cpp --ranks R runs its real path --
+    fork before the first GPU call, id through pipes, gs_dist_init, gs_dist_shard_rows (23 tile rows over 2, 3, 4 ranks:
+    ragged last band / ragged interleaved shares), gs_render_sharded on every rank, the peers' strips received into the
+    root's buffer, rows dealt round-robin put back by one strided copy per rank -- and must write the file one GPU writes
+    alone.  What the mock cannot show is RCCL itself (transport, stream semantics): only where the bytes go."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(os.path.dirname(_lib.LIB_PATH), "gsplat_bench")
+    mock = os.path.join(ROOT, "tools", "mock_rccl")
+    subprocess.run(["make", "-C", mock], check=True, capture_output=True)
+    base = ["--synthetic", "60000", "--res", "640x360", "--warmup", "2", "--frames", "4"]
+    alone = str(tmp_path / "alone.ppm")
+    subprocess.run([exe] + base + ["--ppm", alone], check=True, capture_output=True, timeout=300)
+    out = str(tmp_path / "sharded.ppm")
+    env = dict(os.environ, LD_LIBRARY_PATH=mock + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), MOCK_RCCL_DIR=str(tmp_path),
+               GSPLAT_BENCH_SAME_DEVICE="1")
+    p = subprocess.run([exe] + base + ["--ppm", out, "--ranks", str(ranks)] + (["--interleaved"] if rows == "interleaved" else []),
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and f"ranks: {ranks}" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+    assert "RCCL version" not in p.stdout + p.stderr, "the real RCCL was bound, not the mock"
+    assert open(out, "rb").read() == open(alone, "rb").read()
+
+
 @pytest.mark.parametrize("with_torch", [False, True])
 def test_c_abi_sharded_frame_single_rank(with_torch):
     """The exchange step behind the C-ABI (gs_dist.cpp: RCCL bound at gs_dist_init, grouped ncclSend / ncclRecv on the

@@ -115,7 +115,9 @@ int main(int argc, char** argv) {
     }
 
     gs_config cfg; gs_default_config(&cfg);
-    cfg.device_ordinal = fork_test ? 0 : rank;
+    // GSPLAT_BENCH_SAME_DEVICE (tests only, with tools/mock_rccl first on LD_LIBRARY_PATH: RCCL itself refuses two ranks on
+    // one device): every rank on device 0, the real sharded path
+    cfg.device_ordinal = fork_test || std::getenv("GSPLAT_BENCH_SAME_DEVICE") ? 0 : rank;
     cfg.render_mode = fast ? GS_RENDER_FAST : GS_RENDER_EXACT;
     cfg.sort_algorithm = sort == "splat_first" ? GS_SORT_RADIX4_SPLAT_FIRST : sort == "bucket" ? GS_SORT_TILE_BUCKET
                        : sort == "radix8" ? GS_SORT_RADIX8 : sort == "radix8_splat_first" ? GS_SORT_RADIX8_SPLAT_FIRST : GS_SORT_RADIX4;
