@@ -1070,7 +1070,8 @@ def main():
             sys.stdout.flush()
             os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-    if (world > 1 and not args.rehearse and not args.no_extras) or args.c_abi_gather:
+    # (under --rehearse all ranks share one GPU, which RCCL refuses: the phase then needs GS_RCCL_LIBRARY = tools/mock_rccl)
+    if (world > 1 and not args.no_extras and (not args.rehearse or os.environ.get("GS_RCCL_LIBRARY"))) or args.c_abi_gather:
         import ctypes as C
         import threading
         from vk3dgaussiansplatting_amd import _lib
@@ -1130,7 +1131,7 @@ def main():
                 for _ in range(k_c):
                     frame_and_gather()
                 rc_.synchronize()
-                el_c = torch.tensor([(time.perf_counter() - t_c) / k_c * 1e3], dtype=torch.float64, device=device)
+                el_c = torch.tensor([(time.perf_counter() - t_c) / k_c * 1e3], dtype=torch.float64, device="cpu" if args.rehearse else device)
                 if world > 1:
                     tdist.all_reduce(el_c, op=tdist.ReduceOp.MAX)
                 ms_c = float(el_c.item())

@@ -237,7 +237,7 @@ int gs_get_scene_info(const gs_ctx* ctx, gs_scene_info* out);
  * rank renders its tile rows into a strip (gs_render_device* with gs_set_tile_rows*), and the strips meet on the
  * root over RCCL -- point-to-point transfers over xGMI inside a node, enqueued on the context's stream behind the
  * frame that wrote the strip.  RCCL is bound at gs_dist_init (librccl.so.1 by name, or the copy the process
- * already holds), not at link time.
+ * already holds; the environment variable GS_RCCL_LIBRARY names another build by path), not at link time.
  *   gs_dist_unique_id : ncclGetUniqueId -- call on ONE rank, hand the GS_DIST_UNIQUE_ID_BYTES bytes to the others by
  *                       any means (pipe, file, MPI, torch.distributed broadcast);
  *   gs_dist_init      : ncclCommInitRank for this context's GPU; collective over all `world` ranks;

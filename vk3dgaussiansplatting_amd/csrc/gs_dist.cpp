@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -36,9 +37,15 @@ struct Rccl {
 };
 
 void bind_rccl(Rccl& r) {
+    // GS_RCCL_LIBRARY: a deployment's own build of RCCL, by path (a path with a slash is opened as that file even when a
+    // library of the same SONAME is already mapped) -- and how the tests put tools/mock_rccl under a process that holds torch
+    if (const char* path = std::getenv("GS_RCCL_LIBRARY")) {
+        r.handle = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!r.handle) { r.error = std::string("GS_RCCL_LIBRARY: ") + dlerror(); return; }
+    }
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (r.handle) break;
+        r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!r.handle) { r.error = std::string("cannot load librccl.so.1: ") + dlerror(); return; }
     bool ok = true;
