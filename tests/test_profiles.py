@@ -85,3 +85,7 @@ def test_rehearsal_lines_carry_the_guarded_phases():
         assert set(d["alt_sorters"]) == {"radix8_splat_first", "bucket", "splat_first"}
         for name, a in d["alt_sorters"].items():
             assert a["sharded_image_matches_single_gpu"] is True and a["ms_per_step"] > 0, name
+    # the C-ABI gather phase with R > 1 (over tools/mock_rccl: RCCL refuses ranks that share a device)
+    for name, ranks in (("2ranks_interleaved", 2), ("3ranks_interleaved", 3), ("4ranks", 4)):
+        d = json.loads(open(P + f"bench_rehearse_{name}.json").read())
+        assert d["n_gpus"] == ranks and d["c_abi_gather"]["assembled_frame_matches"] is True and d["sharded_image_matches_single_gpu"] is True
