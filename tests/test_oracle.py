@@ -243,6 +243,28 @@ def test_config_c_through_the_reference_shader_text(oracle_mod):
     assert sha(r["image"]) == str(x["rgba_sha256"])
 
 
+def test_config_d_through_the_reference_shader_text(oracle_mod):
+    """BASELINE config D -- the 4K frame of the tile-row shard: config C's cloud at 3840 x 2160, E = 33,113,361, capacity
+    2^26 -- through the reference's own shader text (make_main_xcheck.py --config-d: 173 minutes and 8.6 GB on one core,
+    hashes only).  The oracle reproduces every hash; a 4K frame on the CPU takes minutes, so GS_ENVELOPE_FULL=1 only -- the
+    HIP path is compared with the same hashes in the GPU suite."""
+    import hashlib
+    if os.environ.get("GS_ENVELOPE_FULL") != "1":
+        pytest.skip("set GS_ENVELOPE_FULL=1 (a 4K config-D frame on the CPU); the GPU suite compares the HIP path with these hashes")
+    mm = _load_golden_script("make_main_xcheck")
+    x = np.load(os.path.join(GOLDEN, "ref_main_configD.npz"))
+    aos, view, proj, pos, w, h = mm.config_inputs("D")
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    r = oracle_mod.full_pipeline(oracle_mod.make_params(w, h, view, proj, pos, sh_mode=0), aos)
+    e, s1 = r["e"], r["stage1"]
+    assert s1["counter"] == int(x["counter"]) == 33113361 and s1["capacity"] == int(x["capacity"]) == 1 << 26
+    assert sha(np.stack([s1["tile"][:e], s1["depth"][:e], s1["id"][:e]], axis=1).astype(np.uint32)) == str(x["list_sha256"])
+    assert sha(np.stack([r["tile"][:e], r["depth"][:e], r["id"][:e]], axis=1).astype(np.uint32)) == str(x["sorted_sha256"])
+    assert sha(r["ranges"].astype(np.uint32)) == str(x["ranges_sha256"])
+    assert sha(s1["color"]) == str(x["color_sha256"]) and sha(s1["cov"]) == str(x["cov_sha256"])
+    assert sha(r["image"]) == str(x["rgba_sha256"])
+
+
 # What the parity envelope measured (tests/golden/make_envelope.py, profiles/r04_parity_envelope.txt): per scene the
 # largest figures over the four non-contract evaluations of the reference's text.
 #   keys: fraction of emitting splats whose depth key moves | dkey: largest |key difference| | moved: channel values that move

@@ -273,13 +273,11 @@ def test_config_a_through_the_reference_shader_text(sort):
 
 def test_config_d_through_the_reference_shader_text():
     """BASELINE config D -- the 4K frame of the tile-row shard: config C's cloud at 3840 x 2160, E = 33.1 M, capacity 2^26 --
-    against the hashes of what the reference's own shader text produces for it (tests/golden/ref_main_configD.npz: about
-    three hours of fibers in the authoring container; no oracle code runs): emitted list, sorted list, ranges, covariance
-    and all 8.3 M pixels.  Skipped until that fixture has been generated."""
+    against the hashes of what the reference's own shader text produces for it (tests/golden/ref_main_configD.npz: 173
+    minutes of fibers in the authoring container; no oracle code runs): emitted list, sorted list, ranges, covariance
+    and all 8.3 M pixels."""
     import hashlib
     path = os.path.join(GOLDEN, "ref_main_configD.npz")
-    if not os.path.exists(path):
-        pytest.skip("ref_main_configD.npz not generated (make_main_xcheck.py --config-d, ~3 h)")
     mm = _golden_script("make_main_xcheck")
     x = np.load(path)
     aos, view, proj, pos, w, h = mm.config_inputs("D")
