@@ -12,7 +12,7 @@ glm by oracle/ref_main_xcheck.cpp, authoring container only) are run five ways o
               division to 2.5 ULP, and `ndc.xyz /= ndc.w` (InitSortList.comp:99, Common.glsl:84) is three divisions by
               one w (10 of the harness's 19 division instructions turn into reciprocal multiplies).
 
-  small   : the 600 splats of small_scene.npz under its camera (SH mode 0)
+  small   : the 600 splats of small_scene.npz under its camera (SH mode 0; small_sh1, small_sh2: SH modes 1 and 2)
   dense   : make_main_xcheck.dense_inputs() -- 2,500 large, mostly opaque splats, lists of up to 296 entries
   extreme : make_glsl_xcheck.extreme_inputs() -- scales 1e-7 .. 1e4, splats on the cull planes, zero quaternions --
             without the splats at or beyond the far plane, whose depth key GLSL leaves undefined (key_is_defined)
@@ -52,6 +52,8 @@ def _load(name):
 def scenes(small_only=False, large=False):
     g = np.load(os.path.join(GOLDEN, "small_scene.npz"))
     yield "small", (g["aos"], g["view"], g["proj"], g["cam_pos"], int(g["width"]), int(g["height"]))
+    for mode in (1, 2):      # the other two SH modes (Camera.h:7-12): only the colours -- and so the pixels -- can differ from mode 0
+        yield f"small_sh{mode}", (g["aos"], g["view"], g["proj"], g["cam_pos"], int(g["width"]), int(g["height"]), mode)
     yield "dense", _load("make_main_xcheck").dense_inputs()
     aos, view, proj, pos, w, h = _load("make_glsl_xcheck").extreme_inputs()
     yield "extreme", (aos[key_is_defined(aos, view)], view, proj, pos, w, h)
@@ -139,9 +141,10 @@ def run_scene(name, inputs, workers=5):
     """The four dumps of one scene (the harness is single-threaded: the variants run side by side)."""
     from concurrent.futures import ThreadPoolExecutor
     mm = _load("make_main_xcheck")
-    aos, view, proj, pos, w, h = inputs
+    aos, view, proj, pos, w, h = inputs[:6]
+    sh_mode = inputs[6] if len(inputs) > 6 else 0
     with ThreadPoolExecutor(workers) as pool:
-        futs = {v: pool.submit(mm.run, aos, view, proj, pos, w, h, 0, EXE[v]) for v in VARIANTS}
+        futs = {v: pool.submit(mm.run, aos, view, proj, pos, w, h, sh_mode, EXE[v]) for v in VARIANTS}
         return {v: f.result() for v, f in futs.items()}
 
 
@@ -151,7 +154,7 @@ def record(name, inputs, dumps, keep, lines):
     of the contract's arrays (the oracle reproduces those bit for bit, so a test rebuilds every variant from the oracle's
     output); appends the scene's rows of the table to `lines`."""
     import hashlib
-    aos, view, proj, pos, w, h = inputs
+    aos, view, proj, pos, w, h = inputs[:6]
     n, grid_w = aos.shape[0], (w + 15) // 16
     base = dumps["contract"]
     b_em, b_key, b_box = per_splat(base["list"], n, grid_w)

@@ -272,6 +272,8 @@ def test_config_d_through_the_reference_shader_text(oracle_mod):
 #   differs (None: the lists differ in length) | lists: tile lists that differ
 ENVELOPE_BOUNDS = {
     "small": dict(keys=0.24, dkey=192, moved=1, boxes=0, e_delta=0, sorted=0, lists=0),
+    "small_sh1": dict(keys=0.24, dkey=192, moved=0, boxes=0, e_delta=0, sorted=0, lists=0),      # SH modes 1 and 2 (Camera.h:7-12)
+    "small_sh2": dict(keys=0.24, dkey=192, moved=0, boxes=0, e_delta=0, sorted=0, lists=0),
     "dense": dict(keys=0.16, dkey=128, moved=1, boxes=0, e_delta=0, sorted=0, lists=0),
     "extreme": dict(keys=0.29, dkey=192, moved=0, boxes=0, e_delta=0, sorted=0, lists=0),
     "configA": dict(keys=0.0, dkey=0, moved=14, boxes=0, e_delta=0, sorted=0, lists=0),
@@ -288,7 +290,7 @@ def test_parity_envelope(oracle_mod, scene):
     HIP path) implement?  tests/golden/ref_envelope.npz holds what the nine main() bodies produce when nothing is
     imposed on them -- glm's own mat4 * vec4 association and normalize, libm's expf (`native`), the same with every
     a * b + c fused (`native_fma`), with exp(x) = exp2(x log2 e) on top (`gpu_like`), and with divisions turned into
-    reciprocal multiplies as well (`gpu_like_rcp`) -- as differences from the contract's dump, for six scenes up to
+    reciprocal multiplies as well (`gpu_like_rcp`) -- as differences from the contract's dump, for nine scenes up to
     BASELINE config A at full size and config B's cloud under a rotated camera (E = 2.26 M).  Measured and asserted here
     against the oracle's own output:
       * depth keys move in 14-29 % of the splats under a rotated camera, by at most 1.5 units in the last place of the
@@ -311,14 +313,15 @@ def test_parity_envelope(oracle_mod, scene):
     if scene == "configC_rot" and os.environ.get("GS_ENVELOPE_FULL") != "1":
         pytest.skip("set GS_ENVELOPE_FULL=1 (a config-C frame on the CPU); the GPU suite runs this scene")
     inputs = dict(me.scenes(small_only=not big, large={"configB_rot": True, "configC_rot": "C"}.get(scene, False)))[scene]
-    aos, view, proj, pos, w, h = inputs
+    aos, view, proj, pos, w, h = inputs[:6]
+    sh_mode = inputs[6] if len(inputs) > 6 else 0
     n, grid_w = aos.shape[0], (w + 15) // 16
     if _reference_harness_present() and (not big or (os.environ.get("GS_ENVELOPE_FULL") == "1" and scene.startswith("configA"))):
         keep, lines = {}, []
         me.record(scene, inputs, me.run_scene(scene, inputs), keep, lines)
         for k, v in keep.items():
             assert np.asarray(v).tobytes() == np.asarray(z[k]).tobytes(), k
-    r = oracle_mod.full_pipeline(oracle_mod.make_params(w, h, view, proj, pos, sh_mode=0), aos)
+    r = oracle_mod.full_pipeline(oracle_mod.make_params(w, h, view, proj, pos, sh_mode=sh_mode), aos)
     e, s1 = r["e"], r["stage1"]
     lst = np.stack([s1["tile"][:e], s1["depth"][:e], s1["id"][:e]], axis=1)
     em, key, box = me.per_splat(lst, n, grid_w)

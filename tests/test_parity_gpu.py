@@ -342,7 +342,7 @@ def test_config_b_through_the_reference_shader_text(sort):
     r.cleanup()
 
 
-@pytest.mark.parametrize("scene", ["small", "dense", "extreme", "configA", "configA_rot", "configB_rot", "configC_rot"])
+@pytest.mark.parametrize("scene", ["small", "small_sh1", "small_sh2", "dense", "extreme", "configA", "configA_rot", "configB_rot", "configC_rot"])
 def test_parity_envelope(scene):
     """The HIP frame against the OTHER legal evaluations of the reference's shader text (tests/golden/ref_envelope.npz,
     make_envelope.py; no oracle code runs): the frame, the per-splat depth keys, tile boxes and emit flags of the HIP
@@ -356,8 +356,10 @@ def test_parity_envelope(scene):
     me = _golden_script("make_envelope")
     z = np.load(os.path.join(GOLDEN, "ref_envelope.npz"))
     big = scene.startswith("config")
-    aos, view, proj, pos, w, h = dict(me.scenes(small_only=not big, large={"configB_rot": True, "configC_rot": "C"}.get(scene, False)))[scene]
+    inputs = dict(me.scenes(small_only=not big, large={"configB_rot": True, "configC_rot": "C"}.get(scene, False)))[scene]
+    aos, view, proj, pos, w, h = inputs[:6]
     sc = _scene_from_matrices(aos, view, proj, pos, w, h)
+    sc.camera.setShMode(inputs[6] if len(inputs) > 6 else 0)
     r = make_renderer(sc, w, h)
     img = r.draw(sc)
     e = r.timings().emitted_elements
