@@ -301,11 +301,18 @@ __global__ __launch_bounds__(kCullThreads) void k_band_cull(const FrameParams fp
         sc.band_list[s_base + before + (uint32_t)__builtin_popcountll(vote & ((1ull << lane) - 1ull))] = b | (mask << 28);
 }
 
+template <bool NT>
+__device__ __forceinline__ float sh_load(const float* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+
 // Seven workgroups per CU: left to itself the compiler hoists the 48 SH loads and takes 117 VGPRs (four waves per SIMD);
 // held to 72 it needs 65 without spilling, and the launch is 30 us shorter at config C (209 against 239 us).
 #ifndef GS_PROJECT_MINBLOCKS
 #define GS_PROJECT_MINBLOCKS 7
 #endif
+// NT_SH: the 48 spherical-harmonics planes (192 of the 236 bytes a splat's record takes) are loaded non-temporally -- a
+// frame reads each of them once, and a scene larger than the 256 MiB Infinity Cache cannot keep them from one frame to
+// the next anyway, while its other planes and the frame's lists can use the space (launch_project picks by scene size).
+template <bool NT_SH>
 __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(const FrameParams fp,
                                                            const SceneBuffers scene,
                                                            const SplatScratch sc, const uint32_t num_blocks) {
@@ -437,18 +444,18 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
                             for (int i = 0; i < 16; ++i)
 #pragma unroll
                                 for (int c = 0; c < 3; ++c)
-                                    res[c] = res[c] + shp[(size_t)(i * 3 + c) * n] * basis[i];
+                                    res[c] = res[c] + sh_load<NT_SH>(shp + (size_t)(i * 3 + c) * n) * basis[i];
                         } else if (fp.sh_mode == 1u) {
 #pragma unroll
                             for (int i = 1; i < 16; ++i)
 #pragma unroll
                                 for (int c = 0; c < 3; ++c)
-                                    res[c] = res[c] + shp[(size_t)(i * 3 + c) * n] * basis[i];
+                                    res[c] = res[c] + sh_load<NT_SH>(shp + (size_t)(i * 3 + c) * n) * basis[i];
 #pragma unroll
                             for (int c = 0; c < 3; ++c) res[c] = res[c] - 0.5f;
                         } else if (fp.sh_mode == 2u) {
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) res[c] = res[c] + shp[(size_t)c * n] * basis[0];
+                            for (int c = 0; c < 3; ++c) res[c] = res[c] + sh_load<NT_SH>(shp + (size_t)c * n) * basis[0];
                         }
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
@@ -756,7 +763,13 @@ void launch_project(const FrameParams& fp, const SceneBuffers& scene, const Spla
     const bool listed = !(fp.row_begin == 0u && fp.row_end == fp.grid_h) && fp.row_stride == 1u;   // a contiguous band
     if (listed) hipLaunchKernelGGL(k_band_cull, dim3((blocks * 4u + (uint32_t)kCullThreads - 1u) / (uint32_t)kCullThreads), dim3(kCullThreads), 0, stream,
                                    fp, scene, sc, blocks);
-    hipLaunchKernelGGL(k_project, dim3(blocks), dim3(kProjThreads), 0, stream, fp, scene, sc, blocks);
+#ifndef GS_PROJECT_NT_SH_ABOVE
+#define GS_PROJECT_NT_SH_ABOVE ((size_t)256u << 20)       /* scene bytes above which the SH planes are loaded non-temporally */
+#endif
+    if ((size_t)fp.num_gaussians * 236u > GS_PROJECT_NT_SH_ABOVE)
+        hipLaunchKernelGGL(k_project<true>, dim3(blocks), dim3(kProjThreads), 0, stream, fp, scene, sc, blocks);
+    else
+        hipLaunchKernelGGL(k_project<false>, dim3(blocks), dim3(kProjThreads), 0, stream, fp, scene, sc, blocks);
 }
 
 void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParams* params,
