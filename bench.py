@@ -14,7 +14,10 @@ and the wall clock of a frame with a host wait per frame (Renderer.cpp:459) are 
 
 --gpus N > 1: this script starts its own N ranks (python -m torch.distributed.run, one process per GPU, RCCL) unless it
 already runs inside such a launch (WORLD_SIZE set); the frame is sharded by screen-tile rows and the RGBA8 strips are
-gathered to rank 0 every step (strong scaling: the frame is fixed).  Rank 0 prints ONE JSON line.
+gathered to rank 0 every step (strong scaling: the frame is fixed -- the same config C at every N, so that the lines of
+--gpus 1, 2, 4, 8 form one series).  The 4K frame BASELINE.json names for the tile-row shard (config D: the same cloud at
+3840x2160) rides along: `sharded_4k` in the N > 1 lines, `sharded_workload_on_one_gpu` in the one-GPU line.  Rank 0
+prints ONE JSON line.
 """
 import argparse
 import json
@@ -49,8 +52,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default=None, choices=sorted(WORKLOADS),
-                    help="default: C (the headline shape) on one GPU, D (the 4K frame BASELINE.json names for the "
-                         "tile-row shard) on several")
+                    help="default: C (the headline shape) at every N, so that --gpus 1, 2, 4, 8 time one workload; with N > 1 "
+                         "the line also carries D (the 4K frame BASELINE.json names for the tile-row shard) as `sharded_4k`")
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
     ap.add_argument("--sort", default="radix4", choices=["radix4", "bucket", "splat_first", "radix8", "radix8_splat_first"],
                     help="radix4 = the contractual nine-stage sort (default); bucket = GS_SORT_TILE_BUCKET; "
@@ -309,7 +312,7 @@ def main():
             f"{world}-rank measurement as a {args.gpus}-GPU one")
         sys.exit(2)
     if args.config is None:
-        args.config = "C" if world == 1 else "D"
+        args.config = "C"          # the headline shape at every N: a scaling series over --gpus 1, 2, 4, 8 times ONE workload
     if args.dry_run:
         sys.exit(dry_run(args, world, rank))
 
@@ -381,8 +384,9 @@ def main():
                 "radix8": gs.GS_SORT_RADIX8, "radix8_splat_first": gs.GS_SORT_RADIX8_SPLAT_FIRST}
     interleaved = args.rows == "interleaved" and world > 1
 
-    def make(record, sort=None, share=None, render_mode=None):
-        r = gs.Renderer(w, h, device=local_rank, render_mode=mode if render_mode is None else render_mode,
+    def make(record, sort=None, share=None, render_mode=None, res=None):
+        rw, rh = res or (w, h)
+        r = gs.Renderer(rw, rh, device=local_rank, render_mode=mode if render_mode is None else render_mode,
                         record_timings=record, warmup_frames=0,
                         sort_algorithm=sort_ids[sort or args.sort],
                         render_kernel=0 if args.render_kernel == "auto" else int(args.render_kernel))
@@ -401,20 +405,21 @@ def main():
         the gaussian arrays are uploaded once and shared (gs_share_scene).  Frame f goes to slot f % F.  F = 1 is a
         frame's GPU time (nothing overlaps); F = 3 is the reference's FRAMES_IN_FLIGHT."""
 
-        def __init__(self, F, sort=None, owner=None, render_mode=None):
+        def __init__(self, F, sort=None, owner=None, render_mode=None, res=None):
             self.F, self.n = F, 0
+            rw, rh = res or (w, h)
             # N > 1: at least two strips, so that the gather of frame f runs beside the rendering of frame f + 1 (the
             # rasterization itself stays in F slots; only the collective is double-buffered)
             self.S = max(F, 2) if world > 1 else F
-            self.sf = gsdist.ShardedFrame(w, h, rank, world, device=device, host_gather=args.rehearse, n_strips=self.S,
+            self.sf = gsdist.ShardedFrame(rw, rh, rank, world, device=device, host_gather=args.rehearse, n_strips=self.S,
                                           interleaved=interleaved)
             rb = 0 if interleaved else self.sf.band[0]
             # the library addresses the FULL frame; hand it the strips shifted up by the band's first row
-            self.ptrs = [s_.data_ptr() - rb * 16 * w * 4 for s_ in self.sf.strips] if not interleaved else \
+            self.ptrs = [s_.data_ptr() - rb * 16 * rw * 4 for s_ in self.sf.strips] if not interleaved else \
                         [s_.data_ptr() for s_ in self.sf.strips]
             self.rs, self.streams = [], []
             for k in range(F):
-                rk = make(0, sort, share=owner if owner is not None else (self.rs[0] if k else None), render_mode=render_mode)
+                rk = make(0, sort, share=owner if owner is not None else (self.rs[0] if k else None), render_mode=render_mode, res=res)
                 set_rows(rk, self.sf)
                 st = torch.cuda.Stream(device=device)
                 rk.setStream(st.cuda_stream)
@@ -708,6 +713,58 @@ def main():
                 "speedup_vs_one_gpu_same_frame": round(one_a / ms_a, 3) if one_a else None,
                 "speedup_vs_one_gpu_default_sorter": round(one_gpu_ms / ms_a, 3) if one_gpu_ms else None}
 
+    def sharded_4k_phase():
+        # BASELINE.json's shard config: the same cloud at 3840 x 2160 (config D), sharded over the same ranks -- guarded like
+        # the sorter phases; timed like the headline; rank 0 also renders the 4K frame alone (the base of ITS speed-up)
+        cfg_d = synth.CONFIGS["D"]
+        assert (cfg_d["n"], cfg_d["mu"], cfg_d["seed"]) == (cfg["n"], cfg["mu"], cfg["seed"])
+        res_d = (cfg_d["width"], cfg_d["height"])
+        ra, err = None, None
+        try:
+            ra = Ring(1, owner=owner, res=res_d)
+        except Exception as ex:  # noqa: BLE001
+            err = repr(ex)
+        if not flag_all(err is None):
+            if ra is not None:
+                ra.close()
+            return {"skipped": err or "set-up failed on another rank"}
+        with torch.cuda.stream(ra.streams[0]):
+            ra.sf.wait(0)
+            ra.rs[0].drawDevice(scene, ra.ptrs[0], sync=False, compact_rows=interleaved)
+            strips_d = ra.sf.gather(0)
+        torch.cuda.synchronize()
+        assembled = ra.sf.assemble(strips_d) if rank == 0 else None
+        ms_d = ra.timed(min(args.steps, 200), 10)
+        ra.close()
+        same, one_d = None, None
+        if rank == 0:
+            full_d = torch.zeros((res_d[1], res_d[0], 4), dtype=torch.uint8, device=device)
+            rf_ = make(1, share=owner, res=res_d)
+            rf_.setStream(torch.cuda.current_stream().cuda_stream)
+            tot_ = []
+            for i in range(13):
+                rf_.drawDevice(scene, full_d.data_ptr(), sync=True)
+                if i >= 3:
+                    tot_.append(rf_.timings().total_ms)
+            one_d = float(np.mean(tot_))
+            rf_.setStream(None)
+            rf_.cleanup()
+            same = bool(torch.equal(assembled.to(full_d.device), full_d))
+        tdist.barrier()
+        return {"workload": WORKLOADS["D"], "ms_per_step": round(ms_d, 4), "value": round(n / ms_d / 1000.0, 2), "unit": "Msplats/s",
+                "sharded_image_matches_single_gpu": same,
+                "one_gpu_same_frame_ms": round(one_d, 4) if one_d else None,
+                "speedup_vs_one_gpu_same_frame": round(one_d / ms_d, 3) if one_d else None,
+                "note": "BASELINE.json's tile-row-shard config (config C's cloud at 3840 x 2160) over the same ranks, timed like the "
+                        "headline (one frame slot, gather included, slowest rank)"}
+
+    if not args.no_extras and world > 1 and args.config == "C":
+        try:
+            extras["sharded_4k"] = sharded_4k_phase()
+        except Exception as ex:  # noqa: BLE001
+            log(f"[bench] 4K phase failed on rank {rank}: {ex!r}")
+            extras["sharded_4k"] = {"error": repr(ex)}
+
     if not args.no_extras and world > 1:
         alt = {}
         for name in ("radix8_splat_first", "bucket", "splat_first"):
@@ -776,9 +833,9 @@ def main():
                         "roofline.traffic / roofline.moved.bytes_per_launch) over the HIP-event mean of those launches"}
 
     def x_sharded_workload_on_one_gpu():
-        # `--gpus N` with N > 1 times config D, the 4K frame BASELINE.json names for the tile-row shard -- the SAME cloud as
-        # config C at four times the pixels.  A scaling series that starts with this one-GPU line therefore needs the 4K frame
-        # on one GPU as its base, not the headline: here it is, timed like the headline (one frame slot, image left in HBM)
+        # `--gpus N` with N > 1 also times config D (`sharded_4k`), the 4K frame BASELINE.json names for the tile-row shard --
+        # the SAME cloud as config C at four times the pixels.  The base of that second series, on one GPU, timed like the
+        # headline (one frame slot, image left in HBM)
         cfg_d = synth.CONFIGS["D"]
         assert (cfg_d["n"], cfg_d["mu"], cfg_d["seed"]) == (cfg["n"], cfg["mu"], cfg["seed"])
         wd, hd = cfg_d["width"], cfg_d["height"]
@@ -799,8 +856,8 @@ def main():
         rd.setStream(None)
         rd.cleanup()
         return {"workload": WORKLOADS["D"], "ms_per_step": round(ms_d, 4), "value": round(n / ms_d / 1000.0, 2), "unit": "Msplats/s",
-                "note": "what `python bench.py --gpus N` shards for N > 1, on this one GPU: the base of a strong-scaling series over "
-                        "that frame (the N > 1 lines repeat it as one_gpu_same_frame_ms, measured on their rank 0)"}
+                "note": "the 4K frame of the N > 1 lines' `sharded_4k`, on this one GPU: the base of a strong-scaling series over "
+                        "that frame (those lines repeat it as sharded_4k.one_gpu_same_frame_ms, measured on their rank 0)"}
 
     if not args.no_extras and world == 1 and args.config == "C" and args.sort in ("radix4", "radix8"):
         extra("hbm_resident", x_hbm_resident)

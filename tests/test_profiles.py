@@ -79,12 +79,17 @@ def test_dominant_kernel_roofline_recomputes(line):
 
 
 def test_rehearsal_lines_carry_the_guarded_phases():
+    one = json.loads(open(P + "bench_configC.json").read())
     for ranks in (2, 4):
         d = json.loads(open(P + f"bench_rehearse_{ranks}ranks.json").read())
         assert d["n_gpus"] == ranks and d["sharded_image_matches_single_gpu"] is True
         assert set(d["alt_sorters"]) == {"radix8_splat_first", "bucket", "splat_first"}
         for name, a in d["alt_sorters"].items():
             assert a["sharded_image_matches_single_gpu"] is True and a["ms_per_step"] > 0, name
+        # every N times the headline's frame (one series over --gpus 1, 2, 4, 8); the 4K frame of the shard rides along
+        assert d["config"]["width"] == 1920 and d["config"]["workload"] == one["config"]["workload"]
+        k4 = d["sharded_4k"]
+        assert "3840x2160" in k4["workload"] and k4["sharded_image_matches_single_gpu"] is True and k4["ms_per_step"] > 0
     # the C-ABI gather phase with R > 1 (over tools/mock_rccl: RCCL refuses ranks that share a device)
     for name, ranks in (("2ranks_interleaved", 2), ("3ranks_interleaved", 3), ("4ranks", 4)):
         d = json.loads(open(P + f"bench_rehearse_{name}.json").read())

@@ -12,7 +12,8 @@ python - <<'PY'
 import json
 for g in (2, 3, 4):
     d = json.loads(open(f"gpurun_out/r04_inter/r_{g}.json").read().strip().splitlines()[-1])
-    print(g, d["config"]["parallelism"], d["sharded_image_matches_single_gpu"], d.get("c_abi_gather"),
+    print(g, d["config"]["workload"][:18], d["config"]["parallelism"], d["sharded_image_matches_single_gpu"], d.get("c_abi_gather"),
+          "4K:", {k: d.get("sharded_4k", {}).get(k) for k in ("sharded_image_matches_single_gpu", "skipped", "error")},
           {k: (v.get("sharded_image_matches_single_gpu"), v.get("skipped"), v.get("error")) for k, v in d["alt_sorters"].items()})
 PY
 tail -3 $o/r_2.err
