@@ -676,87 +676,72 @@ def main():
     def flag_all(ok):
         return all_ranks_ok(tdist, ok, "cpu" if args.rehearse else device)
 
-    def alt_phase(name):
+    def sharded_phase(sort=None, res=None, ref_img=None):
+        """One guarded phase: the frame at `res` (default: the timed one) with sorter `sort` (default: the timed one) over the
+        same ranks, timed like the headline; rank 0 also renders it alone with that sorter.  Returns (fields, rank 0's frame)."""
+        rw, rh = res or (w, h)
         ra, err = None, None
         try:
-            ra = Ring(1, sort=name, owner=owner)
+            ra = Ring(1, sort=sort, owner=owner, res=res)
         except Exception as ex:  # noqa: BLE001
             err = repr(ex)
         if not flag_all(err is None):
             if ra is not None:
                 ra.close()
-            return {"skipped": err or "set-up failed on another rank"}
+            return {"skipped": err or "set-up failed on another rank"}, None
         with torch.cuda.stream(ra.streams[0]):
             ra.sf.wait(0)
             ra.rs[0].drawDevice(scene, ra.ptrs[0], sync=False, compact_rows=interleaved)
             strips_a = ra.sf.gather(0)
         torch.cuda.synchronize()
-        same = bool(torch.equal(ra.sf.assemble(strips_a).to(full.device), full)) if rank == 0 else None
+        assembled = ra.sf.assemble(strips_a) if rank == 0 else None
         ms_a = ra.timed(min(args.steps, 200), 10)
         ra.close()
-        one_a = None
+        one_a, same, alone = None, None, None
         if rank == 0:                                  # the same frame on one GPU alone with this sorter
-            rf_ = make(1, sort=name, share=owner)
+            alone = torch.zeros((rh, rw, 4), dtype=torch.uint8, device=device)
+            rf_ = make(1, sort=sort, share=owner, res=res)
             rf_.setStream(torch.cuda.current_stream().cuda_stream)
             tot_ = []
             for i in range(13):
-                rf_.drawDevice(scene, full.data_ptr(), sync=True)
+                rf_.drawDevice(scene, alone.data_ptr(), sync=True)
                 if i >= 3:
                     tot_.append(rf_.timings().total_ms)
             one_a = float(np.mean(tot_))
             rf_.setStream(None)
             rf_.cleanup()
+            want = alone if ref_img is None else ref_img        # ref_img: the default sorter's one-GPU frame
+            same = bool(torch.equal(assembled.to(want.device), want)) and bool(torch.equal(alone, want))
         tdist.barrier()
         return {"ms_per_step": round(ms_a, 4), "value": round(n / ms_a / 1000.0, 2), "unit": "Msplats/s",
                 "sharded_image_matches_single_gpu": same,
                 "one_gpu_same_frame_ms": round(one_a, 4) if one_a else None,
-                "speedup_vs_one_gpu_same_frame": round(one_a / ms_a, 3) if one_a else None,
-                "speedup_vs_one_gpu_default_sorter": round(one_gpu_ms / ms_a, 3) if one_gpu_ms else None}
+                "speedup_vs_one_gpu_same_frame": round(one_a / ms_a, 3) if one_a else None}, alone
+
+    def alt_phase(name):
+        out, _ = sharded_phase(sort=name, ref_img=full if rank == 0 else None)
+        if "skipped" not in out:
+            out["speedup_vs_one_gpu_default_sorter"] = round(one_gpu_ms / out["ms_per_step"], 3) if one_gpu_ms else None
+        return out
 
     def sharded_4k_phase():
         # BASELINE.json's shard config: the same cloud at 3840 x 2160 (config D), sharded over the same ranks -- guarded like
-        # the sorter phases; timed like the headline; rank 0 also renders the 4K frame alone (the base of ITS speed-up)
+        # the sorter phases; timed like the headline; rank 0 also renders the 4K frame alone (the base of ITS speed-up).
+        # Then once more with the 8-bit passes on the splats first, the sorter that lifts a share's latency floor most.
         cfg_d = synth.CONFIGS["D"]
         assert (cfg_d["n"], cfg_d["mu"], cfg_d["seed"]) == (cfg["n"], cfg["mu"], cfg["seed"])
         res_d = (cfg_d["width"], cfg_d["height"])
-        ra, err = None, None
-        try:
-            ra = Ring(1, owner=owner, res=res_d)
-        except Exception as ex:  # noqa: BLE001
-            err = repr(ex)
-        if not flag_all(err is None):
-            if ra is not None:
-                ra.close()
-            return {"skipped": err or "set-up failed on another rank"}
-        with torch.cuda.stream(ra.streams[0]):
-            ra.sf.wait(0)
-            ra.rs[0].drawDevice(scene, ra.ptrs[0], sync=False, compact_rows=interleaved)
-            strips_d = ra.sf.gather(0)
-        torch.cuda.synchronize()
-        assembled = ra.sf.assemble(strips_d) if rank == 0 else None
-        ms_d = ra.timed(min(args.steps, 200), 10)
-        ra.close()
-        same, one_d = None, None
-        if rank == 0:
-            full_d = torch.zeros((res_d[1], res_d[0], 4), dtype=torch.uint8, device=device)
-            rf_ = make(1, share=owner, res=res_d)
-            rf_.setStream(torch.cuda.current_stream().cuda_stream)
-            tot_ = []
-            for i in range(13):
-                rf_.drawDevice(scene, full_d.data_ptr(), sync=True)
-                if i >= 3:
-                    tot_.append(rf_.timings().total_ms)
-            one_d = float(np.mean(tot_))
-            rf_.setStream(None)
-            rf_.cleanup()
-            same = bool(torch.equal(assembled.to(full_d.device), full_d))
-        tdist.barrier()
-        return {"workload": WORKLOADS["D"], "ms_per_step": round(ms_d, 4), "value": round(n / ms_d / 1000.0, 2), "unit": "Msplats/s",
-                "sharded_image_matches_single_gpu": same,
-                "one_gpu_same_frame_ms": round(one_d, 4) if one_d else None,
-                "speedup_vs_one_gpu_same_frame": round(one_d / ms_d, 3) if one_d else None,
-                "note": "BASELINE.json's tile-row-shard config (config C's cloud at 3840 x 2160) over the same ranks, timed like the "
-                        "headline (one frame slot, gather included, slowest rank)"}
+        out, frame_d = sharded_phase(res=res_d)
+        if "skipped" in out:
+            return out
+        out = {"workload": WORKLOADS["D"], **out,
+               "note": "BASELINE.json's tile-row-shard config (config C's cloud at 3840 x 2160) over the same ranks, timed like the "
+                       "headline (one frame slot, gather included, slowest rank)"}
+        fast, _ = sharded_phase(sort="radix8_splat_first", res=res_d, ref_img=frame_d)
+        if "skipped" not in fast and out["one_gpu_same_frame_ms"]:
+            fast["speedup_vs_one_gpu_default_sorter"] = round(out["one_gpu_same_frame_ms"] / fast["ms_per_step"], 3)
+        out["radix8_splat_first"] = fast
+        return out
 
     if not args.no_extras and world > 1 and args.config == "C":
         try:

@@ -90,6 +90,7 @@ def test_rehearsal_lines_carry_the_guarded_phases():
         assert d["config"]["width"] == 1920 and d["config"]["workload"] == one["config"]["workload"]
         k4 = d["sharded_4k"]
         assert "3840x2160" in k4["workload"] and k4["sharded_image_matches_single_gpu"] is True and k4["ms_per_step"] > 0
+        assert k4["radix8_splat_first"]["sharded_image_matches_single_gpu"] is True
     # the C-ABI gather phase with R > 1 (over tools/mock_rccl: RCCL refuses ranks that share a device)
     for name, ranks in (("2ranks_interleaved", 2), ("3ranks_interleaved", 3), ("4ranks", 4)):
         d = json.loads(open(P + f"bench_rehearse_{name}.json").read())
