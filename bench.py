@@ -743,26 +743,6 @@ def main():
         out["radix8_splat_first"] = fast
         return out
 
-    if not args.no_extras and world > 1 and args.config == "C":
-        try:
-            extras["sharded_4k"] = sharded_4k_phase()
-        except Exception as ex:  # noqa: BLE001
-            log(f"[bench] 4K phase failed on rank {rank}: {ex!r}")
-            extras["sharded_4k"] = {"error": repr(ex)}
-
-    if not args.no_extras and world > 1:
-        alt = {}
-        for name in ("radix8_splat_first", "bucket", "splat_first"):
-            if name != args.sort:
-                try:
-                    alt[name] = alt_phase(name)
-                except Exception as ex:  # noqa: BLE001 -- past the guard: report, the headline is already measured
-                    log(f"[bench] alt sorter phase '{name}' failed on rank {rank}: {ex!r}")
-                    alt[name] = {"error": repr(ex)}
-        extras["alt_sorters"] = alt
-        extras["alt_sorters_note"] = ("the same sharded frame with the opt-in sorters (identical keys, ranges, pixels), timed as the headline "
-                                      "(one frame slot, gather included, slowest rank); the contract's 4-bit passes stay the headline")
-
     # extras run collectives of their own (Ring.timed): with several ranks one rank failing inside an extra would leave
     # the others waiting in it, so they are a one-GPU feature
     if not args.no_extras and world == 1:
@@ -1103,15 +1083,55 @@ def main():
     else:
         out = None
 
-    # ---- the same gather through the C-ABI (gs_dist_init / gs_gather_strips: RCCL bound by the library itself, grouped
-    #      ncclSend / ncclRecv on the context's stream) -- what a C++ host uses (tools/gsplat_bench.cpp --ranks N).  Last,
-    #      and under a watchdog: no N-GPU box is reachable while this is written, and a communicator of our own that hangs
-    #      must cost the run this block, not its line.
+    # ---- the guarded phases of a run with several ranks: after the line is assembled and under a watchdog, so that a
+    #      collective that hangs inside one of them costs the run these blocks, not its line
     def emit_line():
         if rank == 0:
             sys.stdout.flush()
             os.write(json_fd, (json.dumps(out) + "\n").encode())
 
+    if world > 1 and not args.no_extras:
+        import threading
+        limit_s = float(os.environ.get("GS_BENCH_PHASES_LIMIT_S", "300"))
+        phases = {}
+
+        def give_up_phases():
+            log(f"[bench] rank {rank}: the guarded phases did not finish within {limit_s:.0f} s: giving them up")
+            if rank == 0:
+                out.update(phases)
+                out["guarded_phases_error"] = f"timed out after {limit_s:.0f} s (the line above them is complete)"
+                emit_line()
+            os._exit(0 if sharded_ok is not False else 3)
+        dog_p = threading.Timer(limit_s, give_up_phases)
+        dog_p.daemon = True
+        dog_p.start()
+        if os.environ.get("GS_BENCH_HANG_IN_PHASES") == str(rank):      # test knob: this rank never reaches the phases
+            time.sleep(3600.0)
+        if args.config == "C":
+            try:
+                phases["sharded_4k"] = sharded_4k_phase()
+            except Exception as ex:  # noqa: BLE001
+                log(f"[bench] 4K phase failed on rank {rank}: {ex!r}")
+                phases["sharded_4k"] = {"error": repr(ex)}
+        alt = {}
+        for name in ("radix8_splat_first", "bucket", "splat_first"):
+            if name != args.sort:
+                try:
+                    alt[name] = alt_phase(name)
+                except Exception as ex:  # noqa: BLE001 -- past the guard: report, the headline is already measured
+                    log(f"[bench] alt sorter phase '{name}' failed on rank {rank}: {ex!r}")
+                    alt[name] = {"error": repr(ex)}
+        phases["alt_sorters"] = alt
+        phases["alt_sorters_note"] = ("the same sharded frame with the opt-in sorters (identical keys, ranges, pixels), timed as the headline "
+                                      "(one frame slot, gather included, slowest rank); the contract's 4-bit passes stay the headline")
+        dog_p.cancel()
+        if rank == 0:
+            out.update(phases)
+
+    # ---- the same gather through the C-ABI (gs_dist_init / gs_gather_strips: RCCL bound by the library itself, grouped
+    #      ncclSend / ncclRecv on the context's stream) -- what a C++ host uses (tools/gsplat_bench.cpp --ranks N).  Last,
+    #      and under a watchdog: no N-GPU box is reachable while this is written, and a communicator of our own that hangs
+    #      must cost the run this block, not its line.
     # (under --rehearse all ranks share one GPU, which RCCL refuses: the phase then needs GS_RCCL_LIBRARY = tools/mock_rccl)
     if (world > 1 and not args.no_extras and (not args.rehearse or os.environ.get("GS_RCCL_LIBRARY"))) or args.c_abi_gather:
         import ctypes as C

@@ -95,3 +95,7 @@ def test_rehearsal_lines_carry_the_guarded_phases():
     for name, ranks in (("2ranks_interleaved", 2), ("3ranks_interleaved", 3), ("4ranks", 4)):
         d = json.loads(open(P + f"bench_rehearse_{name}.json").read())
         assert d["n_gpus"] == ranks and d["c_abi_gather"]["assembled_frame_matches"] is True and d["sharded_image_matches_single_gpu"] is True
+    # rank 1 never reached the guarded phases: the watchdog still let rank 0 print the line, complete up to them
+    d = json.loads(open(P + "bench_rehearse_2ranks_phase_watchdog.json").read())
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["sharded_image_matches_single_gpu"] is True
+    assert "timed out" in d["guarded_phases_error"] and "alt_sorters" not in d
