@@ -760,9 +760,10 @@ def main():
             extra("hard_cloud", x_hard_cloud)
     # V of SURVEY 8(d) (splats that pass both culls): every one of them has a covariance with the +0.3 dilation in it
     survivors = None
-    if world == 1 and n <= 12_000_000:
+    # (a rank of a sharded frame: those whose records THIS rank stored -- passed both culls and may reach its rows)
+    if (world == 1 or rank == 0) and n <= 12_000_000:
         try:
-            owner.drawDevice(scene, strip_ptr, sync=True)
+            owner.drawDevice(scene, strip_ptr, sync=True, compact_rows=interleaved)
             survivors = int(np.count_nonzero(owner.debugRead(gs.BUF_COV)[:, 0]))
         except Exception as ex:  # noqa: BLE001 -- informational
             log(f"[bench] survivor count failed: {ex!r}")
@@ -1026,6 +1027,7 @@ def main():
             stages[name] = st
         roofline["stages"] = stages
         roofline["stages_note"] = ("per stage: SURVEY 8(d)'s algorithmic bytes (N = gaussians, V = splats passing both culls"
+                                   + (" and able to reach this rank's rows" if world > 1 else "")
                                    + (f" = {survivors} counted this run" if survivors is not None else " ~ 0.75 N assumed")
                                    + f", E = {e_rank} sort elements, T = tiles, P = passes) and the HBM bytes rocprofv3 --pmc FETCH_SIZE x2 + "
                                    "WRITE_SIZE counted for the stage's kernels per frame, each over the stage's bucket of buckets_ms (hipEvents "
