@@ -68,6 +68,10 @@ def parse_args(argv=None):
     ap.add_argument("--rows", default="contiguous", choices=["contiguous", "interleaved"],
                     help="N > 1: how tile rows are dealt to ranks (interleaved = row r to rank r mod N, for scenes "
                          "whose splat density varies over the height of the frame)")
+    ap.add_argument("--pose", default=None, choices=["garden", "train", "bicycle"],
+                    help="render the workload from the reference's 'Camera for benchmarks' of that scene (Scenes/GardenScene.cpp:11-12, "
+                         "...): the cloud is moved rigidly in front of that camera and stored in Morton order of the moved positions "
+                         "(synth.generate_config(pose=...)); default: the generator's own camera at the origin")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the alternative sorter / frames-in-flight extras")
     ap.add_argument("--no-pmc", action="store_true",
@@ -89,31 +93,183 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+# ---- the line must survive whatever runs after the headline --------------------------------------------------------------
+# Rank 0 never hands its JSON line to stdout itself.  It SAVES the line -- first right after the timed region and the
+# instrumented passes, then again after every later block -- into a side file (atomically: write + os.replace), and a process
+# that never touches a GPU prints the last saved state exactly once, when rank 0 is done OR gone:
+#   * `python bench.py [--gpus N]` outside a torch.distributed launch: this script's own first process (supervise) starts the
+#     real run as a child (N = 1: this script again; N > 1: python -m torch.distributed.run), waits, prints;
+#   * inside somebody else's launch (the driver's `python -m torch.distributed.run ... bench.py --gpus N`): rank 0 starts a
+#     keeper (this script with --line-keeper, a session of its own so that the launcher's killpg does not reach it) before it
+#     initialises the GPU; the keeper waits for end-of-file on a pipe only rank 0 holds -- rank 0 finishing, aborting, being
+#     SIGTERMed by the launcher because ANOTHER rank died: all the same to the pipe -- and prints;
+#   * under rocprofv3 (the tools/ scripts) the process prints its line itself at the end, as before: a profiled process has
+#     the GPU initialised before main() runs, and nothing is started from it.
+# A line that is printed although the run did not finish carries "ranks_exit" (the exit code, or what is known about it) and
+# "line_saved_after" (the last block that had completed).
+LINE_ENV = "GS_BENCH_LINE_FILE"
+EXIT_INCOMPLETE = 5           # the line was printed, a block behind the headline was not measured (watchdog, crash)
+
+
+def read_saved_line(path):
+    try:
+        with open(path) as f:
+            box = json.load(f)
+        return box if isinstance(box, dict) and isinstance(box.get("line"), dict) else None
+    except (OSError, ValueError):
+        return None
+
+
+def print_saved_line(path, rc, fd=1):
+    """Print the last state rank 0 saved to `path` (once); rc = exit code of the run as far as the caller knows it
+    (None: not known).  Returns (printed, complete)."""
+    box = read_saved_line(path)
+    if box is None:
+        return False, False
+    line, complete = box["line"], bool(box.get("complete"))
+    if not complete or rc not in (0, None):
+        line["ranks_exit"] = rc if rc is not None else "rank 0 ended before its run was complete (exit code not visible to the keeper)"
+        line["line_saved_after"] = box.get("stage")
+        if not complete:
+            line["line_note"] = ("the run ended before every block was measured; this is the line rank 0 had saved after the block "
+                                 "named in line_saved_after: everything in it was measured, what is missing was not")
+    os.write(fd, (json.dumps(line) + "\n").encode())
+    return True, complete
+
+
+def line_keeper(path):
+    """--line-keeper PATH: wait until the pipe on stdin reports end-of-file (rank 0 has finished or died), print."""
+    import signal
+    signal.signal(signal.SIGTERM, signal.SIG_IGN)
+    signal.signal(signal.SIGINT, signal.SIG_IGN)
+    try:
+        while os.read(0, 4096):
+            pass
+    except OSError:
+        pass
+    printed, complete = print_saved_line(path, None)
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
+    return 0 if printed and complete else EXIT_INCOMPLETE
+
+
+class LineOut:
+    """Rank 0's side of the protocol above."""
+
+    def __init__(self, rank, profiled):
+        self.rank, self.path, self.keeper, self.fd, self.direct = rank, os.environ.get(LINE_ENV), None, None, False
+        if rank != 0:
+            sys.stdout.flush()
+            os.dup2(2, 1)                                 # only rank 0 has anything to say on stdout
+            return
+        # stdout carries exactly ONE JSON line: anything a library prints there meanwhile (gloo/RCCL banners) is sent to
+        # stderr by pointing fd 1 at fd 2; the real stdout is kept for the line
+        sys.stdout.flush()
+        self.fd = os.dup(1)
+        os.dup2(2, 1)
+        if self.path is None and profiled:
+            self.direct = True
+        elif self.path is None:
+            import tempfile
+            fd_, self.path = tempfile.mkstemp(prefix="gs_bench_line_", suffix=".json", dir="/tmp")
+            os.close(fd_)
+            os.unlink(self.path)                          # nothing saved yet = no file
+            self.keeper = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--line-keeper", self.path],
+                                           stdin=subprocess.PIPE, stdout=self.fd, start_new_session=True)
+        self.last = None
+
+    def save(self, line, stage, complete=False):
+        if self.rank != 0:
+            return
+        self.last = line
+        if self.path is not None:
+            tmp = self.path + ".tmp"
+            with open(tmp, "w") as f:
+                json.dump({"complete": complete, "stage": stage, "line": line}, f)
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(tmp, self.path)
+
+    def finish(self, line, stage="end"):
+        """The run is complete (or a watchdog gives the rest up: then `line` says so): make the line visible."""
+        if self.rank != 0:
+            return
+        self.save(line, stage, complete=True)
+        if self.direct:
+            os.write(self.fd, (json.dumps(line) + "\n").encode())
+        elif self.keeper is not None:
+            self.keeper.stdin.close()                     # end-of-file: the keeper prints the state just saved
+            try:
+                self.keeper.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
+            self.keeper = None
+        # else: the supervising parent prints when this process has ended
+
+
+def supervise(cmd, limit_s, what):
+    """The first process of `python bench.py ...`: never imports torch, never touches HIP.  Starts the real run as a child (a
+    process group of its own) with a side file for the line, waits at most limit_s, prints what rank 0 saved."""
+    import signal
+    import tempfile
+    fd_, path = tempfile.mkstemp(prefix="gs_bench_line_", suffix=".json", dir="/tmp")
+    os.close(fd_)
+    os.unlink(path)
+    env = dict(os.environ)
+    env[LINE_ENV] = path
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log(f"[bench] starting {what}: {' '.join(cmd)}")
+    out_fd = os.dup(1)
+    proc = subprocess.Popen(cmd, env=env, stdout=2, start_new_session=True)      # the child's stdout is noise: to stderr
+    try:
+        rc = proc.wait(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        log(f"[bench] ERROR: {what} did not finish within {limit_s} s (a rank hung?): ending process group {proc.pid}")
+        # SIGTERM first: a torch.distributed.run launcher forwards it to its workers (each in a session of its own);
+        # SIGKILL after a grace period for whatever is left of the launcher's group
+        for sig, grace in ((signal.SIGTERM, 20), (signal.SIGKILL, 5)):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        proc.wait()
+        rc = 4
+    printed, complete = print_saved_line(path, rc, out_fd)
+    for f in (path, path + ".tmp"):
+        try:
+            os.unlink(f)
+        except OSError:
+            pass
+    if not printed:
+        log(f"[bench] ERROR: {what} ended with exit code {rc} before a line was saved")
+        return rc if rc != 0 else EXIT_INCOMPLETE
+    if rc == 0 and not complete:
+        return EXIT_INCOMPLETE
+    return rc
+
+
 def launch_ranks(args):
     """--gpus N outside a torch.distributed launch: start the N ranks ourselves.  This parent never imports torch or
     touches HIP; the ranks are fresh child processes (never an exec of a process that has initialised the GPU).  The
-    launch gets a wall-clock limit: a rank that hangs in a collective must not take the whole run with it -- the ranks
-    run in a process group of their own, which is what gets killed."""
-    import signal
+    launch gets a wall-clock limit: a rank that hangs in a collective must not take the whole run with it.  The parent
+    prints the line rank 0 saved -- also when a rank died on the way (supervise)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    log(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}")
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
-    try:
-        return proc.wait(timeout=args.rank_timeout)
-    except subprocess.TimeoutExpired:
-        log(f"[bench] ERROR: the ranks did not finish within {args.rank_timeout} s (a rank hung?): killing process group {proc.pid}")
-        try:
-            os.killpg(proc.pid, signal.SIGKILL)
-        except ProcessLookupError:
-            pass
-        proc.wait()
-        return 4
+    return supervise(cmd, args.rank_timeout, f"{args.gpus} ranks")
+
+
+def under_profiler():
+    return "rocprof" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))
 
 
 def _kname(raw):
@@ -142,8 +298,9 @@ def pmc_traffic(args):
     tmp = tempfile.mkdtemp(prefix="gs_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", "3", "--warmup", "1",
              "--no-extras", "--no-cpu-baseline", "--no-pmc", "--mode", args.mode, "--sort", args.sort,
-             "--render-kernel", args.render_kernel]
+             "--render-kernel", args.render_kernel] + (["--pose", args.pose] if args.pose else [])
     env = dict(os.environ, TMPDIR="/tmp")
+    env.pop(LINE_ENV, None)                               # the children's lines are not this run's line
     per = {}
     try:
         for counters in PMC_PASSES:
@@ -218,7 +375,7 @@ def all_ranks_ok(tdist, ok, device="cpu"):
     return bool(int(f.item()))
 
 
-def dry_run(args, world, rank):
+def dry_run(args, world, rank, line):
     """The N-rank plumbing without a GPU: process group (gloo), ShardedFrame strips, gather, assembly -- every rank
     fills its strip with a value that names (step, rank) and rank 0 checks each assembled frame."""
     import torch
@@ -246,9 +403,19 @@ def dry_run(args, world, rank):
                 for row in rows:
                     ok = ok and bool((img[row * 16:min(row * 16 + 16, h)] == (7 * f + r) % 251).all())
     elapsed = time.perf_counter() - t0
+    skeleton = {"dry_run": True, "n_gpus": world, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
+                "rows": args.rows, "assembled_frames_ok": ok, "guarded_phase": None,
+                "gloo_ranks": tdist.get_world_size() if world > 1 else 1}
+    # the line protocol of the real run (LineOut): the headline is saved before anything that may hang or die ...
+    line.save(skeleton, "headline")
+    if world > 1:
+        tdist.barrier()              # no rank goes on before rank 0 has saved the headline
+    # ... e.g. this (test knob, as in the real run): the rank dies inside the first block behind the headline
+    if os.environ.get("GS_BENCH_ABORT_IN_PHASES") == str(rank):
+        log(f"[bench] rank {rank}: GS_BENCH_ABORT_IN_PHASES: aborting")
+        os.abort()
     # the guard protocol of the optional phases (alt_sorters, c_abi_gather): GS_BENCH_DRY_FAIL_RANK=r makes rank r's set-up
     # "fail"; every rank must then skip the phase -- and none may be left waiting in its gather
-    guarded = None
     if world > 1:
         mine_ok = os.environ.get("GS_BENCH_DRY_FAIL_RANK") != str(rank)
         if all_ranks_ok(tdist, mine_ok):
@@ -257,17 +424,15 @@ def dry_run(args, world, rank):
             guarded = {"ran": True, "ok": bool(rank != 0 or all(int(strips[r][0, 0, 0]) == 200 + r for r in range(world)))}
         else:
             guarded = {"skipped": "set-up failed on this rank" if not mine_ok else "set-up failed on another rank"}
+        skeleton["guarded_phase"] = guarded
         tdist.barrier()
-    if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
-                          "rows": args.rows, "assembled_frames_ok": ok, "guarded_phase": guarded,
-                          "gloo_ranks": tdist.get_world_size() if world > 1 else 1}), flush=True)
+    line.finish(skeleton)
     if world > 1:
         tdist.destroy_process_group()
     return 0 if ok else 1
 
 
-def cpu_baseline(aos, cfg, oracle):
+def cpu_baseline(aos, cfg, oracle, camera=((0.0, 0.0, 0.0), 0.0, 0.0)):
     """The oracle (a scalar C port of the same four stages, oracle/gs_oracle.c -O2) timed on this box's host cores on
     the WHOLE workload: one frame on one thread (`value`), and the threaded port (gso_frame_mt) on the CPUs this
     process may use.  Bounded: clouds beyond 8 M gaussians are sampled (every k-th gaussian, same camera/resolution)."""
@@ -277,8 +442,8 @@ def cpu_baseline(aos, cfg, oracle):
     sub = aos if stride == 1 else np.ascontiguousarray(aos[::stride])
     what = "the whole workload cloud" if stride == 1 else f"every {stride}th gaussian of the workload cloud"
     w, h = cfg["width"], cfg["height"]
-    view, proj = oracle.camera_matrices(np.zeros(3, np.float32), 0.0, 0.0, w / h)
-    p = oracle.make_params(w, h, view, proj, (0, 0, 0))
+    view, proj = oracle.camera_matrices(np.asarray(camera[0], np.float32), camera[1], camera[2], w / h)
+    p = oracle.make_params(w, h, view, proj, camera[0])
     _, e, t = oracle.frame(p, sub)
     ms = float(t[4])
     out = {"value": round(sub.shape[0] / ms / 1000.0, 4), "unit": "Msplats/s", "cores": 1, "kind": "port",
@@ -299,11 +464,17 @@ def cpu_baseline(aos, cfg, oracle):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--line-keeper":
+        sys.exit(line_keeper(sys.argv[2]))
     args = parse_args()
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args))
+    profiled = under_profiler()
+    if "WORLD_SIZE" not in os.environ and LINE_ENV not in os.environ and not profiled:
+        # the first process of `python bench.py ...`: it only supervises (never touches the GPU) and prints the line
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args))
+        sys.exit(supervise([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], max(args.rank_timeout, 3000), "the one-GPU run"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -313,23 +484,18 @@ def main():
         sys.exit(2)
     if args.config is None:
         args.config = "C"          # the headline shape at every N: a scaling series over --gpus 1, 2, 4, 8 times ONE workload
+    line = LineOut(rank, profiled)                   # before anything touches the GPU: rank 0 may start its keeper here
     if args.dry_run:
-        sys.exit(dry_run(args, world, rank))
+        sys.exit(dry_run(args, world, rank, line))
 
     # roofline.traffic: measured by child runs under rocprofv3 --pmc before this process initialises the GPU
     pmc = "not measured (--no-pmc)" if args.no_pmc else "not measured (one-GPU runs of the radix sorters only)"
-    if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+    if profiled:
         pmc = "not measured (this process already runs under rocprofv3)"
     elif world == 1 and not args.no_pmc and not args.rehearse and args.sort != "bucket":
         pmc = pmc_traffic(args)
         if isinstance(pmc, str):
             log(f"[bench] roofline.traffic unavailable: {pmc}")
-
-    # stdout carries exactly ONE JSON line: anything a library prints there meanwhile (gloo/RCCL banners)
-    # is sent to stderr by pointing fd 1 at fd 2 until the result is ready
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -368,16 +534,17 @@ def main():
     cfg = dict(synth.CONFIGS[args.config])
     w, h, n = cfg["width"], cfg["height"], cfg["n"]
     t0 = time.time()
-    aos = synth.generate_config(args.config)[0]
+    aos, cfg_gen = synth.generate_config(args.config, pose=args.pose)
+    camera = cfg_gen["camera"]
     if rank == 0:
-        log(f"[bench] config {args.config}: {n} gaussians @ {w}x{h} generated in {time.time() - t0:.1f}s")
+        log(f"[bench] config {args.config}{' pose ' + args.pose if args.pose else ''}: {n} gaussians @ {w}x{h} generated in {time.time() - t0:.1f}s")
 
     rm = gs.ResourceManager()
     rm.setGaussians(aos)
     scene = gs.Scene(rm, aspect_ratio=w / h)
     cam = scene.getCamera()
-    cam.setPosition((0.0, 0.0, 0.0))
-    cam.setRotation(0.0, 0.0)
+    cam.setPosition(camera[0])
+    cam.setRotation(camera[1], camera[2])
     cam.recalculate()
     mode = gs.GS_RENDER_EXACT if args.mode == "exact" else gs.GS_RENDER_FAST
     sort_ids = {"radix4": gs.GS_SORT_RADIX4, "bucket": gs.GS_SORT_TILE_BUCKET, "splat_first": gs.GS_SORT_RADIX4_SPLAT_FIRST,
@@ -549,16 +716,20 @@ def main():
     passes_full, passes_tile = int(t.scatter_launches), int(t.scatter_tile_launches)
     moved_full, moved_tile = float(t.scatter_bytes_per_elem), float(t.scatter_tile_bytes_per_elem)
 
-    # ---- extras: three frames in flight; the other sort back-end (identical output) ----
-    extras = {}
-
+    # ---- extras: three frames in flight; the other sort back-ends (identical output); ... -- defined here, RUN after the
+    #      headline line has been assembled and saved (see LineOut), each followed by another save
     def extra(name, fn):
-        # an extra must never cost the line its headline: a failure is reported in its place
+        # an extra must never cost the line its headline: an exception is reported in its place (and a crash of the
+        # process inside it leaves the line that was saved before it)
+        if os.environ.get("GS_BENCH_ABORT_IN_PHASES") == str(rank):     # test knob: this rank dies in the first block behind the headline
+            log(f"[bench] rank {rank}: GS_BENCH_ABORT_IN_PHASES: aborting inside extra '{name}'")
+            os.abort()
         try:
-            extras[name] = fn()
+            out[name] = fn()
         except Exception as ex:  # noqa: BLE001
             log(f"[bench] extra '{name}' failed: {ex!r}")
-            extras[name] = {"error": repr(ex)}
+            out[name] = {"error": repr(ex)}
+        line.save(out, name)
 
     def x_three_slots():
         r3 = Ring(3, owner=owner)
@@ -615,18 +786,18 @@ def main():
                         "(<= 1 step per 8-bit channel against the oracle, tests), keys and ranges unchanged; the default and "
                         "the headline stay bit-exact"}
 
-    def x_hard_cloud():
-        # the headline cloud fills the frustum like fog (every tile list about the mean length); this one has the
-        # Garden-30k shape too (same N, E within 0.1 % of README.md:61) but behaves like a capture: clusters, a ground
-        # plane, needles and discs, near-opaque splats -- tile lists from tens to tens of thousands of entries
+    def time_other_scene(cfg_name, pose):
+        """Another cloud of the headline's shape through the headline's protocol (one frame slot, frames back to back on one
+        stream, image left in HBM), + the five buckets and the depth-word Scatter's mean launch (record_timings 1 / 2)."""
         t_g = time.time()
-        aos_h = synth.generate_config("Chard")[0]
-        log(f"[bench] config Chard generated in {time.time() - t_g:.1f}s")
+        aos_h, cfg_h = synth.generate_config(cfg_name, pose=pose)
+        log(f"[bench] config {cfg_name}{' pose ' + pose if pose else ''} generated in {time.time() - t_g:.1f}s")
+        cam_h = cfg_h["camera"]
         rm_h = gs.ResourceManager()
         rm_h.setGaussians(aos_h)
         scene_h = gs.Scene(rm_h, aspect_ratio=w / h)
-        scene_h.getCamera().setPosition((0.0, 0.0, 0.0))
-        scene_h.getCamera().setRotation(0.0, 0.0)
+        scene_h.getCamera().setPosition(cam_h[0])
+        scene_h.getCamera().setRotation(cam_h[1], cam_h[2])
         scene_h.getCamera().recalculate()
         img = torch.empty((h, w, 4), dtype=torch.uint8, device=device)
         cur = torch.cuda.current_stream().cuda_stream
@@ -641,7 +812,7 @@ def main():
             return r
         r0 = mk(0)
         k_h = min(args.steps, 200)
-        for _ in range(5):
+        for _ in range(max(5, min(args.warmup, 20))):
             r0.drawDevice(scene_h, img.data_ptr(), sync=False)
         torch.cuda.synchronize()
         t_b = time.perf_counter()
@@ -658,17 +829,52 @@ def main():
                 t_ = r1.timings()
                 bk += [t_.init_sort_list_ms, t_.radix_sort_ms, t_.find_ranges_ms, t_.render_ms, t_.total_ms]
         e_h = int(r1.timings().num_sort_elements)
-        for r_ in (r1, r0):
+        r2 = mk(2, share=r0)
+        sc_ms = 0.0
+        for i in range(3 + k_b):
+            r2.drawDevice(scene_h, img.data_ptr(), sync=True)
+            if i >= 3:
+                sc_ms += r2.timings().scatter_ms_avg
+        sc_ms /= k_b
+        per_elem = float(r2.timings().scatter_bytes_per_elem)
+        for r_ in (r2, r1, r0):
             r_.setStream(None)
             r_.cleanup()
         ref_c = REF_MS["C"]
-        return {"workload": WORKLOADS["Chard"], "sort_elements": e_h, "ms_per_step": round(ms_h, 4),
+        gbps = per_elem * e_h / (sc_ms * 1e-3) / 1e9 if sc_ms > 0 else 0.0
+        return {"workload": WORKLOADS[cfg_name], "sort_elements": e_h, "ms_per_step": round(ms_h, 4),
                 "value": round(n / ms_h / 1000.0, 2), "unit": "Msplats/s",
                 "vs_baseline": round(ref_c[1] / ms_h, 3),
+                "vs_headline_ms_per_step": round(ms_h / ms_per_step, 4),
                 "buckets_ms": {k_: round(float(v_), 4) for k_, v_ in zip(
                     ["init_sort_list", "radix_sort", "find_ranges", "render", "total"], bk / k_b)},
-                "note": "same protocol as the headline (one frame slot, image left in HBM); vs_baseline against the same "
-                        "README frame (28.499 ms), which was a real capture"}
+                "depth_scatter": {"avg_launch_ms": round(sc_ms, 5), "moved_bytes_per_launch": per_elem * e_h, "basis": "moved",
+                                  "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)}}
+
+    def x_hard_cloud():
+        # the headline cloud fills the frustum like fog (every tile list about the mean length); this one has the
+        # Garden-30k shape too (same N, E within 0.1 % of README.md:61) but behaves like a capture: clusters, a ground
+        # plane, needles and discs, near-opaque splats -- tile lists from tens to tens of thousands of entries
+        res = time_other_scene("Chard", None)
+        res["note"] = ("same protocol as the headline (one frame slot, image left in HBM); vs_baseline against the same "
+                       "README frame (28.499 ms), which was a real capture")
+        return res
+
+    def x_benchmark_pose():
+        # every other number of this line is taken with the generator's own camera (origin, looking down +z), for which the
+        # Morton storage order of the cloud is a SCREEN-SPACE order.  Here: the same cloud moved rigidly in front of the
+        # reference's Garden benchmark camera (Scenes/GardenScene.cpp:11-12) and stored in Morton order of the moved
+        # positions (ResourceManager.cpp:284-297) -- the same frame (E within 0.1 %), a view matrix that is no axis flip, a
+        # storage order a loader would produce
+        res = time_other_scene(args.config, "garden")
+        res["workload"] += ", viewed from the reference's garden benchmark camera (cloud moved rigidly, stored in Morton order of the moved positions)"
+        pos_, yaw_, pitch_ = gs.PlyScene.POSES["garden"]
+        res["camera"] = {"position": list(pos_), "yaw": yaw_, "pitch": pitch_, "source": "Scenes/GardenScene.cpp:11-12"}
+        res["sort_elements_vs_headline"] = round(res["sort_elements"] / max(e_rank, 1), 5)
+        res["note"] = ("same protocol as the headline; what changes is the order in which the splats are stored relative to the "
+                       "screen: InitSortList's emit order no longer follows the tile ids, a Scatter group's digit runs are shorter, "
+                       "RenderGaussians' gathers through the sorted ids are less local (DESIGN.md section 5)")
+        return res
 
     # N > 1: the sorters that cut a band's latency floor, as sequential phases every rank enters
     # together.  Each phase is guarded: a rank whose set-up fails says so in an all_reduce(MIN) and the phase is skipped
@@ -743,21 +949,6 @@ def main():
         out["radix8_splat_first"] = fast
         return out
 
-    # extras run collectives of their own (Ring.timed): with several ranks one rank failing inside an extra would leave
-    # the others waiting in it, so they are a one-GPU feature
-    if not args.no_extras and world == 1:
-        if F != 3:
-            extra("frames_in_flight_3", x_three_slots)
-        extra("alt_sorter", x_alt_sorter)
-        if args.sort != "splat_first":
-            extra("splat_first_sorter", x_splat_first)
-        if args.sort == "radix4":
-            extra("radix8_sorter", x_radix8("radix8"))
-            extra("radix8_splat_first_sorter", x_radix8("radix8_splat_first"))
-        if args.mode == "exact":
-            extra("fast_render_mode", x_fast_render)
-        if args.config == "C":
-            extra("hard_cloud", x_hard_cloud)
     # V of SURVEY 8(d) (splats that pass both culls): every one of them has a covariance with the +0.3 dilation in it
     survivors = None
     # (a rank of a sharded frame: those whose records THIS rank stored -- passed both culls and may reach its rows)
@@ -824,11 +1015,6 @@ def main():
         return {"workload": WORKLOADS["D"], "ms_per_step": round(ms_d, 4), "value": round(n / ms_d / 1000.0, 2), "unit": "Msplats/s",
                 "note": "the 4K frame of the N > 1 lines' `sharded_4k`, on this one GPU: the base of a strong-scaling series over "
                         "that frame (those lines repeat it as sharded_4k.one_gpu_same_frame_ms, measured on their rank 0)"}
-
-    if not args.no_extras and world == 1 and args.config == "C" and args.sort in ("radix4", "radix8"):
-        extra("hbm_resident", x_hbm_resident)
-    if not args.no_extras and world == 1 and args.config == "C":
-        extra("sharded_workload_on_one_gpu", x_sharded_workload_on_one_gpu)
 
     # per-rank numbers to rank 0
     stats = torch.tensor([e_rank, scat, *buckets, local_rank if not args.rehearse else 0],
@@ -1040,7 +1226,9 @@ def main():
             "vs_baseline": round(value / (ref[0] / ref[1] / 1000.0), 3) if ref else None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": WORKLOADS[args.config],
+                "workload": WORKLOADS[args.config] + (f", viewed from the reference's {args.pose} benchmark camera (cloud moved rigidly, "
+                                                      "stored in Morton order of the moved positions)" if args.pose else ""),
+                "camera": {"position": [float(x) for x in camera[0]], "yaw": camera[1], "pitch": camera[2]},
                 "num_gaussians": n, "width": w, "height": h, "sort_elements": e_total,
                 "capacity": int(info.capacity), "radix_passes": passes_full + passes_tile, "render_mode": args.mode,
                 "render_kernel": args.render_kernel,
@@ -1062,7 +1250,6 @@ def main():
             "frame_slots_identical": slots_ok,
             "roofline": roofline,
         }
-        out.update(extras)
         if world > 1:
             out["world_size"] = tdist.get_world_size()
             out["backend"] = tdist.get_backend()     # "nccl" = RCCL over xGMI; "gloo" only under --rehearse
@@ -1077,21 +1264,42 @@ def main():
             out["one_gpu_same_frame_ms"] = round(one_gpu_ms, 4) if one_gpu_ms else None
             out["one_gpu_same_frame_value"] = round(n / one_gpu_ms / 1000.0, 2) if one_gpu_ms else None   # Msplats/s: the series' base
             out["speedup_vs_one_gpu_same_frame"] = round(one_gpu_ms / ms_per_step, 3) if one_gpu_ms else None
-        if world == 1 and not args.no_cpu_baseline:
-            import oracle
-            out["cpu_baseline"] = cpu_baseline(aos, cfg, oracle)
         if world > 1 and sharded_ok is False:
             out["error"] = "the frame assembled from the ranks' strips differs from the frame one GPU renders alone"
+        # the headline is measured: from here on nothing can cost the run its line
+        line.save(out, "headline")
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle
+            out["cpu_baseline"] = cpu_baseline(aos, cfg, oracle, camera)
+            line.save(out, "cpu_baseline")
     else:
         out = None
+    if world > 1:
+        tdist.barrier()              # no rank goes on into the optional blocks before rank 0 has saved the headline
+
+    # ---- the one-GPU extras (they run timed regions of their own: with several ranks one rank failing inside one would leave
+    #      the others waiting in it, so they are a one-GPU feature)
+    if not args.no_extras and world == 1:
+        if F != 3:
+            extra("frames_in_flight_3", x_three_slots)
+        extra("alt_sorter", x_alt_sorter)
+        if args.sort != "splat_first":
+            extra("splat_first_sorter", x_splat_first)
+        if args.sort == "radix4":
+            extra("radix8_sorter", x_radix8("radix8"))
+            extra("radix8_splat_first_sorter", x_radix8("radix8_splat_first"))
+        if args.mode == "exact":
+            extra("fast_render_mode", x_fast_render)
+        if args.config == "C" and not args.pose:
+            extra("benchmark_pose", x_benchmark_pose)
+            extra("hard_cloud", x_hard_cloud)
+        if args.config == "C" and args.sort in ("radix4", "radix8"):
+            extra("hbm_resident", x_hbm_resident)
+        if args.config == "C":
+            extra("sharded_workload_on_one_gpu", x_sharded_workload_on_one_gpu)
 
     # ---- the guarded phases of a run with several ranks: after the line is assembled and under a watchdog, so that a
     #      collective that hangs inside one of them costs the run these blocks, not its line
-    def emit_line():
-        if rank == 0:
-            sys.stdout.flush()
-            os.write(json_fd, (json.dumps(out) + "\n").encode())
-
     if world > 1 and not args.no_extras:
         import threading
         limit_s = float(os.environ.get("GS_BENCH_PHASES_LIMIT_S", "300"))
@@ -1102,19 +1310,27 @@ def main():
             if rank == 0:
                 out.update(phases)
                 out["guarded_phases_error"] = f"timed out after {limit_s:.0f} s (the line above them is complete)"
-                emit_line()
-            os._exit(0 if sharded_ok is not False else 3)
+                line.finish(out, "guarded phases given up")
+            os._exit(EXIT_INCOMPLETE if sharded_ok is not False else 3)   # non-zero: a collective hung, whoever reads only the exit code must see it
         dog_p = threading.Timer(limit_s, give_up_phases)
         dog_p.daemon = True
         dog_p.start()
         if os.environ.get("GS_BENCH_HANG_IN_PHASES") == str(rank):      # test knob: this rank never reaches the phases
             time.sleep(3600.0)
+        if os.environ.get("GS_BENCH_ABORT_IN_PHASES") == str(rank):     # test knob: this rank dies in the first phase
+            log(f"[bench] rank {rank}: GS_BENCH_ABORT_IN_PHASES: aborting inside the guarded phases")
+            os.abort()
+
+        def phase_done(stage):
+            if rank == 0:
+                line.save({**out, **phases}, stage)
         if args.config == "C":
             try:
                 phases["sharded_4k"] = sharded_4k_phase()
             except Exception as ex:  # noqa: BLE001
                 log(f"[bench] 4K phase failed on rank {rank}: {ex!r}")
                 phases["sharded_4k"] = {"error": repr(ex)}
+            phase_done("sharded_4k")
         alt = {}
         for name in ("radix8_splat_first", "bucket", "splat_first"):
             if name != args.sort:
@@ -1123,12 +1339,15 @@ def main():
                 except Exception as ex:  # noqa: BLE001 -- past the guard: report, the headline is already measured
                     log(f"[bench] alt sorter phase '{name}' failed on rank {rank}: {ex!r}")
                     alt[name] = {"error": repr(ex)}
+                phases["alt_sorters"] = alt
+                phase_done("alt_sorters." + name)
         phases["alt_sorters"] = alt
         phases["alt_sorters_note"] = ("the same sharded frame with the opt-in sorters (identical keys, ranges, pixels), timed as the headline "
                                       "(one frame slot, gather included, slowest rank); the contract's 4-bit passes stay the headline")
         dog_p.cancel()
         if rank == 0:
             out.update(phases)
+            line.save(out, "guarded phases")
 
     # ---- the same gather through the C-ABI (gs_dist_init / gs_gather_strips: RCCL bound by the library itself, grouped
     #      ncclSend / ncclRecv on the context's stream) -- what a C++ host uses (tools/gsplat_bench.cpp --ranks N).  Last,
@@ -1145,8 +1364,8 @@ def main():
             log(f"[bench] rank {rank}: the C-ABI gather phase did not finish within 120 s: giving it up")
             if rank == 0:
                 out["c_abi_gather"] = {"error": "timed out after 120 s (the line above it is complete)"}
-                emit_line()
-            os._exit(0 if sharded_ok is not False else 3)
+                line.finish(out, "C-ABI gather given up")
+            os._exit(EXIT_INCOMPLETE if sharded_ok is not False else 3)
         dog = threading.Timer(120.0, give_up)
         dog.daemon = True
         dog.start()
@@ -1212,9 +1431,10 @@ def main():
         dog.cancel()
         if rank == 0:
             out["c_abi_gather"] = res
+            line.save(out, "c_abi_gather")
+    line.finish(out)                 # the line goes out BEFORE the teardown: a context or communicator that fails to die cannot cost it
     owner.setStream(None)
     owner.cleanup()
-    emit_line()
     if world > 1:
         tdist.barrier()
         tdist.destroy_process_group()

@@ -26,6 +26,31 @@ def tile_row_partition(tiles_y: int, world_size: int) -> List[Tuple[int, int]]:
     return out
 
 
+def balanced_row_partition(row_weights, world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous bands whose WEIGHTS (e.g. sort elements per tile row of the last frames) are as equal as whole rows
+    allow: band edge r sits at the row boundary whose weight prefix is nearest to r / world_size of the total.  Every
+    rank gets at least one row while there are rows to give (a rank with no row would still pay the frame's fixed
+    cost); with all-zero weights this is tile_row_partition's answer in spirit (equal row counts)."""
+    wts = np.asarray(row_weights, dtype=np.float64).reshape(-1)
+    tiles_y = int(wts.shape[0])
+    if tiles_y == 0:
+        return [(0, 0)] * world_size
+    if not np.isfinite(wts).all() or wts.sum() <= 0.0:
+        wts = np.ones(tiles_y)
+    prefix = np.concatenate([[0.0], np.cumsum(wts)])          # prefix[k] = weight of rows [0, k)
+    edges = [0]
+    for r in range(1, world_size):
+        target = prefix[-1] * r / world_size
+        k = int(np.searchsorted(prefix, target))               # first boundary with prefix >= target
+        if k > 0 and target - prefix[k - 1] <= prefix[min(k, tiles_y)] - target:
+            k -= 1
+        lo = min(edges[-1] + 1, tiles_y)                       # at least one row for the previous rank ...
+        hi = max(lo, tiles_y - (world_size - r))               # ... and one left for each rank still to come
+        edges.append(int(min(max(k, lo), hi)))
+    edges.append(tiles_y)
+    return [(edges[r], edges[r + 1]) for r in range(world_size)]
+
+
 def strip_rows(tiles_y: int, world_size: int, tile: int = 16) -> int:
     """Pixel rows of one (padded) strip."""
     return ((tiles_y + world_size - 1) // world_size) * tile

@@ -176,11 +176,80 @@ def generate(n: int, width: int, height: int, mu: float, seed: int, morton: bool
     return np.ascontiguousarray(out)
 
 
-def generate_config(name: str, n: int | None = None) -> tuple[np.ndarray, dict]:
+def _quat_of_rotation(m: np.ndarray) -> np.ndarray:
+    """Unit quaternion (w, x, y, z) of a proper 3x3 rotation matrix (row-major, float64)."""
+    t = m[0, 0] + m[1, 1] + m[2, 2]
+    if t > 0.0:
+        s = np.sqrt(t + 1.0) * 2.0
+        q = np.array([0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s])
+    else:
+        i = int(np.argmax([m[0, 0], m[1, 1], m[2, 2]]))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + m[i, i] - m[j, j] - m[k, k]) * 2.0
+        q = np.zeros(4)
+        q[0] = (m[k, j] - m[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (m[j, i] + m[i, j]) / s
+        q[1 + k] = (m[k, i] + m[i, k]) / s
+    return q / np.sqrt((q * q).sum())
+
+
+def rigid_move(aos: np.ndarray, rot: np.ndarray, shift: np.ndarray, morton: bool = True) -> np.ndarray:
+    """The cloud moved rigidly: world' = rot @ world + shift (rot a proper rotation, row-major 3x3).  Positions and the
+    splats' orientations move; the SH coefficients stay as they are (the colours of the moved scene differ -- a splat is
+    lit from another side -- its geometry, keys, tile lists and blend weights do not).  The record's quaternion q stands
+    for the matrix get_rot_mat builds from it (Common.glsl:17-30), which is the TRANSPOSE of the usual R(q); the
+    covariance is Sigma = R(q)^T S^2 R(q) (Common.glsl:41-46), so rot Sigma rot^T needs R(q') = R(q) rot^T, i.e.
+    q' = q (x) conj(m) with m the quaternion of rot.  Afterwards the records are put in Morton order of the MOVED
+    positions, as ResourceManager::loadGaussians would store such a scene (ResourceManager.cpp:284-297)."""
+    rot = np.asarray(rot, dtype=np.float64).reshape(3, 3)
+    assert abs(np.linalg.det(rot) - 1.0) < 1e-5 and np.allclose(rot @ rot.T, np.eye(3), atol=1e-5)
+    out = aos.copy()
+    out[:, 0:3] = (aos[:, 0:3].astype(np.float64) @ rot.T + np.asarray(shift, dtype=np.float64)).astype(np.float32)
+    mw, mx, my, mz = _quat_of_rotation(rot) * np.array([1.0, -1.0, -1.0, -1.0])      # conj(m)
+    q = aos[:, 8:12].astype(np.float64)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    qn = np.stack([w * mw - x * mx - y * my - z * mz,
+                   w * mx + x * mw + y * mz - z * my,
+                   w * my - x * mz + y * mw + z * mx,
+                   w * mz + x * my - y * mx + z * mw], axis=1)
+    qn /= np.sqrt((qn * qn).sum(axis=1, keepdims=True))
+    out[:, 8:12] = qn.astype(np.float32)
+    if morton:
+        out = out[np.argsort(morton_codes(out[:, 0:3]), kind="stable")]
+    return np.ascontiguousarray(out)
+
+
+def move_to_camera(aos: np.ndarray, view_from: np.ndarray, view_to: np.ndarray, morton: bool = True) -> np.ndarray:
+    """The cloud as the camera with view matrix `view_to` must see it to render the frame the camera with `view_from`
+    renders of `aos`: view_to @ world' = view_from @ world (both column-major float[16], as gs_camera_matrices returns)."""
+    v0 = np.asarray(view_from, dtype=np.float64).reshape(4, 4).T
+    v1 = np.asarray(view_to, dtype=np.float64).reshape(4, 4).T
+    t = np.linalg.inv(v1) @ v0
+    return rigid_move(aos, t[:3, :3], t[:3, 3], morton=morton)
+
+
+def generate_config(name: str, n: int | None = None, pose: str | None = None) -> tuple[np.ndarray, dict]:
+    """pose: None = the generator's own camera (origin, looking down +z: the world axes ARE the screen axes and the depth,
+    so the Morton storage order is a screen-space order); "garden" / "train" / "bicycle" = the same cloud moved rigidly in
+    front of the reference's 'Camera for benchmarks' of that scene (Scenes/GardenScene.cpp:11-12, ...) and re-ordered by the
+    Morton code of the moved positions: the same frame up to float rounding (E within 0.1 %), a view matrix that is not an
+    axis flip and a storage order that is no longer aligned with the screen.  cfg then carries the camera."""
     cfg = dict(CONFIGS[name])
     if n is not None:
         cfg["n"] = int(n)
     aos = generate(cfg["n"], cfg["width"], cfg["height"], cfg["mu"], cfg["seed"], kind=cfg.get("kind", "uniform"))
+    cfg["camera"] = ((0.0, 0.0, 0.0), 0.0, 0.0)
+    if pose is not None:
+        from .renderer import Camera, PlyScene
+        aspect = cfg["width"] / cfg["height"]
+        c0, c1 = Camera(aspect), Camera(aspect)
+        c0.setPosition((0.0, 0.0, 0.0)); c0.setRotation(0.0, 0.0); c0.recalculate()
+        pos, yaw, pitch = PlyScene.POSES[pose]
+        c1.setPosition(pos); c1.setRotation(yaw, pitch); c1.recalculate()
+        aos = move_to_camera(aos, c0.getViewMatrix(), c1.getViewMatrix())
+        cfg["camera"] = (pos, yaw, pitch)
+        cfg["pose"] = pose
     return aos, cfg
 
 
