@@ -247,12 +247,13 @@ def supervise(cmd, limit_s, what):
             os.unlink(f)
         except OSError:
             pass
+    code = rc if rc >= 0 else 128 - rc                   # a child killed by signal s: 128 + s, like a shell
     if not printed:
         log(f"[bench] ERROR: {what} ended with exit code {rc} before a line was saved")
-        return rc if rc != 0 else EXIT_INCOMPLETE
-    if rc == 0 and not complete:
+        return code if code != 0 else EXIT_INCOMPLETE
+    if code == 0 and not complete:
         return EXIT_INCOMPLETE
-    return rc
+    return code
 
 
 def launch_ranks(args):

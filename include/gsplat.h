@@ -26,8 +26,10 @@
 extern "C" {
 #endif
 
-#define GS_API_VERSION 3   /* 2: gs_config grew tile_order; 3: gs_config starts with struct_size, gs_api_version(),
-                              gs_runtime_versions(), gs_dist_* / gs_gather_strips */
+#define GS_API_VERSION 4   /* 2: gs_config grew tile_order; 3: gs_config starts with struct_size, gs_api_version(),
+                              gs_runtime_versions(), gs_dist_* / gs_gather_strips; 4: GS_ROWS_BALANCED + gs_dist_rebalance /
+                              gs_dist_bands, gs_render_sharded_async / gs_sharded_frame / gs_sharded_read (two sharded
+                              frames in flight, the assembled frame left in HBM), GS_BUF_COLOR for every non-culled splat */
 
 /* status codes */
 #define GS_OK 0
@@ -67,7 +69,8 @@ typedef struct gs_ctx gs_ctx;
 
 /* Replaces the compile-time constants of Renderer.h:145-147, RadixSort.h:36-39,
  * Camera.cpp:4-5 and Resources/Shaders/Common/Common.glsl:2-15. */
-/* RenderGaussians launch shapes (all bit-identical in GS_RENDER_EXACT).  AUTO picks by tile count. */
+/* RenderGaussians launch shapes (all bit-identical in GS_RENDER_EXACT).  AUTO = GS_RENDER_KERNEL_WORKGROUP_8X8 (a workgroup
+ * per tile, an 8 x 8 quadrant per wave) at every size. */
 #define GS_RENDER_KERNEL_AUTO 0u
 #define GS_RENDER_KERNEL_WAVE_1PX 1u   /* four independent waves per tile, 1 pixel per lane */
 #define GS_RENDER_KERNEL_WAVE_2PX 2u   /* two independent waves per tile, 2 pixels per lane */
@@ -160,7 +163,13 @@ typedef struct gs_scene_info {
 #define GS_BUF_SORTED_DEPTH 1  /* uint32[num_sort_elements]  low half of the key    */
 #define GS_BUF_SORTED_ID 2     /* uint32[num_sort_elements]  gaussian index payload */
 #define GS_BUF_RANGES 3        /* uint32[tiles][2]           {start,end} per tile (GaussianTileRangeData.xy) */
-#define GS_BUF_COLOR 4         /* float[N][4]                GaussianData.color      */
+#define GS_BUF_COLOR 4         /* float[N][4]                GaussianData.color: rgb + opacity of EVERY splat that passed both culls
+                                                             (InitSortList.comp:124-127), zero for the culled ones.  A frame evaluates
+                                                             the colour of the splats that emit an element (nothing else is ever read);
+                                                             the others are evaluated by this call, on demand, from the last frame's
+                                                             camera.  A context that owns a SUBSET of the tile rows (gs_set_tile_rows*)
+                                                             does not project splats that cannot reach its rows: there the buffer
+                                                             holds the emitting splats only */
 #define GS_BUF_COV 5           /* float[N][4]                GaussianData.covariance (w = 0) */
 #define GS_BUF_COUNT 6         /* uint64[1]                  un-truncated element counter */
 #define GS_BUF_UNSORTED_TILE 7 /* uint32[num_sort_elements]  list as emitted by InitSortList */
@@ -253,18 +262,60 @@ int gs_dist_init(gs_ctx* ctx, const void* unique_id, int rank, int world);
 int gs_gather_strips(gs_ctx* ctx, const void* strip_dev, void* gathered_dev, size_t bytes, int root);
 int gs_dist_destroy(gs_ctx* ctx);
 /* The same for a host that holds no device memory of its own -- Renderer::draw on R GPUs (Renderer.cpp:297-515):
- *   gs_dist_shard_rows : after gs_set_resolution + gs_dist_init (again after every gs_set_resolution); rank r of R takes its tile rows (contiguous band of
- *                        ceil(Ty / R) rows, or rows r, r + R, ... when interleaved != 0) and the library allocates the
- *                        strip (and, on rank 0, the gather buffer);
- *   gs_render_sharded  : every rank calls it with the same camera: the rank's rows are rendered into its strip, the
- *                        strips gathered on rank 0 and the whole frame copied to rgba_out there (HOST, height*width*4
- *                        bytes as in gs_render; ignored on the other ranks, may be NULL).  Synchronous.  The frame is
- *                        bit-identical to the one GPU frame of gs_render; gs_get_timings afterwards describes this rank's
- *                        own rows (with record_timings on).  A rank whose own frame fails still takes part
- *                        in the exchange before it returns its error, so the others are not left waiting. */
-int gs_dist_shard_rows(gs_ctx* ctx, uint32_t interleaved);
+ *   gs_dist_shard_rows : after gs_set_resolution + gs_dist_init (again after every gs_set_resolution, and after any
+ *                        gs_set_tile_rows* of the caller's own: the buffers of the sharded frame belong to the rows dealt
+ *                        HERE, and gs_render_sharded* refuse a context whose rows have been changed since).  Rank r of R
+ *                        takes its tile rows --
+ *                          GS_ROWS_CONTIGUOUS  a band of ceil(Ty / R) rows;
+ *                          GS_ROWS_INTERLEAVED rows r, r + R, ...: even load whatever the scene, at the price of
+ *                                              InitSortList's block cull (every rank's rows span the whole frame);
+ *                          GS_ROWS_BALANCED    contiguous bands whose EDGES follow the scene: equal row counts at first,
+ *                                              moved by gs_dist_rebalance towards equal cost --
+ *                        and the library allocates the buffers of two sharded frames in flight (every rank its rows; rank 0
+ *                        the assembled frames).
+ *   gs_render_sharded_async : every rank calls it with the same camera: the rank's rows are rendered on the context's
+ *                        stream; the exchange follows on a stream of the library's own behind an event, so it runs beside
+ *                        the NEXT frame's kernels; bands land in place in rank 0's frame (interleaved rows: re-ordered by R
+ *                        strided copies).  Returns after enqueueing; the assembled frame stays in rank 0's HBM.  A rank
+ *                        whose own frame fails still takes part in the exchange before it returns its error, so the others
+ *                        are not left waiting.
+ *   gs_sharded_frame   : waits (host) until the exchange of the last (which = 0) or the last-but-one (which = 1) sharded
+ *                        frame has finished; on rank 0 *frame_dev is the device pointer of that frame (height * width * 4
+ *                        bytes, valid until the second gs_render_sharded* call from now), NULL on the other ranks.
+ *   gs_sharded_read    : the same, and copies the frame to rgba_out (HOST) on rank 0.
+ *   gs_render_sharded  : gs_render_sharded_async + gs_sharded_read(0) + the timings of this rank's own rows
+ *                        (gs_get_timings, with record_timings on): the synchronous form.  rgba_out: HOST, height*width*4
+ *                        bytes as in gs_render; ignored on the other ranks, may be NULL.  The frame is bit-identical to the
+ *                        one-GPU frame of gs_render.
+ *   gs_dist_rebalance  : GS_ROWS_BALANCED, collective (every rank, same order as the frames, e.g. every 32 frames): each
+ *                        rank contributes the sort-element counts of its tile rows (the last frame's tile ranges) and the
+ *                        GPU time of its share; after one exchange of R (R - 1) messages of Ty + 1 words every rank holds
+ *                        the same vectors and derives the same new edges: weight(row) = elements(row) x (share time / share
+ *                        elements of the rank that rendered it), edges at equal weight prefixes, moved only for a predicted
+ *                        gain of 3 % on the slowest rank.  Waits for the frames in flight.  *moved_out (may be NULL) = 1
+ *                        when the edges moved (the next frame re-captures its hipGraph).
+ *   gs_dist_bands      : the R + 1 band edges (tile rows) of a contiguous or balanced dealing; count must be R + 1.
+ * Collective safety: these calls pair with the other ranks' calls.  A rank that fails a PRECONDITION (no shard, rows changed
+ * behind the library's back, a NULL rgba_out on rank 0, an allocation that failed in gs_dist_shard_rows) returns before the
+ * exchange and its peers wait in theirs: check the status of gs_dist_shard_rows on every rank (e.g. exchange a flag over the
+ * channel that carried the unique id) before the first frame.  A failure of the rank's own FRAME is collective-safe (above). */
+#define GS_ROWS_CONTIGUOUS 0u
+#define GS_ROWS_INTERLEAVED 1u
+#define GS_ROWS_BALANCED 2u
+int gs_dist_shard_rows(gs_ctx* ctx, uint32_t dealing);
+int gs_render_sharded_async(gs_ctx* ctx, const float view[16], const float proj[16], const float cam_pos[3], uint32_t sh_mode);
+int gs_sharded_frame(gs_ctx* ctx, uint32_t which, void** frame_dev);
+int gs_sharded_read(gs_ctx* ctx, uint32_t which, uint8_t* rgba_out);
 int gs_render_sharded(gs_ctx* ctx, const float view[16], const float proj[16], const float cam_pos[3],
                       uint32_t sh_mode, uint8_t* rgba_out);
+int gs_dist_rebalance(gs_ctx* ctx, uint32_t* moved_out);
+int gs_dist_bands(const gs_ctx* ctx, uint32_t* edges_out, uint32_t count);
+/* The partition rule by itself (pure host arithmetic, no context, no GPU): world + 1 edges of contiguous bands over
+ * tiles_y rows whose weights are as equal as whole rows allow -- edge r at the row boundary whose weight prefix is nearest
+ * to r / world of the total, every band at least one row while there are rows to give; all-zero or non-finite weights
+ * count as equal ones.  For hosts that run their own exchange (bench.py's torch path: dist.balanced_row_partition is the
+ * same rule in Python). */
+int gs_balance_rows(const double* row_weights, uint32_t tiles_y, uint32_t world, uint32_t* edges_out);
 
 /* Renderer::draw (Renderer.cpp:297-515): updateUniformBuffer(view, proj) (:531-538), the push
  * constants of Subrenderer.cpp:152-160 (camPos, shMode as an INTEGER 0/1/2), then the recorded

@@ -58,12 +58,16 @@ def assert_frame_equals_oracle(r, img, ref, exact_pixels=True):
     assert np.array_equal(r.debugRead(gs.BUF_SORTED_DEPTH), ref["depth"][:e])
     assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), ref["id"][:e])
     assert np.array_equal(r.debugRead(gs.BUF_RANGES), ref["ranges"])
-    # covariance: every non-culled splat; colour: every splat that emits at least one element (the
-    # product skips the SH evaluation of splats no tile will ever read)
+    # covariance and colour: every non-culled splat, as the reference stores them (InitSortList.comp:124-127, N6) -- the frame
+    # evaluates the colour of the emitting splats only and gs_debug_read fills in the others on demand.  A context that owns
+    # a subset of the tile rows does not project what cannot reach its rows: there only the emitting splats are compared.
     assert np.array_equal(r.debugRead(gs.BUF_COV).view(np.uint32), ref["stage1"]["cov"].view(np.uint32))
-    emits = np.zeros(ref["stage1"]["color"].shape[0], bool)
-    emits[ref["id"][:e]] = True
-    assert np.array_equal(r.debugRead(gs.BUF_COLOR)[emits].view(np.uint32), ref["stage1"]["color"][emits].view(np.uint32))
+    info = r.sceneInfo()
+    sel = slice(None)
+    if info.rows_owned != info.tiles_y:
+        sel = np.zeros(ref["stage1"]["color"].shape[0], bool)
+        sel[ref["id"][:e]] = True
+    assert np.array_equal(r.debugRead(gs.BUF_COLOR)[sel].view(np.uint32), ref["stage1"]["color"][sel].view(np.uint32))
     if exact_pixels:
         assert np.array_equal(img, ref["image"])
     else:
@@ -108,14 +112,17 @@ def test_golden_fixture(sh_mode):
         assert np.array_equal(r.debugRead(gs.BUF_UNSORTED_ID), g["unsorted_id"])
     emits = np.zeros(g["aos"].shape[0], bool)
     emits[g["id"]] = True
-    assert np.array_equal(r.debugRead(gs.BUF_COLOR)[emits].view(np.uint32), g[f"color_mode{sh_mode}"][emits].view(np.uint32))
+    kept = g["cov"][:, 0] != 0                       # passed both culls (the stored covariance carries the +0.3 dilation)
+    assert kept.sum() > emits.sum() and np.all(kept[emits])
+    # colour of EVERY non-culled splat (N6), zero elsewhere: the whole array
+    assert np.array_equal(r.debugRead(gs.BUF_COLOR).view(np.uint32), g[f"color_mode{sh_mode}"].view(np.uint32))
     assert np.array_equal(img, g[f"image_mode{sh_mode}"])
     # cross-check (not a pin): the same splats through the reference's own Common.glsl text compiled over its glm
     # (tests/golden/ref_common_glsl.npz, oracle/ref_glsl_xcheck.cpp) -- colour and covariance straight from the HIP
     # path, no oracle in between
     x = np.load(os.path.join(GOLDEN, "ref_common_glsl.npz"))
-    assert np.array_equal(r.debugRead(gs.BUF_COLOR)[emits, :3].view(np.uint32), x["color"][sh_mode][emits].view(np.uint32))
-    assert np.array_equal(r.debugRead(gs.BUF_COV)[emits, :3].view(np.uint32), x["cov"][emits].view(np.uint32))
+    assert np.array_equal(r.debugRead(gs.BUF_COLOR)[kept, :3].view(np.uint32), x["color"][sh_mode][kept].view(np.uint32))
+    assert np.array_equal(r.debugRead(gs.BUF_COV)[kept, :3].view(np.uint32), x["cov"][kept].view(np.uint32))
     r.cleanup()
 
 
@@ -160,8 +167,10 @@ def test_common_glsl_cross_check_extreme():
         emits = np.zeros(x["aos"].shape[0], bool)
         emits[r.debugRead(gs.BUF_SORTED_ID)] = True
         assert emits.sum() > 300
-        assert np.array_equal(r.debugRead(gs.BUF_COLOR)[emits, :3].view(np.uint32), x["color"][sh_mode][emits].view(np.uint32))
-        assert np.array_equal(r.debugRead(gs.BUF_COV)[emits, :3].view(np.uint32), x["cov"][emits].view(np.uint32))
+        kept = r.debugRead(gs.BUF_COV)[:, 0] != 0            # every splat that passed both culls, emitting or not (N6)
+        assert np.all(kept[emits]) and kept.sum() >= emits.sum()
+        assert np.array_equal(r.debugRead(gs.BUF_COLOR)[kept, :3].view(np.uint32), x["color"][sh_mode][kept].view(np.uint32))
+        assert np.array_equal(r.debugRead(gs.BUF_COV)[kept, :3].view(np.uint32), x["cov"][kept].view(np.uint32))
         if sh_mode == 0:
             # the emitted list against the reference's own getGaussianTileExtents / getDepthKey (InitSortList.comp:45-80
             # run over its glm): every splat's elements are its extents rectangle in row-major order, ascending splat
@@ -206,7 +215,8 @@ def test_shader_main_bodies_cross_check(which, sort):
         emits = np.zeros(g["aos"].shape[0], bool)
         emits[ids] = True
         col = x[f"color_mode{sh_mode}"] if which == "small" else x["color"]
-        assert np.array_equal(r.debugRead(gs.BUF_COLOR)[emits].view(np.uint32), col[emits].view(np.uint32))
+        # GaussianData.color as the reference's InitSortList main() leaves it: every non-culled splat (N6), the whole array
+        assert np.array_equal(r.debugRead(gs.BUF_COLOR).view(np.uint32), col.view(np.uint32))
         if sh_mode == 0:
             assert r.timings().emitted_elements == int(x["counter"]) and r.sceneInfo().capacity == int(x["capacity"])
             assert np.array_equal(r.debugRead(gs.BUF_SORTED_TILE), x["sorted"][:, 0])
@@ -602,7 +612,8 @@ def full_size_parity(oracle_mod, name, sorts, capacity, sort_bits, pixel_tile_ro
     cloud: (aos, cfg) instead of synth.CONFIGS[name]."""
     aos, cfg = cloud if cloud is not None else synth.generate_config(name)
     w, h = cfg["width"], cfg["height"]
-    sc = make_scene(aos, w, h)
+    cam_pos, cam_yaw, cam_pitch = cfg.get("camera", ((0.0, 0.0, 0.0), 0.0, 0.0))     # synth.generate_config(pose=...)
+    sc = make_scene(aos, w, h, pos=cam_pos, yaw=cam_yaw, pitch=cam_pitch)
     cam = sc.getCamera()
     threads = oracle_mod.host_threads()
     gw, gh = oracle_mod.grid(w, h)
@@ -693,6 +704,20 @@ def test_config_c_full_frame(oracle_mod):
     """BASELINE config C, the headline (Garden-30k shape: 5,834,784 gaussians @ 1920x1080, E = 13.1 M, README.md:61):
     keys, ranges and all 1920x1080 pixels bit-exact, both sort back-ends."""
     full_size_parity(oracle_mod, "C", ALL_SORTS, 2**24, 48, e_readme=13_098_506)
+
+
+def test_config_c_under_the_garden_benchmark_pose_full_frame(oracle_mod):
+    """The headline cloud as bench.py's `benchmark_pose` block times it: moved rigidly in front of the reference's Garden
+    benchmark camera (Scenes/GardenScene.cpp:11-12: position (-0.620010, 0.189628, 2.271181), yaw 2.971590, pitch -1.074159)
+    and stored in Morton order of the MOVED positions (ResourceManager.cpp:284-297) -- a view matrix that is no axis flip, a
+    storage order that is not a screen order.  Keys, payload order, ranges and all 1920x1080 pixels bit-exact against the
+    oracle, the contractual sorter and the one the sharded frames prefer, and one band of an 8-way shard; the frame is the
+    headline's frame (E within 0.1 % of config C's 13,121,624)."""
+    cloud = synth.generate_config("C", pose="garden")
+    assert cloud[1]["camera"][1] == pytest.approx(2.971590) and cloud[1]["pose"] == "garden"
+    e = full_size_parity(oracle_mod, "C under the garden pose", (gs.GS_SORT_RADIX4, gs.GS_SORT_RADIX8_SPLAT_FIRST), 2**24, 48,
+                         e_readme=13_098_506, cloud=cloud, shares=(("band", 3, 8),))
+    assert abs(e / 13_121_624 - 1.0) < 1e-3
 
 
 def test_config_c_hard_full_frame(oracle_mod):
@@ -831,7 +856,16 @@ def test_cpp_driver_runs(tmp_path):
     out = subprocess.run([exe, "--synthetic", "50000", "--res", "640x360", "--warmup", "3", "--frames", "10", "--ppm", ppm],
                          check=True, capture_output=True, text=True).stdout
     assert "total gpu time ms" in out and "elements to sort" in out
+    # the host draws through gsplat::Renderer (include/gsplat.hpp): its running means (Renderer.cpp:477-488, warm-up 3, then
+    # 10 frames) must be the plain mean of the last 10 frames' timings, and complete exactly at frame 13
+    assert "averages check" in out and out.split("averages check")[1].strip().endswith(": ok"), out[-600:]
+    # --present: Renderer::draw with the host sink every frame -- same file, same check
+    other = str(tmp_path / "frame_present.ppm")
+    out_p = subprocess.run([exe, "--synthetic", "50000", "--res", "640x360", "--warmup", "3", "--frames", "5", "--present", "--ppm", other],
+                           check=True, capture_output=True, text=True).stdout
+    assert out_p.split("averages check")[1].strip().endswith(": ok") and "present ms: 0.0000" not in out_p
     data = open(ppm, "rb").read()
+    assert open(other, "rb").read() == data
     assert data.startswith(b"P6\n640 360\n255\n") and len(data) == 15 + 640 * 360 * 3
     assert max(data[15:]) > 0
     # the same frame through the other sorters (--sort): identical file
@@ -843,7 +877,8 @@ def test_cpp_driver_runs(tmp_path):
     # the sharded-frame path of the same host (--ranks R forks one process per GPU before any GPU call; one card here, so
     # R = 1): gs_dist_unique_id -> gs_dist_init -> gs_dist_shard_rows -> gs_render_sharded, contiguous and interleaved
     # rows, no Python and no device pointer in the host -- identical file
-    for extra in (["--ranks", "1", "--interleaved"], ["--ranks", "1"]):
+    for extra in (["--ranks", "1", "--interleaved"], ["--ranks", "1"], ["--ranks", "1", "--sync"], ["--ranks", "1", "--balanced", "--rebalance", "2"],
+                  ["--ranks", "1", "--interleaved", "--sync"]):
         other = str(tmp_path / "frame_dist.ppm")
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GSPLAT_BENCH_DIST="1")
         p = subprocess.run([exe, "--synthetic", "50000", "--res", "640x360", "--warmup", "2", "--frames", "5", "--ppm", other] + extra,
@@ -861,7 +896,8 @@ def test_cpp_driver_runs(tmp_path):
         assert open(name, "rb").read() == data, name
 
 
-@pytest.mark.parametrize("ranks,rows", [(3, "contiguous"), (3, "interleaved"), (4, "interleaved"), (2, "contiguous")])
+@pytest.mark.parametrize("ranks,rows", [(3, "contiguous"), (3, "interleaved"), (4, "interleaved"), (2, "contiguous"),
+                                        (3, "balanced"), (4, "balanced"), (2, "balanced"), (3, "contiguous-sync"), (4, "interleaved-sync")])
 def test_cpp_host_several_ranks_over_a_mock_rccl(tmp_path, ranks, rows):
     """The multi-rank logic of csrc/gs_dist.cpp on the one GPU of a test box.  RCCL refuses two ranks on one device, so
     tools/mock_rccl builds a stand-in librccl.so.1 (named pipes between the processes, staged through the host) and puts
@@ -881,11 +917,36 @@ def test_cpp_host_several_ranks_over_a_mock_rccl(tmp_path, ranks, rows):
     out = str(tmp_path / "sharded.ppm")
     env = dict(os.environ, LD_LIBRARY_PATH=mock + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), MOCK_RCCL_DIR=str(tmp_path),
                GSPLAT_BENCH_SAME_DEVICE="1")
-    p = subprocess.run([exe] + base + ["--ppm", out, "--ranks", str(ranks)] + (["--interleaved"] if rows == "interleaved" else []),
-                       capture_output=True, text=True, timeout=300, env=env)
+    flags = {"interleaved": ["--interleaved"], "balanced": ["--balanced", "--rebalance", "2"], "contiguous-sync": ["--sync"],
+             "interleaved-sync": ["--interleaved", "--sync"]}.get(rows, [])
+    p = subprocess.run([exe] + base + ["--ppm", out, "--ranks", str(ranks)] + flags, capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0 and f"ranks: {ranks}" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
     assert "RCCL version" not in p.stdout + p.stderr, "the real RCCL was bound, not the mock"
+    # whichever way the rows are dealt, two frames in flight or one, bands moving between frames or not: the file one GPU writes
     assert open(out, "rb").read() == open(alone, "rb").read()
+    if rows == "balanced":
+        # the uniform cloud of --synthetic leaves little to move, but the protocol ran: every rank contributed its rows'
+        # element counts, all derived the same edges (or the exchange would have hung), the edges cover the 23 tile rows
+        line = [l for l in p.stdout.splitlines() if l.startswith("bands after")][0]
+        bands = [tuple(int(x) for x in b.split("-")) for b in line.split(":")[1].split()]
+        assert len(bands) == ranks and bands[0][0] == 0 and bands[-1][1] == 23 and all(bands[k][1] == bands[k + 1][0] for k in range(ranks - 1))
+    if "sync" not in rows:
+        assert "two frames in flight" in p.stdout and "copied to the host every frame" in p.stdout
+
+
+def test_cpp_host_leaves_when_a_rank_cannot_come_up(tmp_path):
+    """A rank that fails before the communicator exists (here: rank 1 asks for a device that is not there) says so over the
+    pipe it shares with rank 0; everybody leaves with a non-zero exit code instead of waiting in ncclCommInitRank."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(os.path.dirname(_lib.LIB_PATH), "gsplat_bench")
+    mock = os.path.join(ROOT, "tools", "mock_rccl")
+    subprocess.run(["make", "-C", mock], check=True, capture_output=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=mock + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), MOCK_RCCL_DIR=str(tmp_path),
+               GSPLAT_BENCH_SAME_DEVICE="1", GSPLAT_BENCH_FAIL_RANK="1")
+    p = subprocess.run([exe, "--synthetic", "20000", "--res", "320x180", "--warmup", "1", "--frames", "2", "--ranks", "3"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode != 0 and "not ready" in p.stderr and "ranks: 3" not in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
 
 
 @pytest.mark.parametrize("with_torch", [False, True])
@@ -926,12 +987,43 @@ def test_c_abi_sharded_frame_single_rank(with_torch):
         assert L.gs_dist_init(ctx, ident, 1, 1) == _lib.GS_ERR_INVALID and L.gs_dist_init(ctx, None, 0, 1) == _lib.GS_ERR_INVALID
         assert L.gs_dist_init(ctx, ident, 0, 1) == 0, L.gs_last_error(ctx)
         assert L.gs_dist_init(ctx, ident, 0, 1) == _lib.GS_ERR_INVALID          # twice
-        for interleaved in (0, 1, 0):
-            assert L.gs_dist_shard_rows(ctx, interleaved) == 0, L.gs_last_error(ctx)
+        assert L.gs_dist_shard_rows(ctx, 3) == _lib.GS_ERR_INVALID                # no such dealing
+        ty = (h + 15) // 16
+        for dealing in (_lib.ROWS_CONTIGUOUS, _lib.ROWS_INTERLEAVED, _lib.ROWS_BALANCED, _lib.ROWS_CONTIGUOUS):
+            assert L.gs_dist_shard_rows(ctx, dealing) == 0, L.gs_last_error(ctx)
             for _ in range(2):
                 img[:] = 0
                 assert L.gs_render_sharded(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0, img.ctypes.data) == 0, L.gs_last_error(ctx)
-                assert np.array_equal(img, ref), interleaved
+                assert np.array_equal(img, ref), dealing
+            # two sharded frames in flight, the assembled frames left in HBM: frame A (this camera), frame B (shMode 2)
+            dev = C.c_void_p()
+            assert L.gs_sharded_frame(ctx, 2, C.byref(dev)) == _lib.GS_ERR_INVALID
+            assert L.gs_render_sharded_async(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0) == 0, L.gs_last_error(ctx)
+            assert L.gs_render_sharded_async(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 2) == 0, L.gs_last_error(ctx)
+            a, b = np.zeros_like(ref), np.zeros_like(ref)
+            assert L.gs_sharded_read(ctx, 1, a.ctypes.data) == 0 and L.gs_sharded_read(ctx, 0, b.ctypes.data) == 0
+            assert np.array_equal(a, ref) and not np.array_equal(b, ref)
+            ref2 = np.zeros_like(ref)
+            assert L.gs_sharded_frame(ctx, 0, C.byref(dev)) == 0 and dev.value
+            hip = C.CDLL("libamdhip64.so")       # the runtime the process already holds: the device pointer IS the frame
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            assert hip.hipMemcpy(ref2.ctypes.data, dev, h * w * 4, 2) == 0 and np.array_equal(ref2, b)
+            edges = (C.c_uint32 * 2)()
+            if dealing == _lib.ROWS_INTERLEAVED:
+                assert L.gs_dist_bands(ctx, edges, 2) == _lib.GS_ERR_INVALID
+                assert L.gs_dist_rebalance(ctx, None) == _lib.GS_ERR_INVALID
+            else:
+                assert L.gs_dist_bands(ctx, edges, 2) == 0 and list(edges) == [0, ty] and L.gs_dist_bands(ctx, edges, 3) == _lib.GS_ERR_INVALID
+                moved = C.c_uint32(7)
+                if dealing == _lib.ROWS_BALANCED:
+                    assert L.gs_dist_rebalance(ctx, C.byref(moved)) == 0 and moved.value == 0, L.gs_last_error(ctx)    # one rank: nothing to move
+                else:
+                    assert L.gs_dist_rebalance(ctx, C.byref(moved)) == _lib.GS_ERR_INVALID
+            # the buffers belong to the rows dealt by gs_dist_shard_rows: rows changed behind its back are refused, not rendered
+            assert L.gs_set_tile_rows(ctx, 0, 3) == 0
+            assert L.gs_render_sharded(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0, img.ctypes.data) == _lib.GS_ERR_INVALID
+            assert b"gs_dist_shard_rows again" in L.gs_last_error(ctx)
+            assert L.gs_render_sharded_async(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0) == _lib.GS_ERR_INVALID
         assert L.gs_render_sharded(ctx, view.ctypes.data, proj.ctypes.data, pos.ctypes.data, 0, None) == _lib.GS_ERR_INVALID   # the root needs the image
         tm = _lib.GsTimings()
         assert L.gs_get_timings(ctx, C.byref(tm)) == 0 and tm.num_sort_elements > 1000      # filled by gs_render_sharded

@@ -39,6 +39,13 @@ ty, tx = (h + 15) // 16, (w + 15) // 16
 owner = gs.Renderer(w, h, record_timings=0, warmup_frames=0, sort_algorithm=sort); owner.init(rm); owner.initForScene(sc)
 
 
+def report(R, label, res, extra=""):
+    ms = np.array([x[0] for x in res]); es = np.array([x[1] for x in res], dtype=np.float64)
+    print(f"R={R} {label:11s}: max {ms.max():.4f} mean {ms.mean():.4f} max/mean {ms.max() / ms.mean():.3f} "
+          f"speed-up of the slowest rank {one_ms / ms.max():.2f}x | elements max/mean {es.max() / es.mean():.3f} | "
+          f"per rank ms {' '.join(f'{x:.3f}' for x in ms)}{extra}", flush=True)
+
+
 def cost(setup):
     r = gs.Renderer(w, h, record_timings=0, warmup_frames=0, sort_algorithm=sort); r.init(rm); r.initForScene(sc, share_with=owner)
     setup(r)
@@ -68,11 +75,15 @@ for R in a.ranks:
     }
     for label, setups in dealings.items():
         res = [cost(s) for s in setups]
-        ms = np.array([x[0] for x in res]); es = np.array([x[1] for x in res], dtype=np.float64)
         extra = ""
         if label == "balanced":
             extra = " bands " + " ".join(f"{b}-{e}" for b, e in dist.balanced_row_partition(row_elems, R))
-        print(f"R={R} {label:11s}: max {ms.max():.4f} mean {ms.mean():.4f} max/mean {ms.max() / ms.mean():.3f} "
-              f"speed-up of the slowest rank {one_ms / ms.max():.2f}x | elements max/mean {es.max() / es.mean():.3f} | "
-              f"per rank ms {' '.join(f'{x:.3f}' for x in ms)}{extra}", flush=True)
+        report(R, label, res, extra)
+    # element-balanced bands corrected by the measured share times (dist.RowBalancer: weight(row) = elements x the rate of the
+    # rank that rendered it), three rounds starting from the equal-rows split
+    bal = dist.RowBalancer(ty, R, min_gain=0.0)
+    for it in range(4):
+        res = [cost(lambda r, b=b: r.setTileRows(*b)) for b in bal.bands]
+        report(R, f"feedback {it}", res, " bands " + " ".join(f"{b}-{e}" for b, e in bal.bands))
+        bal.update(row_elems, [x[0] for x in res])
 owner.cleanup()

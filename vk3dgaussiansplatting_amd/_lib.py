@@ -113,8 +113,10 @@ EXPORTS = [
     "gs_set_stream", "gs_camera_matrices", "gs_sort_host", "gs_sort_bench", "gs_membench", "gs_write_image", "gs_share_scene",
     "gs_get_host_timings", "gs_set_tile_rows_interleaved", "gs_api_version", "gs_runtime_versions",
     "gs_dist_unique_id", "gs_dist_init", "gs_gather_strips", "gs_dist_destroy", "gs_dist_shard_rows", "gs_render_sharded",
+    "gs_render_sharded_async", "gs_sharded_frame", "gs_sharded_read", "gs_dist_rebalance", "gs_dist_bands", "gs_balance_rows",
 ]
-API_VERSION = 3            # GS_API_VERSION of include/gsplat.h this binding was written against
+ROWS_CONTIGUOUS, ROWS_INTERLEAVED, ROWS_BALANCED = 0, 1, 2   # GS_ROWS_*
+API_VERSION = 4            # GS_API_VERSION of include/gsplat.h this binding was written against
 DIST_UNIQUE_ID_BYTES = 128
 
 
@@ -224,6 +226,12 @@ def lib() -> C.CDLL:
     L.gs_dist_destroy.argtypes = [ctxp]
     L.gs_dist_shard_rows.argtypes = [ctxp, u32]
     L.gs_render_sharded.argtypes = [ctxp, vp, vp, vp, u32, vp]
+    L.gs_render_sharded_async.argtypes = [ctxp, vp, vp, vp, u32]
+    L.gs_sharded_frame.argtypes = [ctxp, u32, C.POINTER(vp)]
+    L.gs_sharded_read.argtypes = [ctxp, u32, vp]
+    L.gs_dist_rebalance.argtypes = [ctxp, C.POINTER(u32)]
+    L.gs_dist_bands.argtypes = [ctxp, C.POINTER(u32), u32]
+    L.gs_balance_rows.argtypes = [C.POINTER(C.c_double), u32, u32, C.POINTER(u32)]
     _lib = L
     _check_hip_runtime(L)
     return L

@@ -81,8 +81,7 @@ void free_resolution(gs_ctx* c) {
     free_sort(c->sort);
     free_dev(c->ranges); free_dev(c->tile_order); free_dev(c->framebuffer);
     // the strips of a sharded frame are sized by the resolution: gs_dist_shard_rows must be called again
-    free_dev(c->dist_strip); free_dev(c->dist_gathered); free_dev(c->dist_image);
-    c->dist_strip_bytes = 0;
+    gsi_dist_free_buffers(c);
     c->capacity = 0; c->width = c->height = 0;
     c->have_frame = false;
 }
@@ -148,6 +147,7 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
     // RadixSort.cpp:676-692) is unobservable once every later stage runs over E instead of C.
     // (the ranges and the sort's coarse totals are cleared inside k_scan_blocks: no fill launches in a frame)
     fp.parity = (c->emit_parity ^= 1u);
+    c->last_fp = fp;
     const bool splat_first = sorts_splat_first(c->cfg.sort_algorithm);
     const uint32_t digit = digit_bits_of(c->cfg.sort_algorithm);
     fp.splat_first = splat_first ? 1u : 0u;
@@ -769,6 +769,7 @@ int gs_debug_init_sort_list(gs_ctx* c, const float view[16], const float proj[16
     HIP_TRY(c, hipSetDevice(c->device));
     FrameParams fp = make_frame_params(c, view, proj, cam_pos, sh_mode);
     fp.parity = (c->emit_parity ^= 1u);
+    c->last_fp = fp;
     launch_project(fp, c->scene, c->scratch, c->stream);
     launch_scan_blocks(fp, c->scratch, c->sort.params, c->ranges, c->sort.coarse, c->stream);
     launch_emit(fp, c->scratch, c->sort, c->stream);
@@ -873,10 +874,27 @@ int gs_debug_read(gs_ctx* c, int which, void* dst, size_t bytes) {
             // already zeroed where the 2x2 determinant vanishes (RenderGaussians.comp:104), so it comes from the scene
             std::vector<float> opacity;
             std::vector<uint32_t> touched;
+            // N6 (InitSortList.comp:124-127): the reference stores colour for EVERY splat that passes the culls; the frame
+            // evaluates it for the emitting ones only, so the others are evaluated here, on demand, from the last frame's
+            // camera (k_debug_colour) -- in a context that owns the whole grid.  A context that owns a subset of the tile rows
+            // does not even project the splats that cannot reach its rows: there GS_BUF_COLOR stays what the frame stored.
+            std::vector<float> on_demand;
+            const bool whole_grid = c->row_begin == 0u && c->row_end == c->grid_h && c->row_stride == 1u;
             if (which == GS_BUF_COLOR) {
                 opacity.resize(c->n); touched.resize(c->n);
                 HIP_TRY(c, hipMemcpy(opacity.data(), c->scene.opacity, (size_t)c->n * sizeof(float), hipMemcpyDeviceToHost));
                 HIP_TRY(c, hipMemcpy(touched.data(), c->scratch.tiles_touched, (size_t)c->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                if (whole_grid) {
+                    float* dev = nullptr;
+                    HIP_TRY(c, hipMalloc((void**)&dev, need));
+                    launch_debug_colour(c->last_fp, c->scene, c->scratch, dev, c->stream);
+                    hipError_t e = hipGetLastError();
+                    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                    on_demand.resize((size_t)c->n * 4);
+                    if (e == hipSuccess) e = hipMemcpy(on_demand.data(), dev, need, hipMemcpyDeviceToHost);
+                    (void)hipFree(dev);
+                    HIP_TRY(c, e);
+                }
             }
             // records of a wave (64 consecutive splats) that k_project did not store this frame -- wholly culled, or with
             // nothing to emit into this context's tile rows -- read back as zero, what a culled splat's scratch holds
@@ -887,7 +905,12 @@ int gs_debug_read(gs_ctx* c, int which, void* dst, size_t bytes) {
                 if (!wrote[i / 64u]) continue;
                 const SplatRaster& r = host[i];
                 float* o = &outv[(size_t)i * 4];
-                if (which == GS_BUF_COLOR) { o[0] = r.r; o[1] = r.g; o[2] = r.b; o[3] = touched[i] ? opacity[i] : 0.0f; }
+                if (which == GS_BUF_COLOR) {
+                    if (touched[i]) { o[0] = r.r; o[1] = r.g; o[2] = r.b; o[3] = opacity[i]; }       // what the frame stored and blended
+                    else if (!on_demand.empty() && on_demand[(size_t)i * 4 + 3] != 0.0f) {           // passed the culls, touched no tile
+                        o[0] = on_demand[(size_t)i * 4]; o[1] = on_demand[(size_t)i * 4 + 1]; o[2] = on_demand[(size_t)i * 4 + 2]; o[3] = opacity[i];
+                    }
+                }
                 else { o[0] = r.cx; o[1] = r.cy; o[2] = r.cz; o[3] = 0.0f; }
             }
             std::memcpy(dst, outv.data(), bytes);

@@ -11,6 +11,8 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <utility>
+#include <vector>
 
 // The uploaded gaussian arrays (read-only on the path), reference-counted so that the contexts that render them
 // (gs_share_scene: frame slots, tile-row bands) can be destroyed in any order.
@@ -75,19 +77,35 @@ struct gs_ctx {
     bool have_entry = false;
     bool have_frame = false;
     bool unsorted_valid = false;   // last thing run was gs_debug_init_sort_list
+    gs::FrameParams last_fp{};     // of the last InitSortList launch (gs_debug_read(GS_BUF_COLOR) evaluates colours on demand)
 
     // gs_dist_init: the RCCL communicator of a multi-GPU frame (gs_dist.cpp)
     void* dist_comm = nullptr;
     int dist_rank = 0, dist_world = 1;
-    // gs_dist_shard_rows: this rank's strip, and on rank 0 the gathered strips (+ the frame re-ordered, interleaved rows)
-    void *dist_strip = nullptr, *dist_gathered = nullptr, *dist_image = nullptr;
-    size_t dist_strip_bytes = 0;
-    bool dist_interleaved = false;
+    // gs_dist_shard_rows: how the tile rows are dealt, and the buffers of a sharded frame -- two slots, so that the gather
+    // of frame f (on dist_stream) runs beside the kernels of frame f + 1 (on the context's stream)
+    uint32_t dist_dealing = 0;            // GS_ROWS_*
+    bool dist_sharded = false;
+    std::vector<uint32_t> dist_edges;     // contiguous / balanced: R + 1 band edges (tile rows), the same on every rank
+    uint32_t dist_rows_sig[5] = {};       // row_begin, row_end, row_stride, first_row, compact_out the buffers were set up for
+    void* dist_strip[2] = {};             // this rank's rows (not on the root of a contiguous dealing: it renders into the frame)
+    void* dist_gathered[2] = {};          // root, interleaved rows: the ranks' packed strips before they are re-ordered
+    void* dist_image[2] = {};             // root: the assembled frame, left in HBM
+    size_t dist_strip_bytes = 0;          // interleaved: bytes of one rank's packed strip (the same on every rank)
+    hipStream_t dist_stream = nullptr;
+    hipEvent_t dist_begin[2] = {}, dist_rendered[2] = {}, dist_done[2] = {};
+    bool dist_used[2] = {false, false};   // the slot's events have been recorded
+    int dist_next = 0;                    // slot of the next gs_render_sharded_async
+    int dist_recent[2] = {-1, -1};        // slots of the last and the last-but-one sharded frame
+    void* dist_xchg = nullptr;            // gs_dist_rebalance: R x (tiles_y + 1) words
+    std::vector<std::pair<double, double>> dist_history;   // ... (elements, ms) of every rank over the last epochs
 };
 
 
 // Text for gs_last_error(NULL) from translation units that have no context at hand (gs_dist.cpp); hidden: not an export.
 __attribute__((visibility("hidden"))) void gsi_set_create_error(const std::string& msg);
+// gs_dist.cpp: frees the buffers of a sharded frame (they are sized by the resolution); hidden: not an export.
+__attribute__((visibility("hidden"))) void gsi_dist_free_buffers(gs_ctx* c);
 // Renderer.cpp:458-475 for a frame enqueued with gs_render_device_async: wait, read the timestamps, fill gs_get_timings.
 __attribute__((visibility("hidden"))) int gsi_finish_frame(gs_ctx* c);
 

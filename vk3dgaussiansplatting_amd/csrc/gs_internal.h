@@ -177,6 +177,7 @@ inline void scatter_depth_bytes(uint32_t shift, uint32_t first_bit, bool drop_de
 void launch_project(const FrameParams& fp, const SceneBuffers& scene, const SplatScratch& sc,
                     hipStream_t stream);
 // sums == nullptr: block_sums -> block_offsets, the frame's clears, the IndirectSetup record in `params`.
+void launch_debug_colour(const FrameParams& fp, const SceneBuffers& scene, const SplatScratch& sc, float* out_rgba, hipStream_t stream);
 void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParams* params,
                         uint32_t* ranges, uint32_t* coarse, hipStream_t stream);
 void launch_emit(const FrameParams& fp, const SplatScratch& sc, const SortBuffers& sb,

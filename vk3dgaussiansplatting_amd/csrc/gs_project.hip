@@ -304,6 +304,41 @@ __global__ __launch_bounds__(kCullThreads) void k_band_cull(const FrameParams fp
 template <bool NT>
 __device__ __forceinline__ float sh_load(const float* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 
+// colour of a splat, InitSortList.comp:124-126 + Common.glsl:141-170 (k_project for the splats that emit, k_debug_colour for
+// the others: one body, so both store the same bits)
+template <bool NT>
+__device__ __forceinline__ void splat_colour(const FrameParams& fp, const float* shp, const uint32_t n, const float px, const float py,
+                                             const float pz, float res[3]) {
+    const float ddx = px - fp.cam_pos[0], ddy = py - fp.cam_pos[1], ddz = pz - fp.cam_pos[2];
+    const float len = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+    float basis[16];
+    sh_eval4(ddx / len, ddy / len, ddz / len, basis);
+    res[0] = 0.0f; res[1] = 0.0f; res[2] = 0.0f;
+    if (fp.sh_mode == 0u) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                res[c] = res[c] + sh_load<NT>(shp + (size_t)(i * 3 + c) * n) * basis[i];
+    } else if (fp.sh_mode == 1u) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                res[c] = res[c] + sh_load<NT>(shp + (size_t)(i * 3 + c) * n) * basis[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) res[c] = res[c] - 0.5f;
+    } else if (fp.sh_mode == 2u) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) res[c] = res[c] + sh_load<NT>(shp + (size_t)c * n) * basis[0];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        res[c] = res[c] + 0.5f;
+        res[c] = maxf(res[c], 0.0f);
+    }
+}
+
 // Seven workgroups per CU: left to itself the compiler hoists the 48 SH loads and takes 117 VGPRs (four waves per SIMD);
 // held to 72 it needs 65 without spilling, and the launch is 30 us shorter at config C (209 against 239 us).
 #ifndef GS_PROJECT_MINBLOCKS
@@ -432,36 +467,8 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
                         }
                         rec0.z = inv_x; rec0.w = inv_y;
                         rec2.x = opacity;
-                        // colour, InitSortList.comp:124-126 + Common.glsl:141-170
-                        const float ddx = px - fp.cam_pos[0], ddy = py - fp.cam_pos[1], ddz = pz - fp.cam_pos[2];
-                        const float len = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
-                        float basis[16];
-                        sh_eval4(ddx / len, ddy / len, ddz / len, basis);
-                        float res[3] = {0.0f, 0.0f, 0.0f};
-                        const float* shp = scene.sh + g;
-                        if (fp.sh_mode == 0u) {
-#pragma unroll
-                            for (int i = 0; i < 16; ++i)
-#pragma unroll
-                                for (int c = 0; c < 3; ++c)
-                                    res[c] = res[c] + sh_load<NT_SH>(shp + (size_t)(i * 3 + c) * n) * basis[i];
-                        } else if (fp.sh_mode == 1u) {
-#pragma unroll
-                            for (int i = 1; i < 16; ++i)
-#pragma unroll
-                                for (int c = 0; c < 3; ++c)
-                                    res[c] = res[c] + sh_load<NT_SH>(shp + (size_t)(i * 3 + c) * n) * basis[i];
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) res[c] = res[c] - 0.5f;
-                        } else if (fp.sh_mode == 2u) {
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) res[c] = res[c] + sh_load<NT_SH>(shp + (size_t)c * n) * basis[0];
-                        }
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            res[c] = res[c] + 0.5f;
-                            res[c] = maxf(res[c], 0.0f);
-                        }
+                        float res[3];
+                        splat_colour<NT_SH>(fp, scene.sh + g, n, px, py, pz, res);
                         rec1 = make_float4(inv_z, res[0], res[1], res[2]);
                         sc.depth_key[g] = depth_key;
                         sc.extents[g] = make_uint2((uint32_t)min_x | ((uint32_t)k0 << 16),
@@ -770,6 +777,29 @@ void launch_project(const FrameParams& fp, const SceneBuffers& scene, const Spla
         hipLaunchKernelGGL(k_project<true>, dim3(blocks), dim3(kProjThreads), 0, stream, fp, scene, sc, blocks);
     else
         hipLaunchKernelGGL(k_project<false>, dim3(blocks), dim3(kProjThreads), 0, stream, fp, scene, sc, blocks);
+}
+
+// gs_debug_read(GS_BUF_COLOR), full-grid contexts: the reference stores a colour for EVERY splat that passes the two culls
+// (InitSortList.comp:124-127, before it knows whether the splat touches a tile; SURVEY "preserve" item N6); k_project
+// evaluates it only for the splats that emit (nothing else is ever read by a frame).  This fills in the others on demand,
+// from the last frame's camera: out[g] = (r, g, b, 1) for a splat whose record k_project stored (its covariance carries
+// the +0.3 dilation, so .cx != 0 marks it) but which touched no tile, (0, 0, 0, 0) otherwise.
+__global__ __launch_bounds__(256) void k_debug_colour(const FrameParams fp, const SceneBuffers scene, const SplatScratch sc, float4* out) {
+    const uint32_t n = fp.num_gaussians;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n) return;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sc.wave_wrote[g >> 6] && sc.raster[g].cx != 0.0f && sc.tiles_touched[g] == 0u) {
+        float res[3];
+        splat_colour<false>(fp, scene.sh + g, n, scene.pos[g], scene.pos[(size_t)n + g], scene.pos[2 * (size_t)n + g], res);
+        o = make_float4(res[0], res[1], res[2], 1.0f);
+    }
+    out[g] = o;
+}
+
+void launch_debug_colour(const FrameParams& fp, const SceneBuffers& scene, const SplatScratch& sc, float* out_rgba, hipStream_t stream) {
+    const uint32_t blocks = (fp.num_gaussians + 255u) / 256u;
+    if (blocks) hipLaunchKernelGGL(k_debug_colour, dim3(blocks), dim3(256), 0, stream, fp, scene, sc, reinterpret_cast<float4*>(out_rgba));
 }
 
 void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParams* params,

@@ -51,6 +51,78 @@ def balanced_row_partition(row_weights, world_size: int) -> List[Tuple[int, int]
     return [(edges[r], edges[r + 1]) for r in range(world_size)]
 
 
+class RowBalancer:
+    """Element-balanced contiguous bands that follow the scene: every K frames each rank contributes the sort-element
+    counts of ITS tile rows (it has them: the frame's tile ranges) and, when it measures one, the GPU time of its share;
+    one small all-reduce later every rank holds the same two vectors and derives the same new band edges.
+
+    Model of a share's time: T_r = F + sum over its rows of weight(row).  F is what every share pays whatever it holds
+    (the launches of a frame, the passes' latency floor: at R = 8 more than half of a share), estimated as the intercept of
+    the least-squares line T = F + b E through the (elements, time) pairs of the last epochs; the rest of a rank's time is
+    spread over its rows in proportion to their elements:
+
+        weight(row) = elements(row) * (T_r - F) / E_r        (elements(row) when no times are known)
+
+    i.e. a row costs what its elements cost on the rank that had it -- which folds what does not scale with E (long lists
+    that saturate early, near-empty rows) into the next partition.  New edges sit at equal weight prefixes.  Hysteresis: the
+    bands move only when the model says the slowest rank gets at least `min_gain` faster, so that noise does not make the
+    bands (and the hipGraphs captured for them) flap.  Pure host arithmetic on identical inputs: every rank computes
+    identical edges without a further exchange.  (csrc/gs_dist.cpp: gs_dist_rebalance is the same rule behind the C-ABI,
+    statement for statement.)"""
+
+    HISTORY_EPOCHS = 4
+
+    def __init__(self, tiles_y: int, world_size: int, min_gain: float = 0.03):
+        self.tiles_y, self.world, self.min_gain = int(tiles_y), int(world_size), float(min_gain)
+        self.bands = tile_row_partition(self.tiles_y, self.world)
+        self.history: List[Tuple[float, float]] = []      # (elements, ms) of every rank over the last epochs
+        self.fixed_ms = 0.0
+
+    @staticmethod
+    def row_elements(ranges: np.ndarray, tiles_x: int, tiles_y: int) -> np.ndarray:
+        """[tiles, 2] {start, end} per tile (GS_BUF_RANGES; zero for tiles of other ranks) -> elements per tile row."""
+        r = np.asarray(ranges, dtype=np.int64).reshape(tiles_y, tiles_x, 2)
+        return (r[:, :, 1] - r[:, :, 0]).sum(axis=1)
+
+    @staticmethod
+    def fixed_cost(history, newest_ms) -> float:
+        """Intercept of the least-squares line through (elements, ms), kept inside [0, 0.8 min(newest times)]."""
+        n = len(history)
+        m_e = sum(h[0] for h in history) / n
+        m_t = sum(h[1] for h in history) / n
+        var = sum((h[0] - m_e) * (h[0] - m_e) for h in history)
+        cov = sum((h[0] - m_e) * (h[1] - m_t) for h in history)
+        f = 0.0
+        if var > 0.0 and cov > 0.0:
+            f = m_t - (cov / var) * m_e
+        if not f > 0.0:
+            f = 0.0
+        return min(f, 0.8 * min(newest_ms))
+
+    def update(self, row_elements, rank_ms=None) -> bool:
+        """row_elements: the summed vector (every row from the rank that owns it); rank_ms: per-rank share times or None.
+        Returns True when the bands changed."""
+        elems = np.asarray(row_elements, dtype=np.float64).reshape(self.tiles_y)
+        weights = elems.copy()
+        fixed = 0.0
+        if rank_ms is not None and all(t > 0.0 for t in rank_ms):
+            rank_ms = [float(t) for t in rank_ms]
+            totals = [float(elems[b:e].sum()) for b, e in self.bands]
+            self.history = (self.history + list(zip(totals, rank_ms)))[-self.HISTORY_EPOCHS * self.world:]
+            fixed = self.fixed_cost(self.history, rank_ms)
+            for r, (b, e) in enumerate(self.bands):
+                if e > b:
+                    # a band without elements still took its time: spread it over the rows
+                    weights[b:e] = elems[b:e] * ((rank_ms[r] - fixed) / totals[r]) if totals[r] > 0 else (rank_ms[r] - fixed) / (e - b)
+        self.fixed_ms = fixed
+        cost = lambda bands: fixed + max(weights[b:e].sum() for b, e in bands)
+        new = balanced_row_partition(weights, self.world)
+        if new != self.bands and cost(new) <= (1.0 - self.min_gain) * cost(self.bands):
+            self.bands = new
+            return True
+        return False
+
+
 def strip_rows(tiles_y: int, world_size: int, tile: int = 16) -> int:
     """Pixel rows of one (padded) strip."""
     return ((tiles_y + world_size - 1) // world_size) * tile
@@ -72,7 +144,7 @@ class ShardedFrame:
     the CPU test (an injected checker)."""
 
     def __init__(self, width: int, height: int, rank: int, world_size: int, device="cpu", group=None,
-                 host_gather: bool = False, n_strips: int = 2, interleaved: bool = False):
+                 host_gather: bool = False, n_strips: int = 2, interleaved: bool = False, bands=None):
         import torch
         self.torch = torch
         self.width, self.height = width, height
@@ -81,18 +153,33 @@ class ShardedFrame:
         # interleaved: rank r owns tile rows r, r + world, ...; its strip holds them packed (owned row k at strip
         # rows [16 k, 16 k + 16)), which is what a context set up with gs_set_tile_rows_interleaved(r, world, 1) writes
         self.interleaved = interleaved
-        self.bands = tile_row_partition(self.tiles_y, world_size)
-        self.rows = strip_rows(self.tiles_y, world_size)
         self.group = group
         self.device = device
         self.n_strips = n_strips
-        self.strips = [torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=device) for _ in range(n_strips)]
         # host_gather: rehearsal of the N > 1 path on one GPU (gloo has no device gather)
         self.host_gather = host_gather
-        gdev = "cpu" if host_gather else device
-        self.gathered = [([torch.zeros((self.rows, width, 4), dtype=torch.uint8, device=gdev) for _ in range(world_size)]
-                          if rank == 0 and world_size > 1 else None) for _ in range(n_strips)]
         self._pending = [None] * n_strips
+        self.rows = 0
+        self.set_bands(bands if bands is not None else tile_row_partition(self.tiles_y, world_size))
+
+    def set_bands(self, bands):
+        """Contiguous bands of ANY heights (balanced_row_partition / RowBalancer): every rank passes the same list.  The
+        strips are as tall as the tallest band (one gather of equal strips; the padding is cropped by assemble) and are
+        re-allocated only when that height grows.  No gather may be pending."""
+        torch = self.torch
+        bands = [(int(b), int(e)) for b, e in bands]
+        assert len(bands) == self.world and bands[0][0] == 0 and bands[-1][1] == self.tiles_y
+        assert all(bands[r][1] == bands[r + 1][0] for r in range(self.world - 1)) and all(b <= e for b, e in bands)
+        assert all(p is None for p in self._pending), "set_bands with a gather in flight"
+        self.bands = bands
+        rows = (self.tiles_y + self.world - 1) // self.world if self.interleaved else max(e - b for b, e in bands)
+        rows = max(rows, 1) * 16
+        if rows > self.rows:
+            self.rows = rows
+            self.strips = [torch.zeros((rows, self.width, 4), dtype=torch.uint8, device=self.device) for _ in range(self.n_strips)]
+            gdev = "cpu" if self.host_gather else self.device
+            self.gathered = [([torch.zeros((rows, self.width, 4), dtype=torch.uint8, device=gdev) for _ in range(self.world)]
+                              if self.rank == 0 and self.world > 1 else None) for _ in range(self.n_strips)]
 
     @property
     def strip(self):
