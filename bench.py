@@ -65,9 +65,10 @@ def parse_args(argv=None):
     ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2, 3],
                     help="frame slots of the TIMED region (default 1 = a frame's GPU time, like the reference's "
                          "timestamps); the 3-slot throughput is always reported as an extra field")
-    ap.add_argument("--rows", default="contiguous", choices=["contiguous", "interleaved"],
-                    help="N > 1: how tile rows are dealt to ranks (interleaved = row r to rank r mod N, for scenes "
-                         "whose splat density varies over the height of the frame)")
+    ap.add_argument("--rows", default="contiguous", choices=["contiguous", "interleaved", "balanced"],
+                    help="N > 1: how tile rows are dealt to ranks (interleaved = row r to rank r mod N; balanced = contiguous bands "
+                         "whose edges follow the scene: re-cut from the per-row element counts and the ranks' share times, "
+                         "dist.RowBalancer -- both for scenes whose splat density varies over the height of the frame)")
     ap.add_argument("--pose", default=None, choices=["garden", "train", "bicycle"],
                     help="render the workload from the reference's 'Camera for benchmarks' of that scene (Scenes/GardenScene.cpp:11-12, "
                          "...): the cloud is moved rigidly in front of that camera and stored in Morton order of the moved positions "
@@ -552,14 +553,15 @@ def main():
                 "radix8": gs.GS_SORT_RADIX8, "radix8_splat_first": gs.GS_SORT_RADIX8_SPLAT_FIRST}
     interleaved = args.rows == "interleaved" and world > 1
 
-    def make(record, sort=None, share=None, render_mode=None, res=None):
+    def make(record, sort=None, share=None, render_mode=None, res=None, world_=None):
         rw, rh = res or (w, h)
+        rm_, scene_ = world_ or (rm, scene)
         r = gs.Renderer(rw, rh, device=local_rank, render_mode=mode if render_mode is None else render_mode,
                         record_timings=record, warmup_frames=0,
                         sort_algorithm=sort_ids[sort or args.sort],
                         render_kernel=0 if args.render_kernel == "auto" else int(args.render_kernel))
-        r.init(rm)
-        r.initForScene(scene, share_with=share)
+        r.init(rm_)
+        r.initForScene(scene_, share_with=share)
         return r
 
     def set_rows(r, sf):
@@ -568,39 +570,59 @@ def main():
         else:
             r.setTileRows(*sf.band)
 
+    REBALANCE_EVERY = 64
+
     class Ring:
         """F frame slots: slot k = a context with its own per-frame buffers on its own stream, rendering into strip k;
         the gaussian arrays are uploaded once and shared (gs_share_scene).  Frame f goes to slot f % F.  F = 1 is a
-        frame's GPU time (nothing overlaps); F = 3 is the reference's FRAMES_IN_FLIGHT."""
+        frame's GPU time (nothing overlaps); F = 3 is the reference's FRAMES_IN_FLIGHT.
+        rows: how the tile rows are dealt (default: --rows); "balanced" = contiguous bands re-cut by dist.RowBalancer from the
+        all-reduced per-row element counts and the ranks' measured share times: a few rounds before the warm-up, then every
+        REBALANCE_EVERY steps INSIDE the timed region (the measurement pays for its own rebalancing)."""
 
-        def __init__(self, F, sort=None, owner=None, render_mode=None, res=None):
+        def __init__(self, F, sort=None, owner=None, render_mode=None, res=None, world_=None, rows=None):
             self.F, self.n = F, 0
             rw, rh = res or (w, h)
+            self.rw, self.scene = rw, (world_ or (rm, scene))[1]
+            rows = rows or args.rows
+            self.inter = rows == "interleaved" and world > 1
+            self.balancer = None
             # N > 1: at least two strips, so that the gather of frame f runs beside the rendering of frame f + 1 (the
             # rasterization itself stays in F slots; only the collective is double-buffered)
             self.S = max(F, 2) if world > 1 else F
             self.sf = gsdist.ShardedFrame(rw, rh, rank, world, device=device, host_gather=args.rehearse, n_strips=self.S,
-                                          interleaved=interleaved)
-            rb = 0 if interleaved else self.sf.band[0]
-            # the library addresses the FULL frame; hand it the strips shifted up by the band's first row
-            self.ptrs = [s_.data_ptr() - rb * 16 * rw * 4 for s_ in self.sf.strips] if not interleaved else \
-                        [s_.data_ptr() for s_ in self.sf.strips]
+                                          interleaved=self.inter)
+            if rows == "balanced" and world > 1:
+                self.balancer = gsdist.RowBalancer(self.sf.tiles_y, world)
+                self.sf.set_bands(self.balancer.bands)
             self.rs, self.streams = [], []
             for k in range(F):
-                rk = make(0, sort, share=owner if owner is not None else (self.rs[0] if k else None), render_mode=render_mode, res=res)
-                set_rows(rk, self.sf)
+                rk = make(0, sort, share=owner if owner is not None else (self.rs[0] if k else None), render_mode=render_mode, res=res,
+                          world_=world_)
                 st = torch.cuda.Stream(device=device)
                 rk.setStream(st.cuda_stream)
                 self.rs.append(rk)
                 self.streams.append(st)
-            self.gather_s = 0.0
+            self.bind_rows()
+            self.rebalance_moves, self.rebalance_calls, self.rebalance_s = 0, 0, 0.0
+
+        def bind_rows(self):
+            # the library addresses the FULL frame; hand it the strips shifted up by the band's first row
+            rb = 0 if self.inter else self.sf.band[0]
+            self.ptrs = [s_.data_ptr() for s_ in self.sf.strips] if self.inter else \
+                        [s_.data_ptr() - rb * 16 * self.rw * 4 for s_ in self.sf.strips]
+            for rk in self.rs:
+                if self.inter:
+                    rk.setTileRowsInterleaved(rank, world)
+                else:
+                    rk.setTileRows(*self.sf.band)
 
         def step(self):
             k, st = self.n % self.F, self.n % self.S
             self.n += 1
             with torch.cuda.stream(self.streams[k]):
                 self.sf.wait(st)                 # the previous gather of this strip must have read it
-                self.rs[k].drawDevice(scene, self.ptrs[st], sync=False, compact_rows=interleaved)
+                self.rs[k].drawDevice(self.scene, self.ptrs[st], sync=False, compact_rows=self.inter)
                 if world > 1:
                     self.sf.gather_async(st)
 
@@ -611,18 +633,60 @@ def main():
                 tdist.barrier()
                 torch.cuda.synchronize()
 
+        def rebalance(self):
+            """Collective.  One frame of this rank's share between two events (its GPU time, no gather), the elements of its
+            tile rows from the frame's ranges; all-reduce; every rank derives the same bands (dist.RowBalancer)."""
+            t_r = time.perf_counter()
+            self.sf.wait_all()
+            torch.cuda.synchronize()
+            rk = self.rs[0]
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(self.streams[0]):
+                ev0.record()
+                rk.drawDevice(self.scene, self.ptrs[0], sync=False, compact_rows=False)
+                ev1.record()
+            torch.cuda.synchronize()
+            info_ = rk.sceneInfo()
+            rows_ = gsdist.RowBalancer.row_elements(rk.debugRead(gs.BUF_RANGES), int(info_.tiles_x), int(info_.tiles_y))
+            cdev = "cpu" if args.rehearse else device
+            vec = torch.zeros(self.sf.tiles_y + world, dtype=torch.float64, device=cdev)
+            vec[:self.sf.tiles_y] = torch.from_numpy(rows_.astype(np.float64)).to(cdev)
+            vec[self.sf.tiles_y + rank] = ev0.elapsed_time(ev1)
+            tdist.all_reduce(vec)                      # every row from the rank that owns it, every time from its rank
+            vec = vec.cpu().numpy()
+            moved = self.balancer.update(vec[:self.sf.tiles_y], [float(x) for x in vec[self.sf.tiles_y:]])
+            if moved:
+                self.sf.set_bands(self.balancer.bands)
+                self.bind_rows()
+                for _ in range(self.S):                # the new bands' hipGraphs are captured outside the timed frames' steady state
+                    self.step()
+                self.sf.wait_all()
+                torch.cuda.synchronize()
+            self.rebalance_calls += 1
+            self.rebalance_moves += int(moved)
+            self.rebalance_s += time.perf_counter() - t_r
+            return moved
+
         def timed(self, steps, warmup):
             # one untimed frame per slot first: the hipGraph of the radix passes is captured on a slot's first frame
             # and kernels are loaded lazily, so the W warm-up and K timed steps are steady-state frames
             for _ in range(max(self.F, self.S)):
                 self.step()
             self.barrier()
+            if self.balancer is not None:
+                for _ in range(4):                     # the bands settle before the warm-up ...
+                    if not self.rebalance():
+                        break
+                self.barrier()
+                self.rebalance_s = 0.0
             self.n = 0
             for _ in range(warmup):
                 self.step()
             self.barrier()
             t_begin = time.perf_counter()
-            for _ in range(steps):
+            for i in range(steps):
+                if self.balancer is not None and i and i % REBALANCE_EVERY == 0:
+                    self.rebalance()                   # ... and are checked again every REBALANCE_EVERY frames, inside the timed region
                 self.step()
             self.barrier()
             elapsed = time.perf_counter() - t_begin
@@ -883,35 +947,45 @@ def main():
     def flag_all(ok):
         return all_ranks_ok(tdist, ok, "cpu" if args.rehearse else device)
 
-    def sharded_phase(sort=None, res=None, ref_img=None):
+    def sharded_phase(sort=None, res=None, ref_img=None, world_=None, rows=None, scene_owner=None):
         """One guarded phase: the frame at `res` (default: the timed one) with sorter `sort` (default: the timed one) over the
-        same ranks, timed like the headline; rank 0 also renders it alone with that sorter.  Returns (fields, rank 0's frame)."""
+        same ranks, timed like the headline; rank 0 also renders it alone with that sorter.  world_ = (ResourceManager, Scene)
+        of another cloud (with scene_owner = the context that uploaded it on this rank); rows = how its tile rows are dealt
+        (default: --rows).  Returns (fields, rank 0's frame)."""
         rw, rh = res or (w, h)
+        scene_ = (world_ or (rm, scene))[1]
+        own_ = scene_owner if world_ is not None else owner
         ra, err = None, None
         try:
-            ra = Ring(1, sort=sort, owner=owner, res=res)
+            ra = Ring(1, sort=sort, owner=own_, res=res, world_=world_, rows=rows)
         except Exception as ex:  # noqa: BLE001
             err = repr(ex)
         if not flag_all(err is None):
             if ra is not None:
                 ra.close()
             return {"skipped": err or "set-up failed on another rank"}, None
+        ms_a = ra.timed(min(args.steps, 200), 10)
+        # the frame the ranks assemble (after the timed region: with rows = "balanced" the bands have settled by now)
         with torch.cuda.stream(ra.streams[0]):
             ra.sf.wait(0)
-            ra.rs[0].drawDevice(scene, ra.ptrs[0], sync=False, compact_rows=interleaved)
+            ra.rs[0].drawDevice(scene_, ra.ptrs[0], sync=False, compact_rows=ra.inter)
             strips_a = ra.sf.gather(0)
         torch.cuda.synchronize()
         assembled = ra.sf.assemble(strips_a) if rank == 0 else None
-        ms_a = ra.timed(min(args.steps, 200), 10)
+        bal = None
+        if ra.balancer is not None:
+            bal = {"bands": [list(b) for b in ra.sf.bands], "rebalance_calls_in_timed_region": ra.rebalance_calls, "moves": ra.rebalance_moves,
+                   "rebalance_ms_per_call": round(ra.rebalance_s / max(ra.rebalance_calls, 1) * 1e3, 3),
+                   "fixed_cost_ms_of_the_model": round(ra.balancer.fixed_ms, 4)}
         ra.close()
         one_a, same, alone = None, None, None
         if rank == 0:                                  # the same frame on one GPU alone with this sorter
             alone = torch.zeros((rh, rw, 4), dtype=torch.uint8, device=device)
-            rf_ = make(1, sort=sort, share=owner, res=res)
+            rf_ = make(1, sort=sort, share=own_, res=res, world_=world_)
             rf_.setStream(torch.cuda.current_stream().cuda_stream)
             tot_ = []
             for i in range(13):
-                rf_.drawDevice(scene, alone.data_ptr(), sync=True)
+                rf_.drawDevice(scene_, alone.data_ptr(), sync=True)
                 if i >= 3:
                     tot_.append(rf_.timings().total_ms)
             one_a = float(np.mean(tot_))
@@ -920,10 +994,52 @@ def main():
             want = alone if ref_img is None else ref_img        # ref_img: the default sorter's one-GPU frame
             same = bool(torch.equal(assembled.to(want.device), want)) and bool(torch.equal(alone, want))
         tdist.barrier()
-        return {"ms_per_step": round(ms_a, 4), "value": round(n / ms_a / 1000.0, 2), "unit": "Msplats/s",
+        res_ = {"ms_per_step": round(ms_a, 4), "value": round(n / ms_a / 1000.0, 2), "unit": "Msplats/s",
                 "sharded_image_matches_single_gpu": same,
                 "one_gpu_same_frame_ms": round(one_a, 4) if one_a else None,
-                "speedup_vs_one_gpu_same_frame": round(one_a / ms_a, 3) if one_a else None}, alone
+                "speedup_vs_one_gpu_same_frame": round(one_a / ms_a, 3) if one_a else None}
+        if bal is not None:
+            res_["balanced_rows"] = bal
+        return res_, alone
+
+    def sharded_hard_cloud_phase():
+        # the headline cloud is fog: every band of equal height holds the same work.  The capture-like cloud (config Chard:
+        # clusters, a ground plane, tile rows from 50 k to 470 k elements) over the same ranks, with equal bands and with
+        # bands that follow the scene (--rows balanced: dist.RowBalancer): a sharded frame ends with its SLOWEST rank.
+        t_g = time.time()
+        err, world_h, own_h = None, None, None
+        try:
+            aos_h = synth.generate_config("Chard")[0]
+            rm_h = gs.ResourceManager()
+            rm_h.setGaussians(aos_h)
+            scene_h = gs.Scene(rm_h, aspect_ratio=w / h)
+            scene_h.getCamera().setPosition((0.0, 0.0, 0.0))
+            scene_h.getCamera().setRotation(0.0, 0.0)
+            scene_h.getCamera().recalculate()
+            world_h = (rm_h, scene_h)
+            own_h = make(0, world_=world_h)            # uploads the cloud on this rank; the phases' contexts share it
+        except Exception as ex:  # noqa: BLE001
+            err = repr(ex)
+        if not flag_all(err is None):
+            if own_h is not None:
+                own_h.cleanup()
+            return {"skipped": err or "set-up failed on another rank"}
+        log(f"[bench] rank {rank}: config Chard generated and uploaded in {time.time() - t_g:.1f}s")
+        out_h = {"workload": WORKLOADS["Chard"]}
+        ref_frame = None
+        for rows_ in ("contiguous", "balanced"):
+            res_, frame_ = sharded_phase(world_=world_h, rows=rows_, scene_owner=own_h, ref_img=ref_frame)
+            out_h[rows_] = res_
+            if "skipped" in res_:
+                break
+            ref_frame = frame_ if ref_frame is None else ref_frame
+        if "skipped" not in out_h.get("balanced", {"skipped": 1}) and "skipped" not in out_h["contiguous"]:
+            out_h["balanced_vs_contiguous"] = round(out_h["contiguous"]["ms_per_step"] / out_h["balanced"]["ms_per_step"], 3)
+        out_h["note"] = ("the capture-like cloud of `hard_cloud` over the same ranks, timed like the headline (one frame slot, gather "
+                         "included, slowest rank): equal bands, then bands re-cut from the per-row element counts and the ranks' share "
+                         f"times (before the warm-up and every {REBALANCE_EVERY} frames inside the timed region)")
+        own_h.cleanup()
+        return out_h
 
     def alt_phase(name):
         out, _ = sharded_phase(sort=name, ref_img=full if rank == 0 else None)
@@ -1303,7 +1419,7 @@ def main():
     #      collective that hangs inside one of them costs the run these blocks, not its line
     if world > 1 and not args.no_extras:
         import threading
-        limit_s = float(os.environ.get("GS_BENCH_PHASES_LIMIT_S", "300"))
+        limit_s = float(os.environ.get("GS_BENCH_PHASES_LIMIT_S", "420"))
         phases = {}
 
         def give_up_phases():
@@ -1332,6 +1448,12 @@ def main():
                 log(f"[bench] 4K phase failed on rank {rank}: {ex!r}")
                 phases["sharded_4k"] = {"error": repr(ex)}
             phase_done("sharded_4k")
+            try:
+                phases["sharded_hard_cloud"] = sharded_hard_cloud_phase()
+            except Exception as ex:  # noqa: BLE001
+                log(f"[bench] hard-cloud phase failed on rank {rank}: {ex!r}")
+                phases["sharded_hard_cloud"] = {"error": repr(ex)}
+            phase_done("sharded_hard_cloud")
         alt = {}
         for name in ("radix8_splat_first", "bucket", "splat_first"):
             if name != args.sort:
@@ -1379,50 +1501,70 @@ def main():
             if world > 1:
                 tdist.broadcast_object_list(box, src=0)
             rc_ = make(0, share=owner)
-            set_rows(rc_, sf_main)
             st_c = torch.cuda.Stream(device=device)
             rc_.setStream(st_c.cuda_stream)
-            ok_init = L.gs_dist_init(rc_._ctx.handle, box[0], rank, world) == 0
+            h_ = rc_._ctx.handle
+            ok_init = L.gs_dist_init(h_, box[0], rank, world) == 0
+            if ok_init:
+                dealing = {"contiguous": _lib.ROWS_CONTIGUOUS, "interleaved": _lib.ROWS_INTERLEAVED, "balanced": _lib.ROWS_BALANCED}[args.rows]
+                ok_init = L.gs_dist_shard_rows(h_, dealing) == 0
             if not ok_init:
-                log(f"[bench] rank {rank}: gs_dist_init: {L.gs_last_error(rc_._ctx.handle).decode()}")
+                log(f"[bench] rank {rank}: gs_dist_init / gs_dist_shard_rows: {L.gs_last_error(h_).decode()}")
             if not (flag_all(ok_init) if world > 1 else ok_init):
-                res = {"skipped": "gs_dist_init failed on a rank"}
+                res = {"skipped": "gs_dist_init / gs_dist_shard_rows failed on a rank"}
             else:
-                strip = sf_main.strips[0]
-                nbytes = strip.numel()
-                gathered = torch.zeros((world,) + tuple(strip.shape), dtype=torch.uint8, device=device) if rank == 0 else None
+                cam_ = scene.getCamera()
+                view_, proj_, pos_ = (np.ascontiguousarray(a_, dtype=np.float32) for a_ in
+                                      (cam_.getViewMatrix(), cam_.getProjectionMatrix(), cam_.getPosition()))
+                sh_ = int(cam_.getShMode())
+                moved_ = C.c_uint32(0)
 
                 def frame_and_gather():
-                    rc_.drawDevice(scene, strip_ptr, sync=False, compact_rows=interleaved)
-                    r_ = L.gs_gather_strips(rc_._ctx.handle, strip.data_ptr(), gathered.data_ptr() if rank == 0 else None, nbytes, 0)
-                    if r_ != 0:
-                        raise RuntimeError(L.gs_last_error(rc_._ctx.handle).decode())
+                    r_ = L.gs_render_sharded_async(h_, view_.ctypes.data, proj_.ctypes.data, pos_.ctypes.data, sh_)
+                    if r_ < 0:
+                        raise RuntimeError(L.gs_last_error(h_).decode())
+
+                def wait_last():
+                    dev_ = C.c_void_p()
+                    if L.gs_sharded_frame(h_, 0, C.byref(dev_)) != 0:
+                        raise RuntimeError(L.gs_last_error(h_).decode())
+                    return dev_.value
                 torch.cuda.synchronize()
-                for _ in range(3):
+                for i_ in range(6):
                     frame_and_gather()
-                rc_.synchronize()
+                    if args.rows == "balanced" and i_ in (2, 4) and L.gs_dist_rebalance(h_, C.byref(moved_)) < 0:
+                        raise RuntimeError(L.gs_last_error(h_).decode())
+                dev_ptr = wait_last()
                 same = None
                 if rank == 0:
-                    img_c = sf_main.assemble([gathered[r_] for r_ in range(world)])
+                    img_c = torch.empty((h, w, 4), dtype=torch.uint8, device=device)
+                    hip_rt = C.CDLL("libamdhip64.so")
+                    hip_rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+                    if hip_rt.hipMemcpy(img_c.data_ptr(), dev_ptr, h * w * 4, 3) != 0:        # device to device
+                        raise RuntimeError("hipMemcpy of the assembled frame failed")
                     if full is not None:
                         same = bool(torch.equal(img_c, full))
-                    else:                                   # one rank: the strip is the frame
-                        same = bool(torch.equal(gathered[0], strip))
+                    else:                                   # one rank: the frame the torch path rendered into its strip
+                        same = bool(torch.equal(img_c, sf_main.strips[0][:h]))
                 k_c = min(args.steps, 200)
                 if world > 1:
                     tdist.barrier()
                 t_c = time.perf_counter()
-                for _ in range(k_c):
+                for i_ in range(k_c):
+                    if args.rows == "balanced" and i_ and i_ % REBALANCE_EVERY == 0 and L.gs_dist_rebalance(h_, C.byref(moved_)) < 0:
+                        raise RuntimeError(L.gs_last_error(h_).decode())
                     frame_and_gather()
-                rc_.synchronize()
+                wait_last()
                 el_c = torch.tensor([(time.perf_counter() - t_c) / k_c * 1e3], dtype=torch.float64, device="cpu" if args.rehearse else device)
                 if world > 1:
                     tdist.all_reduce(el_c, op=tdist.ReduceOp.MAX)
                 ms_c = float(el_c.item())
                 res = {"ms_per_step": round(ms_c, 4), "value": round(n / ms_c / 1000.0, 2), "unit": "Msplats/s",
-                       "assembled_frame_matches": same,
-                       "note": "frame + gs_gather_strips on the context's stream, one frame slot, no overlap of the gather with the "
-                               "next frame (the headline double-buffers its strips); slowest rank"}
+                       "assembled_frame_matches": same, "vs_headline_ms_per_step": round(ms_c / ms_per_step, 4),
+                       "note": "gs_dist_shard_rows + gs_render_sharded_async: the library's own strips and exchange (RCCL bound by the "
+                               "library, grouped ncclSend / ncclRecv on a stream of its own), two frames in flight, the assembled frame "
+                               "left in rank 0's HBM -- what a C++ host without device pointers gets (tools/gsplat_bench --ranks N); "
+                               "slowest rank"}
                 L.gs_dist_destroy(rc_._ctx.handle)
             rc_.setStream(None)
             rc_.cleanup()
