@@ -36,3 +36,19 @@ for k in sorted(set(a[0]) | set(b[0]), key=lambda k: -(b[0].get(k, (0, 0, 0))[2]
     print(f"{k[:44]:44s} {cb / frames:11.2f} {ua:8.2f} {ub:8.2f} {ub / ua if ua else 0:6.2f} | "
           f"{a[1]['FETCH_SIZE'].get(k, 0) / 1e6:9.1f} {b[1]['FETCH_SIZE'].get(k, 0) / 1e6:10.1f} {a[1]['WRITE_SIZE'].get(k, 0) / 1e6:9.1f} {b[1]['WRITE_SIZE'].get(k, 0) / 1e6:10.1f}")
 print(f"sum of kernel time per frame: own {tot[0]:.1f} us, pose {tot[1]:.1f} us")
+# the pose's own two tables in the formats of tools/kstats.py and tools/pmc_frame.sh (profiles/rNN_bench_configC_garden_pose_kernel_stats.txt,
+# rNN_pmc_frame_traffic_configC_garden_pose.txt)
+with open(f"{d}/kstats_{pose}.txt", "w") as f:
+    for r in csv.DictReader(open(glob.glob(f"{d}/k_{pose}/**/*kernel_stats.csv", recursive=True)[0])):
+        f.write(f"{r['Name'][:70]:70s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.2f} min_us={float(r['MinNs'])/1e3:8.2f} pct={r['Percentage']}\n")
+with open(f"{d}/pmc_frame_{pose}.txt", "w") as f:
+    raw = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(glob.glob(f"{d}/pmc_{pose}_{c}/**/*counter_collection.csv", recursive=True)[0])):
+            agg[r["Kernel_Name"].split("(")[0][:48]].append(float(r["Counter_Value"]))
+        raw[c] = agg
+    for k in sorted(raw["FETCH_SIZE"]):
+        fv = raw["FETCH_SIZE"][k]; wv = raw["WRITE_SIZE"].get(k, [0])
+        rd, wr = 2 * sum(fv) / len(fv) * 1024, sum(wv) / len(wv) * 1024     # FETCH_SIZE x2 (MI355X_MICROARCH.md), KB -> bytes
+        f.write(f"{k:50s} launches={len(fv):4d}  read {rd/1e6:9.1f} MB  write {wr/1e6:9.1f} MB\n")
