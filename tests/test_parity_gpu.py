@@ -912,6 +912,8 @@ def test_cpp_host_several_ranks_over_a_mock_rccl(tmp_path, ranks, rows):
     mock = os.path.join(ROOT, "tools", "mock_rccl")
     subprocess.run(["make", "-C", mock], check=True, capture_output=True)
     base = ["--synthetic", "60000", "--res", "640x360", "--warmup", "2", "--frames", "4"]
+    if rows == "balanced":
+        base = ["--synthetic", "60000", "--skew", "--res", "640x360", "--warmup", "4", "--frames", "8"]    # equal bands are not equal work
     alone = str(tmp_path / "alone.ppm")
     subprocess.run([exe] + base + ["--ppm", alone], check=True, capture_output=True, timeout=300)
     out = str(tmp_path / "sharded.ppm")
@@ -925,11 +927,15 @@ def test_cpp_host_several_ranks_over_a_mock_rccl(tmp_path, ranks, rows):
     # whichever way the rows are dealt, two frames in flight or one, bands moving between frames or not: the file one GPU writes
     assert open(out, "rb").read() == open(alone, "rb").read()
     if rows == "balanced":
-        # the uniform cloud of --synthetic leaves little to move, but the protocol ran: every rank contributed its rows'
-        # element counts, all derived the same edges (or the exchange would have hung), the edges cover the 23 tile rows
+        # the protocol ran: every rank contributed its rows' element counts and share time, all derived the same edges (or the
+        # exchange would have hung), the edges cover the 23 tile rows
         line = [l for l in p.stdout.splitlines() if l.startswith("bands after")][0]
         bands = [tuple(int(x) for x in b.split("-")) for b in line.split(":")[1].split()]
         assert len(bands) == ranks and bands[0][0] == 0 and bands[-1][1] == 23 and all(bands[k][1] == bands[k + 1][0] for k in range(ranks - 1))
+        # the skewed cloud crowds the upper rows: the bands MOVED between frames (and the file is still the one-GPU file), the
+        # first band ends up shorter than an equal share
+        moves = int(line.split()[2])
+        assert moves >= 1 and bands[0][1] - bands[0][0] < -(-23 // ranks), (line, moves)
     if "sync" not in rows:
         assert "two frames in flight" in p.stdout and "copied to the host every frame" in p.stdout
 
@@ -1177,6 +1183,41 @@ def test_ply_end_to_end(oracle_mod, tmp_path):
     _, ref = oracle_run(oracle_mod, sc, w, h)
     assert ref["e"] > 3000
     assert_frame_equals_oracle(r, img, ref)
+    r.cleanup()
+
+
+@pytest.mark.parametrize("world", [3, 5])
+def test_one_context_sweeping_element_balanced_bands(oracle_mod, world):
+    """A capture-like cloud (synth kind="hard": clusters, a ground plane) whose tile rows hold very different numbers of
+    elements: one context renders every band of dist.balanced_row_partition over the frame's own per-row element counts; the
+    bands' lists are the frame's list restricted to their rows, their elements add up to the frame's, their pixel rows tile the
+    frame.  (What a rank of a GS_ROWS_BALANCED / --rows balanced frame runs after a rebalance.)"""
+    from vk3dgaussiansplatting_amd import dist as gsdist
+    w, h, n = 640, 360, 60_000
+    aos = synth.generate(n, w, h, -4.2, seed=91, kind="hard")
+    sc = make_scene(aos, w, h)
+    r = make_renderer(sc, w, h)
+    full = r.draw(sc).copy()
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    assert_frame_equals_oracle(r, full, ref)
+    info = r.sceneInfo()
+    rows = gsdist.RowBalancer.row_elements(r.debugRead(gs.BUF_RANGES), info.tiles_x, info.tiles_y)
+    e_all, ids_all, tiles_all = ref["e"], ref["id"][:ref["e"]], ref["tile"][:ref["e"]]
+    assert rows.sum() == e_all and rows.max() > 3 * max(1, rows.min())                 # the rows are NOT equal work
+    bands = gsdist.balanced_row_partition(rows, world)
+    equal = gsdist.tile_row_partition(info.tiles_y, world)
+    worst = lambda bb: max(rows[b:e].sum() for b, e in bb)
+    assert bands != equal and worst(bands) < worst(equal)
+    total, canvas = 0, np.zeros_like(full)
+    for b, e in bands:
+        r.setTileRows(b, e)
+        img = r.draw(sc)
+        mine = (tiles_all // info.tiles_x >= b) & (tiles_all // info.tiles_x < e)
+        assert r.timings().num_sort_elements == int(mine.sum()) == int(rows[b:e].sum())
+        assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), ids_all[mine]) and np.array_equal(r.debugRead(gs.BUF_SORTED_TILE), tiles_all[mine])
+        total += int(mine.sum())
+        canvas[b * 16:min(e * 16, h)] = img[b * 16:min(e * 16, h)]
+    assert total == e_all and np.array_equal(canvas, full)
     r.cleanup()
 
 

@@ -5,8 +5,39 @@ the document can follow a profile refresh without retyping numbers.
 """
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 P = os.path.join(ROOT, "profiles", R + "_")
+
+
+def rank_costs():
+    """section 6, round 5: every rank of R = 2, 4, 8 -- slowest share (max / mean) per dealing; tools/rank_costs.py"""
+    import glob
+    print("\n## section 6: the slowest rank (tools/rank_costs.py)")
+    print("| cloud, sorter | one GPU | R | equal bands: slowest share (max / mean) → speed-up | interleaved | element-balanced | time-fed, rounds 1 / 2 / 3 | middle band, 1 → 3 frame slots |")
+    print("|---|---|---|---|---|---|---|---|")
+    for f in sorted(glob.glob(P + "rank_costs_*.txt")):
+        tag = os.path.basename(f)[len(R) + 12:-4]
+        one, rows, slots = None, {}, {}
+        for line in open(f):
+            m = re.match(r"config (\S+) pose \S+ (\d+x\d+) sorter (\S+): one GPU ([\d.]+) ms", line)
+            if m:
+                one = float(m.group(4)); head = f"{m.group(1)} @ {m.group(2)}, {m.group(3)}"
+            m = re.match(r"R=(\d) (contiguous|interleaved|balanced|feedback \d)\s*: max ([\d.]+) mean ([\d.]+) max/mean ([\d.]+) speed-up of the slowest rank ([\d.]+)x", line)
+            if m:
+                rows[(int(m.group(1)), m.group(2))] = (float(m.group(3)), float(m.group(5)), float(m.group(6)))
+            m = re.match(r"R=(\d) band \S+: one frame slot ([\d.]+) ms per frame, three frame slots ([\d.]+) ms", line)
+            if m:
+                slots[int(m.group(1))] = (float(m.group(2)), float(m.group(3)))
+        for R_ in (2, 4, 8):
+            c = lambda k: "{:.3f} ({:.2f}) → {:.2f}×".format(*rows[(R_, k)]) if (R_, k) in rows else "—"
+            fb = " / ".join(f"{rows[(R_, f'feedback {i}')][0]:.3f}" for i in (1, 2, 3) if (R_, f"feedback {i}") in rows)
+            sl = f"{slots[R_][0]:.3f} → {slots[R_][1]:.3f}" if R_ in slots else "—"
+            print(f"| {head if R_ == 2 else ''} | {one if R_ == 2 else ''} | {R_} | {c('contiguous')} | {c('interleaved')} | {c('balanced')} | {fb} | {sl} |")
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "ranks":
+    rank_costs()
+    sys.exit(0)
 
 
 def bench(name):

@@ -3,11 +3,13 @@
 // the reference's Renderer: init, initForScene / initForScenePly, the scene's benchmark camera, draw every frame, and the
 // running averages of the five GPU timing buckets (Renderer.cpp:477-510) printed at the end.
 //
-//   gsplat_bench <scene.ply | --synthetic N> [--scene garden|train|bicycle|origin] [--res WxH]
+//   gsplat_bench <scene.ply | --synthetic N [--skew]> [--scene garden|train|bicycle|origin] [--res WxH]
 //                [--warmup F] [--frames F] [--fast] [--sort radix4|splat_first|bucket|radix8|radix8_splat_first]
 //                [--present] [--out frame.png|frame.ppm]
 //                [--ranks R [--interleaved | --balanced [--rebalance K]] [--sync]]
 //
+// --skew: the synthetic cloud crowds towards the top of the frame (what a sky-less capture does to the upper tile rows), so
+// that equal bands are NOT equal work and --balanced has something to move.
 // --present: draw() copies every frame to the host (the windowless sink that stands in for the swapchain present); without
 // it drawDevice() leaves the frame in HBM, as the reference's frame stays in the swapchain image.
 // --ranks R: the multi-GPU frame of SURVEY 8(e) without any Python -- R processes, one per GPU (rank r on device r),
@@ -154,7 +156,7 @@ int main(int argc, char** argv) {
     std::string ply, scene = "origin", sort = "radix4";   // GPU_SORT_ALGORITHM (Renderer.h:33)
     Options o;
     uint32_t n_syn = 0;
-    bool fast = false, present = false;
+    bool fast = false, present = false, skew = false;
     int ranks = 1, rank = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -166,6 +168,7 @@ int main(int argc, char** argv) {
         else if ((a == "--out" || a == "--ppm") && i + 1 < argc) o.out = argv[++i];
         else if (a == "--fast") fast = true;
         else if (a == "--present") present = true;
+        else if (a == "--skew") skew = true;
         else if (a == "--sort" && i + 1 < argc) sort = argv[++i];
         else if (a == "--ranks" && i + 1 < argc) ranks = atoi(argv[++i]);
         else if (a == "--interleaved") o.dealing = GS_ROWS_INTERLEAVED;
@@ -232,7 +235,9 @@ int main(int argc, char** argv) {
         for (uint32_t i = 0; i < n_syn; ++i) {
             float* g = &rec[(size_t)i * 84];
             const float d = 0.5f + 19.5f * uni(s);
-            g[0] = d * aspect * (-1.5f + 3.0f * uni(s)); g[1] = d * (-1.5f + 3.0f * uni(s)); g[2] = d;
+            g[0] = d * aspect * (-1.5f + 3.0f * uni(s));
+            const float uy = uni(s);
+            g[1] = d * (skew ? 1.2f - 2.7f * uy * uy * uy : -1.5f + 3.0f * uy); g[2] = d;     // world +y is up: the upper rows of the frame
             for (int a = 0; a < 3; ++a) g[4 + a] = std::exp(-4.0f + 1.2f * (uni(s) - 0.5f));
             float q[4], l = 0; for (int a = 0; a < 4; ++a) { q[a] = uni(s) - 0.5f; l += q[a] * q[a]; }
             l = 1.0f / std::sqrt(l + 1e-12f); for (int a = 0; a < 4; ++a) g[8 + a] = q[a] * l;

@@ -79,6 +79,23 @@ for R in a.ranks:
         if label == "balanced":
             extra = " bands " + " ".join(f"{b}-{e}" for b, e in dist.balanced_row_partition(row_elems, R))
         report(R, label, res, extra)
+    # the middle band with three frame slots (three contexts on three streams, frames dealt round-robin): what frames in flight
+    # make of a share that is a chain of short launches
+    b_mid = dist.tile_row_partition(ty, R)[R // 2]
+    slots = []
+    for _ in range(3):
+        r = gs.Renderer(w, h, record_timings=0, warmup_frames=0, sort_algorithm=sort); r.init(rm); r.initForScene(sc, share_with=owner)
+        r.setTileRows(*b_mid)
+        slots.append(r)
+    for f in range(12): slots[f % 3].drawDevice(sc, None, sync=False)
+    for r in slots: r.synchronize()
+    t0 = time.perf_counter()
+    for f in range(3 * a.frames): slots[f % 3].drawDevice(sc, None, sync=False)
+    for r in slots: r.synchronize()
+    ms3 = 1e3 * (time.perf_counter() - t0) / (3 * a.frames)
+    for r in slots: r.cleanup()
+    ms1 = cost(lambda r: r.setTileRows(*b_mid))[0]
+    print(f"R={R} band {b_mid[0]}-{b_mid[1]}: one frame slot {ms1:.4f} ms per frame, three frame slots {ms3:.4f} ms per frame ({ms1 / ms3:.2f}x the throughput)", flush=True)
     # element-balanced bands corrected by the measured share times (dist.RowBalancer: weight(row) = elements x the rate of the
     # rank that rendered it), three rounds starting from the equal-rows split
     bal = dist.RowBalancer(ty, R, min_gain=0.0)

@@ -22,8 +22,6 @@ if [ "${1:-}" = "--install" ]; then
   cp $src/pmc_sq.txt profiles/${r}_pmc_sq_frame_configC.txt
   for c in C D; do cp $src/band_$c.txt profiles/${r}_band_cost_config$c.txt; cp $src/band_${c}_sf.txt profiles/${r}_band_cost_config${c}_splat_first.txt;
     [ -s $src/band_${c}_bucket.txt ] && cp $src/band_${c}_bucket.txt profiles/${r}_band_cost_config${c}_bucket.txt; done
-  [ -s $src/rehearse_2.json ] && tail -1 $src/rehearse_2.json > profiles/${r}_bench_rehearse_2ranks.json
-  [ -s $src/rehearse_4.json ] && tail -1 $src/rehearse_4.json > profiles/${r}_bench_rehearse_4ranks.json
   [ -s $src/readme_shapes.json ] && cp $src/readme_shapes.json profiles/${r}_readme_shapes.json
   s8=gpurun_out/refresh8
   if [ -d $s8 ]; then
@@ -89,10 +87,7 @@ for c in C D; do
   timeout -k 10 250 python tools/band_cost.py $c splat_first > $out/band_${c}_sf.txt 2>&1
   timeout -k 10 250 python tools/band_cost.py $c bucket > $out/band_${c}_bucket.txt 2>&1
 done
-# the N > 1 code path of bench.py on this one GPU (gloo gather on the host: timings mean nothing, the blocks of the line do)
-# (GS_RCCL_LIBRARY = tools/mock_rccl: the C-ABI gather phase runs too, over named pipes -- RCCL refuses ranks that share a device)
-make -C tools/mock_rccl > /dev/null
-for g in 2 4; do GS_RCCL_LIBRARY=$PWD/tools/mock_rccl/librccl.so.1 MOCK_RCCL_DIR=/tmp timeout -k 10 900 python bench.py --gpus $g --rehearse --steps 60 --warmup 10 > $out/rehearse_$g.json 2> $out/rehearse_$g.err || echo "FAIL rehearse $g"; done
+# (the N > 1 rehearsals of bench.py on this one GPU moved to tools/rehearse_r05.sh / rehearse_abort.sh / rehearse_hang.sh: tools/refresh_r05.sh)
 timeout -k 10 600 python tools/readme_shapes.py --frames 200 > $out/readme_shapes.json 2> $out/readme_shapes.err || echo "FAIL readme shapes"
 python - <<'PY'
 import json, glob
