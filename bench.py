@@ -177,8 +177,12 @@ class LineOut:
             fd_, self.path = tempfile.mkstemp(prefix="gs_bench_line_", suffix=".json", dir="/tmp")
             os.close(fd_)
             os.unlink(self.path)                          # nothing saved yet = no file
-            self.keeper = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--line-keeper", self.path],
-                                           stdin=subprocess.PIPE, stdout=self.fd, start_new_session=True)
+            try:
+                self.keeper = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--line-keeper", self.path],
+                                               stdin=subprocess.PIPE, stdout=self.fd, start_new_session=True)
+            except OSError as ex:                         # no keeper: print the line ourselves at the end, as a profiled run does
+                log(f"[bench] could not start the line keeper ({ex!r}): rank 0 will print its line itself")
+                self.path, self.direct = None, True
         self.last = None
 
     def save(self, line, stage, complete=False):

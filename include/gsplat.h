@@ -293,7 +293,9 @@ int gs_dist_destroy(gs_ctx* ctx);
  *                        the same vectors and derives the same new edges: weight(row) = elements(row) x (share time / share
  *                        elements of the rank that rendered it), edges at equal weight prefixes, moved only for a predicted
  *                        gain of 3 % on the slowest rank.  Waits for the frames in flight.  *moved_out (may be NULL) = 1
- *                        when the edges moved (the next frame re-captures its hipGraph).
+ *                        when the edges moved (the next frame re-captures its hipGraph).  With GS_REBALANCE_ELEMENTS_ONLY in the
+ *                        environment (of every rank) the share times are ignored and the bands are cut by element counts
+ *                        alone: for ranks whose times are not comparable, e.g. several ranks sharing one GPU.
  *   gs_dist_bands      : the R + 1 band edges (tile rows) of a contiguous or balanced dealing; count must be R + 1.
  * Collective safety: these calls pair with the other ranks' calls.  A rank that fails a PRECONDITION (no shard, rows changed
  * behind the library's back, a NULL rgba_out on rank 0, an allocation that failed in gs_dist_shard_rows) returns before the
