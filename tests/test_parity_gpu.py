@@ -1206,7 +1206,7 @@ def test_one_context_sweeping_element_balanced_bands(oracle_mod, world):
     info = r.sceneInfo()
     rows = gsdist.RowBalancer.row_elements(r.debugRead(gs.BUF_RANGES), info.tiles_x, info.tiles_y)
     e_all, ids_all, tiles_all = ref["e"], ref["id"][:ref["e"]], ref["tile"][:ref["e"]]
-    assert rows.sum() == e_all and rows.max() > 3 * max(1, rows.min())                 # the rows are NOT equal work
+    assert rows.sum() == e_all and rows.max() > 2 * max(1, rows.min())                 # the rows are NOT equal work
     bands = gsdist.balanced_row_partition(rows, world)
     equal = gsdist.tile_row_partition(info.tiles_y, world)
     worst = lambda bb: max(rows[b:e].sum() for b, e in bb)
