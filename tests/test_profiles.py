@@ -177,3 +177,19 @@ def test_rank_cost_tables_say_what_design_says():
             assert eq[1] > 1.15                                                             # the imbalance VERDICT r4 asked about
             assert rows[(R, "balanced")][0] < 0.95 * eq[0] and fed < 0.93 * eq[0] and fed < inter[0]
         assert one / min(rows[(8, f"feedback {i}")][0] for i in (2, 3)) > one / rows[(8, "contiguous")][0] * 1.08
+
+
+def test_pose_sweep_is_flat():
+    """tools/pose_sweep.sh: both clouds under the generator's own camera and the reference's three benchmark poses -- the frame time
+    does not depend on how the stored order lies relative to the screen."""
+    rows = {}
+    for ln in open(P + "pose_sweep.txt"):
+        m = re.match(r"config (\S+)\s+pose (\S+)\s*: frame ([\d.]+) ms\s+E (\d+)", ln)
+        if m:
+            rows[(m.group(1), m.group(2))] = (float(m.group(3)), int(m.group(4)))
+    assert len(rows) == 8
+    for cfg in ("C", "Chard"):
+        own_ms, own_e = rows[(cfg, "none")]
+        for pose in ("garden", "train", "bicycle"):
+            ms, e = rows[(cfg, pose)]
+            assert abs(ms / own_ms - 1.0) < 0.03 and abs(e / own_e - 1.0) < 1e-4, (cfg, pose)

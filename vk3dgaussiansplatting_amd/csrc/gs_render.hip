@@ -719,6 +719,29 @@ __global__ __launch_bounds__(1024) void k_tile_scatter(const uint32_t* __restric
     if (c < tiles) order[s_base[v & 63u] + (v >> 6)] = c;
 }
 
+// At most 1024 owned tiles (a 1/8 band of a 1920 x 1080 frame, BASELINE config A): one workgroup holds every count, so both
+// steps are one launch -- the same classes, slots and class bases as the two kernels above (wgs = 1: nothing before us).
+__global__ __launch_bounds__(1024) void k_tile_order_small(const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order,
+                                                            uint32_t tiles, TileMap map) {
+    __shared__ uint32_t s_count[33], s_base[33];
+    if (threadIdx.x < 33) s_count[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t c = threadIdx.x;
+    const bool active = c < tiles;                                       // whole waves vote in class_slot
+    const uint2 r = active ? reinterpret_cast<const uint2*>(ranges)[global_tile(map, c)] : make_uint2(0u, 0u);
+    const uint32_t len = r.y > r.x ? r.y - r.x : 0u;
+    const uint32_t cls = len ? 32u - (uint32_t)__builtin_clz(len) : 0u;
+    const uint32_t slot = class_slot(cls, active, s_count);
+    __syncthreads();
+    if (threadIdx.x < 64) {                                              // longest class first, as k_tile_scatter
+        const uint32_t n = threadIdx.x < 33 ? s_count[32 - threadIdx.x] : 0u;
+        const uint32_t start = wave_inclusive_scan(n) - n;
+        if (threadIdx.x < 33) s_base[32 - threadIdx.x] = start;
+    }
+    __syncthreads();
+    if (active) order[s_base[cls] + slot] = c;
+}
+
 void launch_tile_order(const FrameParams& fp, const uint32_t* ranges, uint32_t* order, hipStream_t stream) {
     const uint32_t tiles = fp.rows_owned * fp.grid_w;
     if (tiles == 0) return;
@@ -728,6 +751,10 @@ void launch_tile_order(const FrameParams& fp, const uint32_t* ranges, uint32_t* 
     uint32_t* scratch = order + all;
     uint32_t* wg_count = order + 2 * all;
     const uint32_t wgs = (tiles + kOrderTiles - 1u) / kOrderTiles;
+    if (wgs == 1u) {
+        hipLaunchKernelGGL(k_tile_order_small, dim3(1), dim3(1024), 0, stream, ranges, order, tiles, map);
+        return;
+    }
     hipLaunchKernelGGL(k_tile_classes, dim3(wgs), dim3(1024), 0, stream, ranges, scratch, wg_count, tiles, map);
     hipLaunchKernelGGL(k_tile_scatter, dim3(wgs), dim3(1024), 0, stream, scratch, wg_count, order, tiles);
 }
