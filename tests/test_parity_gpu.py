@@ -941,6 +941,11 @@ def test_cpp_host_several_ranks_over_a_mock_rccl(tmp_path, ranks, rows):
             assert moves >= 1 and bands[0][1] - bands[0][0] < -(-23 // ranks), (line, moves)
     if "sync" not in rows:
         assert "two frames in flight" in p.stdout and "copied to the host every frame" in p.stdout
+    else:
+        # the synchronous form has timings: every rank reports the GPU time of its own rows over the pipes, rank 0 prints them all
+        share = [l for l in p.stdout.splitlines() if l.startswith("per-rank share")][0]
+        vals = [float(x) for x in share.split(":")[1].split("slowest")[0].split()]
+        assert len(vals) == ranks and all(v > 0.0 for v in vals), share
 
 
 def test_cpp_host_leaves_when_a_rank_cannot_come_up(tmp_path):

@@ -119,6 +119,19 @@ static int run_rank(gsplat::Renderer& r, Channel& ch, const Options& o, const fl
             if (f >= o.warmup) ms += ms_since(t0);
         }
         if (root) printf("ranks: %d (%s tile rows)   frame + gather + copy to host ms (host clock, rank 0): %.3f\n", ch.ranks, how, ms / std::max(1u, o.frames));
+        // every rank's own share (gsplat::Renderer::averages(): the GPU time of ITS rows, no exchange): a sharded frame ends with its
+        // slowest rank, so rank 0 prints them all
+        double mine = r.averages()[4];
+        if (root) {
+            std::vector<double> share(1, mine);
+            for (int fd : ch.up) { double v = 0.0; if (!read_all(fd, &v, sizeof(v))) v = -1.0; share.push_back(v); }
+            double worst = 0.0, sum = 0.0;
+            printf("per-rank share, total gpu time ms:");
+            for (double v : share) { printf(" %.3f", v); worst = std::max(worst, v); sum += v; }
+            printf("   slowest / mean: %.3f\n", sum > 0.0 ? worst / (sum / (double)share.size()) : 0.0);
+        } else if (!write_all(ch.up[0], &mine, sizeof(mine))) {
+            fprintf(stderr, "[Log Error]: rank %d: cannot report its share time\n", ch.rank);
+        }
     } else {
         // two frames in flight; pass 0: the frame stays in HBM, pass 1: the frame before is copied to the host every frame
         double ms[2] = {0.0, 0.0};
