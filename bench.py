@@ -1395,6 +1395,37 @@ def main():
             line.save(out, "cpu_baseline")
     else:
         out = None
+    def x_share_ceiling():
+        # what N GPUs could make of this frame before the gather, measured HERE: every rank's share of an R-way tile-row shard is
+        # rendered on this GPU (the rows rank r would own, equal bands, one frame slot, frames back to back); a sharded frame ends
+        # with its slowest rank, so ms_per_step / slowest share is the ceiling of the strong-scaling series --gpus 1, 2, 4, 8
+        # (tools/rank_costs.py is the long form: other dealings, other clouds)
+        res = {}
+        ty = (h + 15) // 16
+        frames_ = max(20, min(args.steps, 100))
+        for R_ in (2, 4, 8):
+            times = []
+            for rb, re_ in gsdist.tile_row_partition(ty, R_):
+                rk = make(0, share=owner)
+                rk.setTileRows(rb, re_)
+                rk.setStream(torch.cuda.current_stream().cuda_stream)
+                for _ in range(5):
+                    rk.drawDevice(scene, None, sync=False)
+                torch.cuda.synchronize()
+                t_b = time.perf_counter()
+                for _ in range(frames_):
+                    rk.drawDevice(scene, None, sync=False)
+                torch.cuda.synchronize()
+                times.append((time.perf_counter() - t_b) / frames_ * 1e3)
+                rk.setStream(None)
+                rk.cleanup()
+            res[str(R_)] = {"slowest_share_ms": round(max(times), 4), "mean_share_ms": round(sum(times) / R_, 4),
+                            "slowest_over_mean": round(max(times) / (sum(times) / R_), 3),
+                            "speedup_ceiling": round(ms_per_step / max(times), 3)}
+        res["note"] = ("every rank's share of an R-way tile-row shard of this frame (equal contiguous bands), rendered on this one GPU, one "
+                       "frame slot, no gather: ms_per_step / slowest share = the ceiling of the --gpus R line before the exchange")
+        return res
+
     if world > 1:
         tdist.barrier()              # no rank goes on into the optional blocks before rank 0 has saved the headline
 
@@ -1418,6 +1449,7 @@ def main():
             extra("hbm_resident", x_hbm_resident)
         if args.config == "C":
             extra("sharded_workload_on_one_gpu", x_sharded_workload_on_one_gpu)
+        extra("share_ceiling_on_one_gpu", x_share_ceiling)
 
     # ---- the guarded phases of a run with several ranks: after the line is assembled and under a watchdog, so that a
     #      collective that hangs inside one of them costs the run these blocks, not its line

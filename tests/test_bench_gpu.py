@@ -42,6 +42,11 @@ def test_one_gpu_line_config_a():
     for extra in ("frames_in_flight_3", "alt_sorter", "radix8_splat_first_sorter", "fast_render_mode"):
         assert "error" not in d[extra], (extra, d[extra])
     assert "ranks_exit" not in d and "line_note" not in d
+    # what R GPUs could make of this frame before the gather, measured here from every rank's share
+    sc = d["share_ceiling_on_one_gpu"]
+    for r in ("2", "4", "8"):
+        assert sc[r]["slowest_share_ms"] >= sc[r]["mean_share_ms"] > 0 and sc[r]["speedup_ceiling"] == pytest.approx(d["ms_per_step"] / sc[r]["slowest_share_ms"], rel=2e-3)
+    assert sc["2"]["speedup_ceiling"] > 1.0
 
 
 def test_one_gpu_line_under_the_garden_pose():
