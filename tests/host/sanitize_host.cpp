@@ -1,4 +1,4 @@
-// Host-side code of the library (PLY reader + ResourceManager conversions, frame sinks) built with
+// Host-side code of the library (PLY reader + ResourceManager conversions, frame sinks, the band-cutting rule) built with
 // -fsanitize=address,undefined and fed valid, truncated and corrupted inputs.  GPU sanitizers are not
 // available on the pool, so this is where the parsers get their memory checking.  The device upload is
 // replaced by a counter: nothing here touches HIP.
@@ -7,8 +7,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <fstream>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -99,6 +101,38 @@ int main(int argc, char** argv) {
     if (gs_write_image((dir + "/big.png").c_str(), img.data(), 1, 77 * 333) != GS_OK) return 1;
     if (gs_write_image((dir + "/f.bmp").c_str(), img.data(), 333, 77) != GS_ERR_INVALID) return 1;
     if (gs_write_image(nullptr, img.data(), 1, 1) != GS_ERR_INVALID) return 1;
+    // the band-cutting rule of a sharded frame (gs_balance.cpp: gs_dist_shard_rows / gs_dist_rebalance / gs_balance_rows): random,
+    // degenerate and hostile weight vectors -- the edges must always be a partition of the rows, whatever the weights are
+    {
+        uint64_t s = 12345;
+        auto rnd = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(s >> 33); };
+        int cuts = 0;
+        for (int t = 0; t < 20000; ++t) {
+            const uint32_t ty = rnd() % 300u, world = 1u + rnd() % 70u;
+            std::vector<double> w(ty);
+            for (double& x : w) {
+                switch (t % 6) {
+                    case 0: x = (double)(rnd() % 500000u); break;
+                    case 1: x = 0.0; break;
+                    case 2: x = (rnd() % 10u) ? 1.0 : 1e300; break;                                  // the sum overflows to infinity
+                    case 3: x = (rnd() % 7u) ? (double)(rnd() % 100u) : std::numeric_limits<double>::quiet_NaN(); break;
+                    case 4: x = -(double)(rnd() % 100u); break;                                     // negative weights: treated as equal rows
+                    default: x = 1e-300 * (double)(rnd() % 3u); break;
+                }
+            }
+            std::vector<uint32_t> e(world + 1u, 0xDEADBEEFu);
+            if (gs_balance_rows(ty ? w.data() : nullptr, ty, world, e.data()) != GS_OK) { std::printf("gs_balance_rows failed\n"); return 1; }
+            if (e[0] != 0u || e[world] != ty) { std::printf("edges do not span the rows (ty %u world %u)\n", ty, world); return 1; }
+            for (uint32_t r = 0; r < world; ++r) {
+                if (e[r] > e[r + 1u]) { std::printf("edges not monotone\n"); return 1; }
+                if (ty >= world && e[r] == e[r + 1u]) { std::printf("a rank idles although there are rows to give (ty %u world %u)\n", ty, world); return 1; }
+            }
+            ++cuts;
+        }
+        uint32_t e2[3];
+        if (gs_balance_rows(nullptr, 4, 2, e2) != GS_ERR_INVALID || gs_balance_rows(nullptr, 0, 0, e2) != GS_ERR_INVALID) return 1;
+        std::printf("%d band cuts checked\n", cuts);
+    }
     std::printf("sanitize_host ok: %d malformed inputs survived\n", checked);
     return 0;
 }

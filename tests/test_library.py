@@ -399,14 +399,16 @@ def _build_and_run(tmp_path, name, compiler, flags, sources, args=()):
 
 
 def test_host_parsers_and_sinks_under_sanitizers(tmp_path):
-    """gs_ply.cpp + gs_image.cpp with -fsanitize=address,undefined on valid, truncated and corrupted inputs
-    (GPU sanitizers are not available on the pool: the host code is where memory checking is possible)."""
+    """gs_ply.cpp + gs_image.cpp + gs_balance.cpp (the band-cutting rule of a sharded frame) with -fsanitize=address,undefined on
+    valid, truncated, corrupted and hostile inputs (GPU sanitizers are not available on the pool: the host code is where memory
+    checking is possible)."""
     csrc = os.path.join(ROOT, "vk3dgaussiansplatting_amd", "csrc")
     out = _build_and_run(tmp_path, "san_host", "g++",
                          ["-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"],
                          [os.path.join(ROOT, "tests", "host", "sanitize_host.cpp"),
-                          os.path.join(csrc, "gs_ply.cpp"), os.path.join(csrc, "gs_image.cpp")], [str(tmp_path)])
-    assert "sanitize_host ok" in out
+                          os.path.join(csrc, "gs_ply.cpp"), os.path.join(csrc, "gs_image.cpp"), os.path.join(csrc, "gs_balance.cpp")],
+                         [str(tmp_path)])
+    assert "sanitize_host ok" in out and "band cuts checked" in out
 
 
 @pytest.mark.parametrize("san", ["address,undefined", "thread"])

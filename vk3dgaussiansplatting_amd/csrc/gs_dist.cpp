@@ -21,6 +21,7 @@
 // stable since NCCL 2.7: an opaque communicator pointer, a 128-byte id passed by value, int enums), so the library
 // builds on a ROCm install without the RCCL development headers.
 #include "gs_ctx.h"
+#include "gs_balance.h"
 
 #include <dlfcn.h>
 
@@ -96,40 +97,6 @@ int fail(gs_ctx* c, int code, const std::string& msg) {
         const hipError_t e_ = (call);                                                                  \
         if (e_ != hipSuccess) return fail((c), GS_ERR_HIP, std::string(#call ": ") + hipGetErrorString(e_)); \
     } while (0)
-
-// Contiguous bands whose weights are as equal as whole rows allow -- vk3dgaussiansplatting_amd/dist.py:
-// balanced_row_partition, statement for statement (the two are compared in the tests): edge r sits at the row boundary
-// whose weight prefix is nearest to r / R of the total; every rank keeps at least one row while there are rows to give.
-std::vector<uint32_t> balanced_edges(const std::vector<double>& weights_in, uint32_t world) {
-    const uint32_t ty = (uint32_t)weights_in.size();
-    std::vector<uint32_t> edges(world + 1u, 0u);
-    if (ty == 0u) return edges;
-    std::vector<double> w = weights_in;
-    double total = 0.0;
-    bool finite = true;
-    for (double x : w) { total += x; finite = finite && std::isfinite(x); }
-    if (!finite || total <= 0.0) w.assign(ty, 1.0);
-    std::vector<double> prefix(ty + 1u, 0.0);
-    for (uint32_t k = 0; k < ty; ++k) prefix[k + 1u] = prefix[k] + w[k];
-    for (uint32_t r = 1; r < world; ++r) {
-        const double target = prefix[ty] * (double)r / (double)world;
-        uint32_t k = (uint32_t)(std::lower_bound(prefix.begin(), prefix.end(), target) - prefix.begin());   // first prefix >= target
-        if (k > 0u && target - prefix[k - 1u] <= prefix[std::min(k, ty)] - target) --k;
-        const uint32_t lo = std::min(edges[r - 1u] + 1u, ty);
-        const uint32_t left = world - r;                                  // ranks still to come
-        const uint32_t hi = std::max(lo, ty > left ? ty - left : 0u);
-        edges[r] = std::min(std::max(k, lo), hi);
-    }
-    edges[world] = ty;
-    return edges;
-}
-
-std::vector<uint32_t> equal_row_edges(uint32_t ty, uint32_t world) {       // dist.tile_row_partition: ceil(Ty / R) rows each
-    const uint32_t per = (ty + world - 1u) / world;
-    std::vector<uint32_t> e(world + 1u);
-    for (uint32_t r = 0; r <= world; ++r) e[r] = std::min(r * per, ty);
-    return e;
-}
 
 size_t band_bytes(const gs_ctx* c, uint32_t rb, uint32_t re) {            // the pixel rows of tile rows [rb, re) that exist
     const uint32_t y0 = std::min(rb * 16u, c->height), y1 = std::min(re * 16u, c->height);
@@ -311,7 +278,7 @@ int gs_dist_shard_rows(gs_ctx* c, uint32_t dealing) {
         if (rc == GS_OK) remember_rows(c);
     } else {
         // GS_ROWS_BALANCED starts from equal row counts too (no frame has been seen yet); gs_dist_rebalance moves the edges
-        c->dist_edges = dealing == GS_ROWS_BALANCED ? balanced_edges(std::vector<double>(c->grid_h, 1.0), R) : equal_row_edges(c->grid_h, R);
+        c->dist_edges = dealing == GS_ROWS_BALANCED ? gs::balanced_edges(std::vector<double>(c->grid_h, 1.0), R) : gs::equal_row_edges(c->grid_h, R);
         rc = apply_band(c);
     }
     if (rc != GS_OK) return rc;
@@ -337,13 +304,6 @@ int gs_dist_shard_rows(gs_ctx* c, uint32_t dealing) {
     if (e == hipSuccess && dealing == GS_ROWS_BALANCED) e = hipMalloc(&c->dist_xchg, (size_t)R * (c->grid_h + 1u) * sizeof(uint32_t));
     if (e != hipSuccess) { gsi_dist_free_buffers(c); return fail(c, GS_ERR_HIP, std::string("gs_dist_shard_rows: ") + hipGetErrorString(e)); }
     c->dist_sharded = true;
-    return GS_OK;
-}
-
-int gs_balance_rows(const double* row_weights, uint32_t tiles_y, uint32_t world, uint32_t* edges_out) {
-    if (!edges_out || world == 0u || (tiles_y && !row_weights)) return GS_ERR_INVALID;
-    const std::vector<uint32_t> e = balanced_edges(std::vector<double>(row_weights, row_weights + tiles_y), world);
-    for (uint32_t k = 0; k <= world; ++k) edges_out[k] = e[k];
     return GS_OK;
 }
 
@@ -517,7 +477,7 @@ int gs_dist_rebalance(gs_ctx* c, uint32_t* moved_out) {
         }
         return fixed + worst;
     };
-    const std::vector<uint32_t> next = balanced_edges(weights, R);
+    const std::vector<uint32_t> next = gs::balanced_edges(weights, R);
     // hysteresis: the bands (and the hipGraphs captured for them) move only for a predicted gain of 3 % on the slowest rank
     if (next == c->dist_edges || !(cost(next) <= (1.0 - 0.03) * cost(c->dist_edges))) return GS_OK;
     c->dist_edges = next;
