@@ -5,7 +5,8 @@ A "step" is one frame (InitSortList -> 4-bit radix sort -> FindRanges -> RenderG
 cloud at a reference README shape, inputs resident in HBM, image left in HBM (the reference writes into the swapchain
 image; it never copies a frame to the host).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config A|B|C|D|E] [--mode exact|fast]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config A|B|C|D|E|Chard] [--mode exact|fast]
+                  [--pose garden|train|bicycle] [--rows contiguous|interleaved|balanced] [--sort ...]
 
 What `value` is: N_gaussians / ms_per_step with ONE frame slot -- frames run back to back on one HIP stream, nothing
 of frame f+1 overlaps frame f -- i.e. the GPU time of a frame, which is what the reference's "Total GPU time"
@@ -16,8 +17,14 @@ and the wall clock of a frame with a host wait per frame (Renderer.cpp:459) are 
 already runs inside such a launch (WORLD_SIZE set); the frame is sharded by screen-tile rows and the RGBA8 strips are
 gathered to rank 0 every step (strong scaling: the frame is fixed -- the same config C at every N, so that the lines of
 --gpus 1, 2, 4, 8 form one series).  The 4K frame BASELINE.json names for the tile-row shard (config D: the same cloud at
-3840x2160) rides along: `sharded_4k` in the N > 1 lines, `sharded_workload_on_one_gpu` in the one-GPU line.  Rank 0
-prints ONE JSON line.
+3840x2160) rides along: `sharded_4k` in the N > 1 lines, `sharded_workload_on_one_gpu` in the one-GPU line; so do the
+capture-like cloud with equal and with balanced bands (`sharded_hard_cloud`), three frame slots per rank (`frames_in_flight_3`),
+the opt-in sorters and the library's own exchange (`c_abi_gather`).  The one-GPU line carries the same frame under the reference's
+Garden benchmark camera (`benchmark_pose`) and what R = 2, 4, 8 GPUs could make of it (`share_ceiling_on_one_gpu`).
+
+ONE JSON line comes out, from rank 0 -- and it survives what runs behind the headline: rank 0 saves the line after the timed
+region and after every later block, and a process that never touches a GPU prints the last saved state once (LineOut / supervise
+/ line_keeper below).
 """
 import argparse
 import json
