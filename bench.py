@@ -163,6 +163,11 @@ def line_keeper(path):
     return 0 if printed and complete else EXIT_INCOMPLETE
 
 
+def _plain(o):
+    """json default: numpy scalars (a block that forgot to convert one must not cost the line) and anything else as text"""
+    return o.item() if hasattr(o, "item") else str(o)
+
+
 class LineOut:
     """Rank 0's side of the protocol above."""
 
@@ -199,7 +204,7 @@ class LineOut:
         if self.path is not None:
             tmp = self.path + ".tmp"
             with open(tmp, "w") as f:
-                json.dump({"complete": complete, "stage": stage, "line": line}, f)
+                json.dump({"complete": complete, "stage": stage, "line": line}, f, default=_plain)
                 f.flush()
                 os.fsync(f.fileno())
             os.replace(tmp, self.path)
@@ -210,7 +215,7 @@ class LineOut:
             return
         self.save(line, stage, complete=True)
         if self.direct:
-            os.write(self.fd, (json.dumps(line) + "\n").encode())
+            os.write(self.fd, (json.dumps(line, default=_plain) + "\n").encode())
         elif self.keeper is not None:
             self.keeper.stdin.close()                     # end-of-file: the keeper prints the state just saved
             try:
