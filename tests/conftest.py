@@ -98,3 +98,43 @@ def extreme_cloud(n=4000, k=500, w=200, h=120, seed=2024):
     aos[::11, 8:12] = 0.0                                                             # zero quaternion
     aos[::13, 4:7] = 0.0                                                              # zero scale
     return aos
+
+
+# ---- collection order of the -m gpu suite -------------------------------------------------------------------------
+# The driver runs `pytest tests/ -x -q -m gpu`: the first red test ends the run.  The parity evidence therefore comes
+# first -- the golden fixture, BASELINE configs A-E against the oracle, the reference-shader-text dumps, the radix sort
+# against a stable sort -- then the rest of test_parity_gpu.py, then everything that starts other processes (C++ host,
+# mock RCCL, fresh interpreters), then the 150 M-key stress, and the bench.py harness tests last of all.  A red harness
+# test can then cost the harness tests behind it and nothing else.
+_PARITY_FIRST = ("test_golden_fixture", "test_config_a_", "test_config_b_", "test_config_c_", "test_config_d_", "test_config_e_",
+                 "test_shader_main_bodies_cross_check", "test_common_glsl_cross_check", "test_radix_sort_",
+                 "test_init_sort_list_stage", "test_frame_matches_oracle")
+_SUBPROCESS_TESTS = ("test_cpp_driver_runs", "test_cpp_host_", "test_library_before_torch_in_a_fresh_process",
+                     "test_rccl_calls_of_the_sharded_frame_single_rank", "test_c_abi_sharded_frame_single_rank")
+_STRESS_TESTS = ("test_sort_stress_sortedness",)
+
+
+def _gpu_rank(item):
+    fname = os.path.basename(str(item.fspath))
+    name = item.name
+    if fname == "test_bench_gpu.py":
+        return 9
+    if fname != "test_parity_gpu.py":
+        return 5
+    if name.startswith(_STRESS_TESTS):
+        return 7
+    if name.startswith(_SUBPROCESS_TESTS):
+        return 6
+    if name.startswith(_PARITY_FIRST):
+        return 0
+    return 1
+
+
+def pytest_collection_modifyitems(config, items):
+    """Stable re-ordering of the GPU tests only (see above); the CPU tests keep pytest's order."""
+    gpu = [i for i, it in enumerate(items) if it.get_closest_marker("gpu") is not None]
+    if not gpu:
+        return
+    ordered = sorted((items[i] for i in gpu), key=_gpu_rank)         # sorted() is stable
+    for slot, it in zip(gpu, ordered):
+        items[slot] = it
