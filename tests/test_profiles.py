@@ -193,3 +193,18 @@ def test_pose_sweep_is_flat():
         for pose in ("garden", "train", "bicycle"):
             ms, e = rows[(cfg, pose)]
             assert abs(ms / own_ms - 1.0) < 0.03 and abs(e / own_e - 1.0) < 1e-4, (cfg, pose)
+
+
+def test_gpu_suite_log_is_of_this_tree():
+    """profiles/r06_gpu_tests.log is the driver's exact GPU command (`pytest tests/ -x -q -m gpu`) run on a fresh MI355X box by
+    tools/gpu_suite.sh.  It must be green, complete, and of THESE sources: a change to the library, its headers or the host code the
+    tests drive it through after the run makes this test fail until the suite has run again."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import src_hash
+    text = open(os.path.join(ROOT, "profiles", "r06_gpu_tests.log")).read()
+    m = re.search(r"src_sha256=([0-9a-f]{64})", text)
+    assert m, "the log carries no source hash"
+    assert m.group(1) == src_hash.source_hash(), "sources changed after the GPU suite ran: run tools/gpu_suite.sh again"
+    tail = re.search(r"(\d+) passed, (\d+) deselected", text)
+    assert tail and int(tail.group(1)) >= 191 and " failed" not in text and " error" not in text.lower().replace("errors='", "")
