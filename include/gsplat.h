@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GS_API_VERSION 4   /* 2: gs_config grew tile_order; 3: gs_config starts with struct_size, gs_api_version(),
+#define GS_API_VERSION 5   /* 5: gs_config grew count_launches (GS_COUNT_*).  2: gs_config grew tile_order; 3: gs_config starts with struct_size, gs_api_version(),
                               gs_runtime_versions(), gs_dist_* / gs_gather_strips; 4: GS_ROWS_BALANCED + gs_dist_rebalance /
                               gs_dist_bands, gs_render_sharded_async / gs_sharded_frame / gs_sharded_read (two sharded
                               frames in flight, the assembled frame left in HBM), GS_BUF_COLOR for every non-culled splat */
@@ -83,6 +83,14 @@ typedef struct gs_ctx gs_ctx;
 #define GS_TILE_ORDER_LONGEST_FIRST 0u /* by list length, longest first: one small launch behind FindRanges (default) */
 #define GS_TILE_ORDER_RASTER 1u        /* row-major, like the reference's dispatch (Subrenderer.cpp:330-333) */
 
+/* The Count stage of the 4-bit radix sort (GS_SORT_RADIX4; RadixSortCount.comp:40-91): one launch per pass, or one launch per
+ * SORT with every Scatter launch counting the next pass's digits of the keys it stores ("fed" counts: for short lists -- a
+ * tile-row band of a multi-GPU frame, a small frame -- where a pass is two fixed launch latencies and little else).  Same
+ * sorted list either way. */
+#define GS_COUNT_AUTO 0u      /* fed when a recent frame held at most 896 groups of 2048 elements = 1.8 M (default) */
+#define GS_COUNT_PER_PASS 1u  /* always a Count launch per pass */
+#define GS_COUNT_FED 2u       /* always fed (correct at every size; slow for long lists) */
+
 typedef struct gs_config {
     uint32_t struct_size;     /* sizeof(gs_config) as the CALLER's header declares it (gs_default_config fills it in).
                                  gs_create copies that many bytes and keeps its defaults for fields the caller's
@@ -101,6 +109,7 @@ typedef struct gs_config {
                                  2 = additionally one event pair around every Scatter launch (roofline measurement) */
     uint32_t render_kernel;   /* GS_RENDER_KERNEL_*: how a tile maps to waves in RenderGaussians; same pixels either way */
     uint32_t tile_order;      /* GS_TILE_ORDER_* */
+    uint32_t count_launches;  /* GS_COUNT_*: GS_SORT_RADIX4 frames and the stand-alone 4-bit sorter; ignored by the other sorters */
 } gs_config;
 
 /* The five buckets of Renderer.cpp:471-475 (ms) + the sort element count ("Elements To Sort"

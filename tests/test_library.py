@@ -40,12 +40,18 @@ def test_config_struct_size_is_checked():
     L = _lib.lib()
     cfg = _lib.GsConfig()
     L.gs_default_config(C.byref(cfg))
-    assert cfg.struct_size == C.sizeof(_lib.GsConfig) == 52
+    assert cfg.struct_size == C.sizeof(_lib.GsConfig) == 56 and cfg.count_launches == _lib.GS_COUNT_AUTO
     h = C.c_void_p()
-    for bad in (0, 4, C.sizeof(_lib.GsConfig) - 4, C.sizeof(_lib.GsConfig) + 4, 1 << 20):
+    for bad in (0, 4, 48, C.sizeof(_lib.GsConfig) + 4, 1 << 20):
         cfg.struct_size = bad
         assert L.gs_create(C.byref(cfg), C.byref(h)) == _lib.GS_ERR_INVALID and not h.value
         assert b"struct_size" in L.gs_last_error(None)
+    # a caller built against the version-4 header (52 bytes, no count_launches) is still served: the field keeps its default
+    cfg.struct_size = 52
+    rc = L.gs_create(C.byref(cfg), C.byref(h))
+    assert b"struct_size" not in L.gs_last_error(None) and rc in (_lib.GS_OK, _lib.GS_ERR_NO_DEVICE)
+    if h.value:
+        L.gs_destroy(h)
     info = _lib.runtime_info()
     assert info["hip_build"] >= 70000000
 

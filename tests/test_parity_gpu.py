@@ -35,8 +35,9 @@ ALL_SORTS = (gs.GS_SORT_RADIX4, gs.GS_SORT_TILE_BUCKET, gs.GS_SORT_RADIX4_SPLAT_
 
 
 def make_renderer(sc, w, h, mode=gs.GS_RENDER_EXACT, sort=gs.GS_SORT_RADIX4, kernel=gs.GS_RENDER_KERNEL_AUTO,
-                  order=gs.GS_TILE_ORDER_LONGEST_FIRST):
-    r = gs.Renderer(w, h, render_mode=mode, warmup_frames=0, sort_algorithm=sort, render_kernel=kernel, tile_order=order)
+                  order=gs.GS_TILE_ORDER_LONGEST_FIRST, count=gs.GS_COUNT_AUTO):
+    r = gs.Renderer(w, h, render_mode=mode, warmup_frames=0, sort_algorithm=sort, render_kernel=kernel, tile_order=order,
+                    count_launches=count)
     r.init(sc.getResourceManager())
     r.initForScene(sc)
     return r
@@ -495,13 +496,22 @@ def test_tile_row_bands_reproduce_full_frame(oracle_mod, small_cloud):
     r.cleanup()
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 4095, 4096, 4097, 100_003, 1_500_000])
+def _radix4_per_pass():
+    return gs.RadixSort(count_launches=gs.GS_COUNT_PER_PASS)
+
+
+def _radix4_fed():
+    return gs.RadixSort(count_launches=gs.GS_COUNT_FED)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097, 100_003, 1_500_000, 3_000_001])
 @pytest.mark.parametrize("bits", [44, 48])
-@pytest.mark.parametrize("sorter", [gs.RadixSort, gs.RadixSort8])
+@pytest.mark.parametrize("sorter", [_radix4_per_pass, _radix4_fed, gs.RadixSort8], ids=["radix4", "radix4_fed", "radix8"])
 def test_radix_sort_matches_stable_sort(n, bits, sorter):
-    """GpuSort seam on caller arrays: ragged sizes around the 64-lane and 4096-key tile edges,
+    """GpuSort seam on caller arrays: ragged sizes around the 64-lane and 2048- / 4096-key group edges,
     heavy ties (payload order must be preserved).  Tile words carry bits above the sorted ones when bits < 48 is
-    paired with a wider draw (the 8-bit variant's last pass must mask them)."""
+    paired with a wider draw (the 8-bit variant's last pass must mask them).  radix4_fed: one Count launch per sort, every
+    Scatter feeds the next pass's counts (GS_COUNT_FED) -- also beyond the list length GS_COUNT_AUTO would choose it for."""
     rng = np.random.default_rng(n * 131 + bits)
     tile = rng.integers(0, 1 << (bits - 32), n, dtype=np.uint32)
     depth = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
@@ -557,8 +567,9 @@ def test_radix_sort_ignores_bits_above_num_sort_bits(sorter, bits):
     rs.cleanup()
 
 
-def test_radix_sort_all_equal_and_presorted():
-    rs = gs.RadixSort()
+@pytest.mark.parametrize("count", [gs.GS_COUNT_PER_PASS, gs.GS_COUNT_FED, gs.GS_COUNT_AUTO])
+def test_radix_sort_all_equal_and_presorted(count):
+    rs = gs.RadixSort(count_launches=count)
     n = 50_000
     rs.initForScene(n, 8160)
     z = np.zeros(n, np.uint32)
@@ -569,6 +580,60 @@ def test_radix_sort_all_equal_and_presorted():
     t, d, i = rs.computeSort(tile, z, ident[::-1].copy())
     assert np.array_equal(t, tile) and np.array_equal(i[:5], ident[::-1][:5])
     rs.cleanup()
+
+
+@pytest.mark.parametrize("count", [gs.GS_COUNT_PER_PASS, gs.GS_COUNT_FED])
+def test_radix_sort_digit_runs_of_every_length(count):
+    """Fed counts key a stored element by (digit run, destination group): runs of one element, runs that fill a whole group,
+    runs that end exactly on a group edge, digits that never occur, and a descending list (every run crosses into the next
+    group)."""
+    rng = np.random.default_rng(5)
+    n = 300_000
+    ident = np.arange(n, dtype=np.uint32)
+    cases = {
+        "descending": (np.zeros(n, np.uint32), (np.uint32(n) - ident).astype(np.uint32)),
+        "two_digits": (np.zeros(n, np.uint32), rng.choice(np.array([0x00000003, 0xF000000C], np.uint32), n)),
+        "one_rare_key": (np.zeros(n, np.uint32), np.where(ident == 123_457, np.uint32(7), np.uint32(0xFFFFFFF0)).astype(np.uint32)),
+        "group_sized_runs": (np.zeros(n, np.uint32), ((ident // 2048) % 16).astype(np.uint32) * np.uint32(0x11111111)),
+        "tiles_only": (rng.integers(0, 4096, n).astype(np.uint32), np.zeros(n, np.uint32)),
+    }
+    rs = gs.RadixSort(count_launches=count)
+    rs.initForScene(n, 4096)
+    for name, (tile, depth) in cases.items():
+        t, d, i = rs.computeSort(tile, depth, ident)
+        key = (tile.astype(np.uint64) << np.uint64(32)) | depth.astype(np.uint64)
+        order = np.argsort(key, kind="stable")
+        assert np.array_equal(i, ident[order]), name
+        assert np.array_equal(t, tile[order]) and np.array_equal(d, depth[order]), name
+    rs.cleanup()
+
+
+@pytest.mark.parametrize("count", [gs.GS_COUNT_PER_PASS, gs.GS_COUNT_FED, gs.GS_COUNT_AUTO])
+def test_config_a_count_launches(oracle_mod, count):
+    """gs_config.count_launches on BASELINE config A (108 groups): a Count launch per pass, fed counts, and GS_COUNT_AUTO,
+    which sorts the first frame with a Count per pass and, knowing its length, the following ones fed -- every frame bit-exact."""
+    aos, cfg = synth.generate_config("A")
+    w, h = cfg["width"], cfg["height"]
+    sc = make_scene(aos, w, h)
+    r = make_renderer(sc, w, h, count=count)
+    _, ref = oracle_run(oracle_mod, sc, w, h)
+    for _ in range(3):
+        img = r.draw(sc)
+        assert_frame_equals_oracle(r, img, ref)
+    # a band of tile rows (16-bit compact tile ids, fewer passes), same context
+    full = ref["image"]
+    r.setTileRows(5, 14)
+    _, band = oracle_run(oracle_mod, sc, w, h, row_begin=5, row_end=14)
+    e = band["e"]
+    for _ in range(3):
+        img = r.draw(sc)
+        assert r.timings().num_sort_elements == e
+        assert np.array_equal(r.debugRead(gs.BUF_SORTED_TILE), band["tile"][:e])
+        assert np.array_equal(r.debugRead(gs.BUF_SORTED_DEPTH), band["depth"][:e])
+        assert np.array_equal(r.debugRead(gs.BUF_SORTED_ID), band["id"][:e])
+        assert np.array_equal(r.debugRead(gs.BUF_RANGES), band["ranges"])
+        assert np.array_equal(img[5 * 16:14 * 16], full[5 * 16:14 * 16])
+    r.cleanup()
 
 
 def test_config_a_full_parity(oracle_mod):

@@ -27,6 +27,7 @@ GS_RENDER_FAST = 1
 GS_RENDER_KERNEL_AUTO, GS_RENDER_KERNEL_WAVE_1PX, GS_RENDER_KERNEL_WAVE_2PX = 0, 1, 2
 GS_RENDER_KERNEL_WAVE_4PX, GS_RENDER_KERNEL_WORKGROUP, GS_RENDER_KERNEL_WORKGROUP_8X8 = 4, 16, 17
 GS_TILE_ORDER_LONGEST_FIRST, GS_TILE_ORDER_RASTER = 0, 1
+GS_COUNT_AUTO, GS_COUNT_PER_PASS, GS_COUNT_FED = 0, 1, 2
 GS_SORT_RADIX4 = 0
 GS_SORT_TILE_BUCKET = 1
 GS_SORT_RADIX4_SPLAT_FIRST = 2
@@ -54,6 +55,7 @@ class GsConfig(C.Structure):
         ("record_timings", C.c_uint32),
         ("render_kernel", C.c_uint32),
         ("tile_order", C.c_uint32),
+        ("count_launches", C.c_uint32),
     ]
 
 
@@ -116,7 +118,7 @@ EXPORTS = [
     "gs_render_sharded_async", "gs_sharded_frame", "gs_sharded_read", "gs_dist_rebalance", "gs_dist_bands", "gs_balance_rows",
 ]
 ROWS_CONTIGUOUS, ROWS_INTERLEAVED, ROWS_BALANCED = 0, 1, 2   # GS_ROWS_*
-API_VERSION = 4            # GS_API_VERSION of include/gsplat.h this binding was written against
+API_VERSION = 5            # GS_API_VERSION of include/gsplat.h this binding was written against
 DIST_UNIQUE_ID_BYTES = 128
 
 

@@ -67,6 +67,7 @@ void free_scene(gs_ctx* c) {
 void free_sort(SortBuffers& s) {
     for (int k = 0; k < 2; ++k) { free_dev(s.lo[k]); free_dev(s.hi[k]); free_dev(s.id[k]); }
     free_dev(s.table); free_dev(s.seg_sum); free_dev(s.params); free_dev(s.coarse);
+    free_dev(s.fed[0]); s.fed[1] = s.fed[2] = nullptr;      // one allocation, three sets
 }
 
 void drop_sort_graph(gs_ctx* c) {
@@ -84,6 +85,7 @@ void free_resolution(gs_ctx* c) {
     gsi_dist_free_buffers(c);
     c->capacity = 0; c->width = c->height = 0;
     c->have_frame = false;
+    if (c->elems_note) *(volatile uint32_t*)c->elems_note = 0u;     // (free_resolution's callers have waited for the stream)
 }
 
 // Renderer.cpp:703-710
@@ -114,12 +116,25 @@ int alloc_sort(gs_ctx* ctx, SortBuffers& s, uint32_t capacity, uint32_t digit_bi
         const uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
         HIP_TRY(ctx, hipMalloc((void**)&s.table, (size_t)kBins * max_groups * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMalloc((void**)&s.seg_sum, (size_t)kBins * kSegments * sizeof(uint32_t)));
+        // fed counts: three rotating sets of [groups][16] rows (k_scatter<.., FED>); every row a pass reads was written or
+        // cleared earlier in the same sort, so no initial clear
+        const size_t set_words = (size_t)kBins * max_groups;
+        HIP_TRY(ctx, hipMalloc((void**)&s.fed[0], 3 * set_words * sizeof(uint32_t)));
+        s.fed[1] = s.fed[0] + set_words;
+        s.fed[2] = s.fed[1] + set_words;
     }
     s.digit_bits = digit_bits;
     HIP_TRY(ctx, hipMalloc((void**)&s.params, sizeof(SortParams)));
     HIP_TRY(ctx, hipMemset(s.params, 0, sizeof(SortParams)));
     HIP_TRY(ctx, hipMalloc((void**)&s.coarse, (size_t)kMaxSortPasses * kBins * kCoarse * sizeof(uint32_t)));
     return GS_OK;
+}
+
+// the stand-alone 4-bit sorter knows its element count: fed counts (gs_sort.hip) for short lists
+bool fed_for(const gs_ctx* c, uint32_t n) {
+    if (digit_bits_of(c->cfg.sort_algorithm) != (uint32_t)kRadixBits) return false;
+    return c->cfg.count_launches == GS_COUNT_FED ||
+           (c->cfg.count_launches == GS_COUNT_AUTO && n <= kFedMaxGroups * (uint32_t)kSortTile);
 }
 
 int check_launch(gs_ctx* ctx, const char* what) {
@@ -233,9 +248,26 @@ int enqueue_frame(gs_ctx* c, const float* view, const float* proj, const float* 
         if (tm) HIP_TRY(c, hipEventRecord(c->ev[2], st));
         // gpuSort->computeSort (RadixSort.cpp:207-653).  The passes' arguments are fixed once resolution and tile rows are:
         // captured once, replayed as a hipGraph.  Without timers FindRanges (same property) rides in the same graph.
+        // fed counts (gs_sort.hip): for the contractual sorter, when the list is short.  The host enqueues a frame without
+        // knowing its element count, so GS_COUNT_AUTO goes by the count of a recent frame, which k_scan_blocks leaves in
+        // a pinned host word (nothing waits for it; none yet: a Count launch per pass); a change of mind re-captures
+        // the graph.  Speed only: the sorted list is the same either way and at any length.
+        bool fed = false;
+        if (c->cfg.sort_algorithm == GS_SORT_RADIX4) {
+            const uint32_t limit = kFedMaxGroups * (uint32_t)kSortTile;
+            const uint32_t note = c->elems_note ? *(volatile const uint32_t*)c->elems_note : 0u;   // count + 1 of a recent frame
+            fed = c->cfg.count_launches == GS_COUNT_FED ||
+                  (c->cfg.count_launches == GS_COUNT_AUTO && note != 0u &&
+                   note - 1u <= (c->sort_fed ? limit : limit - limit / 16u));
+        }
+        if (fed != c->sort_fed) {
+            if (c->sort_graph || c->chain_graph) HIP_TRY(c, hipStreamSynchronize(st));   // the graph may still be executing (rare: the mode flips)
+            drop_sort_graph(c);
+            c->sort_fed = fed;
+        }
         auto all_passes = [&](hipEvent_t* evs) {
             return launch_radix_sort(c->sort, c->capacity, c->band_sort_bits, st, evs, bucket ? 32u : 0u, !bucket, c->hi16, tile_share,
-                                     0, 0, nullptr, digit);
+                                     0, 0, nullptr, digit, fed);
         };
         if (!tm && !bucket) {
             const int sorted = radix_passes(c->chain_graph, c->chain_result, [&](hipEvent_t*) {
@@ -420,6 +452,7 @@ void gs_default_config(gs_config* cfg) {
     cfg->record_timings = 0;        // RECORD_GPU_TIMES is commented out in the reference (GfxSettings.h:7)
     cfg->render_kernel = GS_RENDER_KERNEL_AUTO;
     cfg->tile_order = GS_TILE_ORDER_LONGEST_FIRST;
+    cfg->count_launches = GS_COUNT_AUTO;
 }
 
 int gs_create(const gs_config* cfg_in, gs_ctx** out) {
@@ -444,6 +477,7 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
         cfg.render_kernel != GS_RENDER_KERNEL_WORKGROUP && cfg.render_kernel != GS_RENDER_KERNEL_WORKGROUP_8X8)
         return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown render_kernel");
     if (cfg.tile_order > GS_TILE_ORDER_RASTER) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown tile_order");
+    if (cfg.count_launches > GS_COUNT_FED) return fail(nullptr, GS_ERR_INVALID, "gs_create: unknown count_launches");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -462,6 +496,17 @@ int gs_create(const gs_config* cfg_in, gs_ctx** out) {
         return fail(nullptr, GS_ERR_HIP, msg);
     }
     c->stream = c->own_stream;
+    // a pinned host word the frames' k_scan_blocks writes their element count to (GS_COUNT_AUTO reads it when it enqueues
+    // the next frame); doing without it is no error: the sort then keeps a Count launch per pass
+    if (cfg.sort_algorithm == GS_SORT_RADIX4 && cfg.count_launches == GS_COUNT_AUTO) {
+        void* note = nullptr;
+        if (hipHostMalloc(&note, 64, hipHostMallocMapped) == hipSuccess && note) {
+            c->elems_note = (uint32_t*)note;
+            *c->elems_note = 0u;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     for (auto& ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) {
             std::string msg = std::string("gs_create: ") + hipGetErrorString(e);
@@ -520,6 +565,7 @@ int gs_destroy(gs_ctx* c) {
     if (c->join_ev) (void)hipEventDestroy(c->join_ev);
     if (c->helper_stream) { (void)hipStreamSynchronize(c->helper_stream); (void)hipStreamDestroy(c->helper_stream); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->elems_note) (void)hipHostFree(c->elems_note);
     delete c;
     return GS_OK;
 }
@@ -552,6 +598,12 @@ static int alloc_scratch(gs_ctx* c, uint32_t n) {
     HIP_TRY(c, hipMemsetAsync(c->scratch.wave_wrote, 0, (size_t)c->num_blocks * 4, c->stream));
     HIP_TRY(c, hipMalloc((void**)&c->scratch.help_list, (size_t)kEmitHelpCap * sizeof(uint2)));
     HIP_TRY(c, hipMalloc((void**)&c->scratch.help_count, 4 * sizeof(uint32_t)));
+    c->scratch.elems_note = nullptr;
+    if (c->elems_note) {
+        void* dev = nullptr;
+        if (hipHostGetDevicePointer(&dev, c->elems_note, 0) == hipSuccess) c->scratch.elems_note = (uint32_t*)dev;
+        else (void)hipGetLastError();
+    }
     HIP_TRY(c, hipMalloc((void**)&c->scratch.band_list, (size_t)c->num_blocks * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void**)&c->scratch.help_slot, (size_t)c->num_blocks * sizeof(uint32_t)));
     HIP_TRY(c, hipMemsetAsync(c->scratch.help_count, 0, 4 * sizeof(uint32_t), c->stream));
@@ -690,6 +742,10 @@ static int apply_tile_rows(gs_ctx* c, uint32_t row_begin, uint32_t row_end, uint
     c->first_row = row_begin + phase;
     c->rows_owned = c->first_row < row_end ? (row_end - c->first_row + stride - 1u) / stride : 0u;
     c->compact_out = compact_out;
+    if (c->elems_note) {           // another band: another list length (GS_COUNT_AUTO learns it from the next frame)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));   // no frame in flight may still write the old one
+        *(volatile uint32_t*)c->elems_note = 0u;
+    }
     const uint32_t owned_tiles = c->rows_owned * c->grid_w;
     c->band_sort_bits = num_sort_bits_for(owned_tiles ? owned_tiles : 1u);
     c->hi16 = owned_tiles <= 65535u;
@@ -984,7 +1040,7 @@ int gs_sort_host(gs_ctx* c, uint32_t* tile, uint32_t* depth, uint32_t* id, uint3
     if (e == hipSuccess) {
         launch_set_sort_params(sb.params, sb.coarse, n, c->stream);
         si = launch_radix_sort(sb, n, num_sort_bits, c->stream, nullptr, 0u, false, false, 1.0f, 0, 0, nullptr,
-                               digit_bits_of(c->cfg.sort_algorithm));
+                               digit_bits_of(c->cfg.sort_algorithm), fed_for(c, n));
         e = hipGetLastError();
         if (si < 0) { free_sort(sb); return fail(c, GS_ERR_INVALID, "gs_sort_host: sort buffers of another digit width"); }
     }
@@ -1018,7 +1074,7 @@ int gs_sort_bench(gs_ctx* c, uint32_t n, uint32_t num_tiles, uint32_t iters, uin
         e = hipEventRecord(e0, c->stream);
         if (e != hipSuccess) break;
         si = launch_radix_sort(sb, n, bits, c->stream, nullptr, 0u, false, false, 1.0f, 0, 0, nullptr,
-                               digit_bits_of(c->cfg.sort_algorithm));
+                               digit_bits_of(c->cfg.sort_algorithm), fed_for(c, n));
         if (si < 0) { si = 0; e = hipErrorInvalidValue; break; }
         e = hipEventRecord(e1, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

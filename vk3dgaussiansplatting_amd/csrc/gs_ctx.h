@@ -69,6 +69,9 @@ struct gs_ctx {
     hipEvent_t pre_ev[3] = {};        // ... after the splat list / after its passes / after the emit
     int sort_graph_result = 0, presort_result = 1;
     bool sort_graph_failed = false;
+    uint32_t* elems_note = nullptr;   // pinned host word k_scan_blocks writes (element count + 1 of the latest list; 0: none
+                                      // since the rows were set) -- what GS_COUNT_AUTO goes by
+    bool sort_fed = false;        // the captured radix passes are the fed kind (k_scatter<.., FED>)
     bool depth_dropped = false;   // last frame's tile-word passes did not carry the depth words (see k_scatter)
 
     gs_timings timings{};

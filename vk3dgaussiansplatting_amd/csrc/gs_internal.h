@@ -25,6 +25,12 @@ constexpr int kSegments = 512;                // reduce segments = Count workgro
                                               // (measured: 512 beats 256 and 1024 at configs A-E)
 constexpr int kCoarse = 64;                   // coarse reduce segments (kSegments / kCoarse segments each): second Reduce level
 constexpr int kMaxSortPasses = 16;            // 64 key bits / 4
+// Fed counts (gs_sort.hip, k_scatter<.., FED>): lists of at most this many groups may sort without per-pass Count
+// launches -- every Scatter workgroup then sums the count rows of all groups itself (G x 64 bytes out of L2).
+#ifndef GS_FED_MAX_GROUPS
+#define GS_FED_MAX_GROUPS 896     /* measured on MI355X (profiles/r06_fed_probe.txt): fed wins below ~900 groups, by more the shorter the list */
+#endif
+constexpr uint32_t kFedMaxGroups = GS_FED_MAX_GROUPS;
 
 // ---- GS_SORT_RADIX8*: the same sort with 8-bit digits (gs_sort8.hip) ------------------------
 constexpr int kBins8 = 256;
@@ -135,6 +141,8 @@ struct SplatScratch {
     uint32_t* flag_offsets;  // same size, exclusive scan
     uint32_t* sorted_sums;   // [blocks, padded]  tile counts per 256 positions of the sorted splat list
     SortParams* aux_params;  // [2]: the splat list's dispatch record; scratch for the second scan
+    uint32_t* elems_note;    // device alias of a pinned host word (or null): k_scan_blocks leaves the frame's element count + 1
+                             // there, so that the host knows the length of recent lists without waiting for a frame
 };
 #ifndef GS_EMIT_SLICE
 #define GS_EMIT_SLICE 4096
@@ -156,6 +164,8 @@ struct SortBuffers {
                                      // [256][kSegments] counts, then [256][kSegments] scanned
     uint32_t* coarse;                // [kMaxSortPasses][16][kCoarse]  per-pass digit counts of the coarse segments
                                      // (8-bit digits: the first 256 words of a pass's slab = its digit totals)
+    uint32_t* fed[3];                // 4-bit digits: [G_max][16] digit counts per group, three rotating sets of the fed
+                                     // sort (k_scatter<.., FED>); null for 8-bit digits
     SortParams* params;
     uint32_t digit_bits;             // what alloc_sort sized table / seg_sum for (4 or 8): the launchers refuse the other width
 };
@@ -196,12 +206,14 @@ void launch_emit_sorted(const FrameParams& fp, const SplatScratch& sc, const Sor
 // hi16: the hi arrays hold 16-bit tile ids (frame path, at most 65535 owned tiles).
 // start: the ping-pong buffer the list lies in; coarse_pass: first slab of sb.coarse to use (one per pass; two sorts
 // in one frame must not share slabs); params: dispatch record of this list (default sb.params).
+// fed: 4-bit digits only -- one Count launch for the whole sort, every Scatter feeds the next pass's counts (k_scatter<.., FED>);
+// same output, meant for lists of at most kFedMaxGroups groups (correct, but slow, beyond).
 // Returns -1 without launching anything when digit_bits is not the width sb was allocated for.
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events = nullptr, uint32_t first_bit = 0,
                       bool drop_depth_payload = false, bool hi16 = false, float share = 1.0f,
                       int start = 0, uint32_t coarse_pass = 0, const SortParams* params = nullptr,
-                      uint32_t digit_bits = kRadixBits);
+                      uint32_t digit_bits = kRadixBits, bool fed = false);
 // the same with 8-bit digits (gs_sort8.hip); launch_radix_sort forwards here when digit_bits == 8
 int launch_radix_sort8(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits, hipStream_t stream,
                        hipEvent_t* scatter_events, uint32_t first_bit, bool drop_depth_payload, bool hi16, float share,

@@ -537,7 +537,8 @@ __global__ __launch_bounds__(kProjThreads, GS_PROJECT_MINBLOCKS) void k_project(
 // entries at upload): one pass to sum, one block scan, one pass to write -- no row-by-row carry chain.
 // It also does the frame's clears (computeInitSortList's fills, Subrenderer.cpp:42-60): the tile ranges and the
 // per-pass coarse digit totals of the sort -- two fill launches less per frame.
-struct ScanJob { const uint32_t* sums; uint32_t* offsets; SortParams* params; uint32_t capacity; };
+struct ScanJob { const uint32_t* sums; uint32_t* offsets; SortParams* params; uint32_t capacity;
+                 uint32_t* host_note; };   // host-mapped word (or null): the element count + 1, for the host to read when it likes
 constexpr uint32_t kScanClearWgs = 8;   // workgroups behind the scanning ones: the frame's clears, beside the scan
 __global__ __launch_bounds__(1024) void k_scan_blocks(const ScanJob job0, const ScanJob job1, uint32_t jobs, uint32_t num_blocks,
                                                        uint4* __restrict__ zero_a, uint32_t n16_a,
@@ -591,6 +592,8 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const ScanJob job0, const 
         params->num_groups = (e + kSortTile - 1) / kSortTile;
         params->groups_per_seg = (params->num_groups + kSegments - 1) / kSegments;
         params->overflow = counter > capacity ? 1u : 0u;
+        // what GS_COUNT_AUTO goes by (gs_api.cpp): a fire-and-forget store into pinned host memory, nobody waits for it
+        if (job.host_note) __hip_atomic_store(job.host_note, e + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (held) {
 #pragma unroll
@@ -808,9 +811,9 @@ void launch_scan_blocks(const FrameParams& fp, const SplatScratch& sc, SortParam
     // ranges: [grid_w * grid_h][2] uint32 (hipMalloc'd, so 16-byte aligned; padded to a multiple of 16 bytes by the caller)
     const uint32_t n16_ranges = (fp.grid_w * fp.grid_h * 2u + 3u) / 4u;
     const uint32_t n16_coarse = (uint32_t)(kMaxSortPasses * kBins * kCoarse) / 4u;
-    const ScanJob elements{sc.block_sums, sc.block_offsets, params, fp.capacity};
+    const ScanJob elements{sc.block_sums, sc.block_offsets, params, fp.capacity, sc.elems_note};
     // GS_SORT_RADIX4_SPLAT_FIRST: the emitting splats are scanned beside the elements (a second workgroup)
-    const ScanJob splats{sc.block_flags, sc.flag_offsets, sc.aux_params, fp.num_gaussians};
+    const ScanJob splats{sc.block_flags, sc.flag_offsets, sc.aux_params, fp.num_gaussians, nullptr};
     const uint32_t jobs = fp.splat_first ? 2u : 1u;
     hipLaunchKernelGGL(k_scan_blocks, dim3(jobs + kScanClearWgs), dim3(1024), 0, stream, elements, splats, jobs, blocks,
                        reinterpret_cast<uint4*>(ranges), n16_ranges, reinterpret_cast<uint4*>(coarse), n16_coarse,

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(kCountThreads) void k_count(const SortParams* __res
                                                          uint32_t* __restrict__ table,
                                                          uint32_t* __restrict__ seg_sum,
                                                          uint32_t* __restrict__ coarse,
-                                                         uint32_t sh) {
+                                                         uint32_t sh, uint32_t* __restrict__ fed_rows,
+                                                         uint32_t* __restrict__ fed_zero) {
     __shared__ uint32_t s_pack[kCountWaves][8];      // wave-private: packed totals of the group the wave just counted
     __shared__ uint32_t s_hist[kCountMaxK][kBins];  // digit counts of the segment's groups (the first kCountMaxK of them)
     const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
@@ -161,13 +162,17 @@ __global__ __launch_bounds__(kCountThreads) void k_count(const SortParams* __res
             const int half = (lane >> 2) & 1;
             const uint32_t t = (s_pack[wave][widx] >> (16 * half)) & 0xFFFFu;
             const uint32_t j = grp - grp0;
-            if (j < (uint32_t)kCountMaxK) s_hist[j][lane] = t;
+            if (fed_rows) {                          // fed counts (see k_scatter<.., FED>): the raw row of the group, and
+                fed_rows[grp * kBins + lane] = t;    // the row the first Scatter adds into starts from zero
+                fed_zero[grp * kBins + lane] = 0u;
+            } else if (j < (uint32_t)kCountMaxK) s_hist[j][lane] = t;
             else table[lane * G + grp] = t;          // segments of more than kCountMaxK groups (E > 268 M): raw counts, see below
         }
         __builtin_amdgcn_wave_barrier();   // ... nor the next group's writes above these reads
         if (nxt_grp < grp_end) cur = nxt;
         grp = nxt_grp;
     }
+    if (fed_rows) return;            // kernel-uniform: no Reduce / ScanAdd structure in this mode
     __syncthreads();
     // ScanAdd inside the segment (RadixSortScanAdd.comp:34-66), here rather than in every Scatter workgroup: the table
     // gets, per group and digit, the number of keys of that digit in the EARLIER groups of the segment (bin-major,
@@ -217,6 +222,10 @@ __global__ __launch_bounds__(kCountThreads) void k_count(const SortParams* __res
 #define GS_SCATTER_MINWAVES_SMALL 5  // ... passes whose element fits one 8-byte LDS slot
 #endif
 
+constexpr uint32_t kSortTileLog2 = 11;
+static_assert((1u << kSortTileLog2) == (uint32_t)kSortTile, "destination group of an element = index >> kSortTileLog2");
+__device__ __forceinline__ void fed_zero_row(uint32_t* rows, uint32_t grp, int d) { rows[grp * kBins + d] = 0u; }
+
 // inclusive prefix sum inside each row of 16 lanes (DPP row_shr 1/2/4/8; lanes shifted in from outside the row add 0)
 __device__ __forceinline__ uint32_t row16_inclusive_scan(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
@@ -235,14 +244,26 @@ __device__ __forceinline__ uint32_t row16_inclusive_scan(uint32_t v) {
 // HI16: the tile words are 16-bit compact tile ids (at most 65535 owned tiles): 2 bytes less read and 2 less written
 // per element in every pass.
 // FULL: the group holds kSortTile valid keys (every group but the last): no per-element bounds logic.
-template <int LO_IN, int LO_OUT, bool HI16, bool FULL>
+// FED: "fed counts" -- the pass has no Count launch of its own.  Every Scatter workgroup of pass p counts, per digit run it
+// stores and per destination group the run reaches (at most two: a run is at most one group long), the NEXT digit of the
+// keys it stores (LDS atomics while they pass through the store loop) and adds those <= 32 rows of 16 counts to the rows
+// of the destination groups, rows[g][16], with agent-scope atomics (16 lanes = one 64-byte request; a destination row
+// receives ~16-32 such requests, so no line is a hot spot -- which is why there are no coarser levels: a level that
+// sums S groups would take 16 S requests per line).  The prologue of pass p + 1 therefore sums the rows of ALL groups
+// itself (those ahead of its own for the prefix, all of them for the digit totals): G x 64 bytes per workgroup out of
+// L2, affordable for lists of up to ~1000 groups (a tile-row band of a multi-GPU frame, config A), where a Count launch
+// is one fixed ~8 us latency chain per pass.  Three row sets rotate: pass p reads set p % 3, adds into (p + 1) % 3 and
+// clears its own row of (p + 2) % 3; pass 0's rows come from k_count (one launch per sort instead of one per pass).
+// In this mode the kernel's `table` argument is the row set read, `seg_sum` the set added into (null in the last
+// pass) and `coarse` the set cleared.
+template <int LO_IN, int LO_OUT, bool HI16, bool FULL, bool FED>
 __device__ __forceinline__ void scatter_group(
     uint32_t e, uint32_t G, uint32_t K, uint32_t grp, const uint32_t* __restrict__ in_lo,
     const uint32_t* __restrict__ in_hi, const uint32_t* __restrict__ in_id,
     uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_hi, uint32_t* __restrict__ out_id,
     const uint32_t* __restrict__ table, const uint32_t* __restrict__ seg_sum, const uint32_t* __restrict__ coarse,
     uint32_t shift, uint2* s_slot, typename std::conditional<HI16, uint16_t, uint32_t>::type* s_third,
-    uint32_t* s_wcnt, uint32_t* s_pre) {
+    uint32_t* s_wcnt, uint32_t* s_pre, uint32_t* s_next, uint32_t* s_first) {
     constexpr int R = kSortKeysPerThread;
     // what travels beside the 8-byte slot {id, word}: nothing when the element is id + one 32-bit word (tile-word
     // passes; depth passes whose depth and tile words are both 16 bits wide), else the tile word (s_third)
@@ -263,11 +284,28 @@ __device__ __forceinline__ void scatter_group(
     const int sd = lane & 15, sq = lane >> 4;
     // thread t: digit t >> 4, coarse segments 4 (t & 15) .. + 3
     static_assert(kCoarse == 64 && kSortThreads == 256, "one 16-byte load per thread covers the coarse totals");
-    const uint4 cv = reinterpret_cast<const uint4*>(coarse)[tid];
-    // the table already holds the group's prefix inside its segment (k_count); lanes of row 0 take it, every row
-    // adds its share of the segment totals ahead inside the coarse segment
-    uint32_t pre = sq == 0 ? table[sd * G + grp] : 0u;
-    for (uint32_t l = (uint32_t)sq; l < jf; l += 4u) pre += seg_sum[sd * kSegments + cseg * kFinePerCoarse + l];
+    uint4 cv = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t pre = 0u;
+    constexpr int kFedBatch = 8;                 // 16-byte row loads a thread keeps in flight: 512 rows per batch
+    uint4 fv[FED ? kFedBatch : 1];
+    if constexpr (FED) {
+        // rows of all groups, first batch: thread t takes digits 4 (t & 3) .. + 3 of rows t >> 2, + 64, ... (a wave
+        // instruction = 16 whole rows); issued ahead of the keys (L2 hits: they are back long before the keys are)
+        s_next[tid] = 0u; s_next[tid + kSortThreads] = 0u;
+        if (tid < kBins) fed_zero_row(const_cast<uint32_t*>(coarse), grp, tid);
+        const uint4* __restrict__ rows4 = reinterpret_cast<const uint4*>(table);
+#pragma unroll
+        for (int k = 0; k < kFedBatch; ++k) {
+            const uint32_t r = ((uint32_t)tid >> 2) + 64u * (uint32_t)k;
+            fv[k] = r < G ? rows4[r * 4u + ((uint32_t)tid & 3u)] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    } else {
+        cv = reinterpret_cast<const uint4*>(coarse)[tid];
+        // the table already holds the group's prefix inside its segment (k_count); lanes of row 0 take it, every row
+        // adds its share of the segment totals ahead inside the coarse segment
+        pre = sq == 0 ? table[sd * G + grp] : 0u;
+        for (uint32_t l = (uint32_t)sq; l < jf; l += 4u) pre += seg_sum[sd * kSegments + cseg * kFinePerCoarse + l];
+    }
 
     uint32_t lo[R], hi[R], id[R];
     {
@@ -289,17 +327,54 @@ __device__ __forceinline__ void scatter_group(
 
     // ---- per digit: total over all coarse segments, and over those before this group's (row of 16 lanes = one
     //      digit; DPP scan inside the row, lane 15 of the row holds the sums) -> LDS, read after barrier 1
-    {
+    if constexpr (FED) {
+        uint4 fa = make_uint4(0u, 0u, 0u, 0u), fb = make_uint4(0u, 0u, 0u, 0u);    // all groups / the groups ahead of this one
+        auto take = [&](const uint4& v, uint32_t r) {
+            fa.x += v.x; fa.y += v.y; fa.z += v.z; fa.w += v.w;
+            if (r < grp) { fb.x += v.x; fb.y += v.y; fb.z += v.z; fb.w += v.w; }
+        };
+#pragma unroll
+        for (int k = 0; k < kFedBatch; ++k) take(fv[k], ((uint32_t)tid >> 2) + 64u * (uint32_t)k);
+        {   // lists of more than 512 groups: further batches (each one L2 round trip)
+            const uint4* __restrict__ rows4 = reinterpret_cast<const uint4*>(table);
+            for (uint32_t b = 64u * (uint32_t)kFedBatch; b < G; b += 64u * (uint32_t)kFedBatch) {   // kernel-uniform trip count
+                uint4 w[kFedBatch];
+#pragma unroll
+                for (int k = 0; k < kFedBatch; ++k) {
+                    const uint32_t r = b + ((uint32_t)tid >> 2) + 64u * (uint32_t)k;
+                    w[k] = r < G ? rows4[r * 4u + ((uint32_t)tid & 3u)] : make_uint4(0u, 0u, 0u, 0u);
+                }
+#pragma unroll
+                for (int k = 0; k < kFedBatch; ++k) take(w[k], b + ((uint32_t)tid >> 2) + 64u * (uint32_t)k);
+            }
+        }
+        // lanes l, l + 4, ... of a wave hold partial sums of the same four digits: rotate-and-add inside the rows of 16
+        // lanes (DPP row_ror 4, 8), then across the four rows; lanes 0..3 leave the wave's share in LDS
+        // (s_pre[wave][0..15] totals, [16..31] ahead of this group), summed over the waves after barrier 1
+        auto wsum = [](uint32_t v) {
+            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);   // row_ror:4
+            v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);   // row_ror:8
+            v += (uint32_t)__shfl_xor((int)v, 16, 64);
+            v += (uint32_t)__shfl_xor((int)v, 32, 64);
+            return v;
+        };
+        fa.x = wsum(fa.x); fa.y = wsum(fa.y); fa.z = wsum(fa.z); fa.w = wsum(fa.w);
+        fb.x = wsum(fb.x); fb.y = wsum(fb.y); fb.z = wsum(fb.z); fb.w = wsum(fb.w);
+        if (lane < 4) {
+            *reinterpret_cast<uint4*>(&s_pre[wave * 2 * kBins + 4 * lane]) = fa;
+            *reinterpret_cast<uint4*>(&s_pre[wave * 2 * kBins + kBins + 4 * lane]) = fb;
+        }
+    } else {
         const uint32_t c0 = 4u * (uint32_t)(tid & 15);
         const uint32_t all = cv.x + cv.y + cv.z + cv.w;
         const uint32_t before = (c0 < cseg ? cv.x : 0u) + (c0 + 1u < cseg ? cv.y : 0u) + (c0 + 2u < cseg ? cv.z : 0u) +
                                 (c0 + 3u < cseg ? cv.w : 0u);
         const uint32_t all_s = row16_inclusive_scan(all), before_s = row16_inclusive_scan(before);
         if ((tid & 15) == 15) { s_pre[tid >> 4] = all_s; s_pre[kBins + (tid >> 4)] = before_s; }
+        // fine segments and groups ahead inside this coarse segment (every wave alike, lanes sd + 16 q)
+        pre += (uint32_t)__shfl_xor((int)pre, 16, 64);
+        pre += (uint32_t)__shfl_xor((int)pre, 32, 64);
     }
-    // fine segments and groups ahead inside this coarse segment (every wave alike, lanes sd + 16 q)
-    pre += (uint32_t)__shfl_xor((int)pre, 16, 64);
-    pre += (uint32_t)__shfl_xor((int)pre, 32, 64);
 
     // ---- stable rank inside the wave.  Per round: 4 ballots give every lane the mask of lanes holding the same
     //      digit; lane d (d < 16) keeps the wave's running count of digit d.
@@ -346,9 +421,18 @@ __device__ __forceinline__ void scatter_group(
         const uint32_t dstart = row16_inclusive_scan(tot) - tot;        // first local position of digit sd
         wbase = dstart + (wave > 0 ? c.x : 0u) + (wave > 1 ? c.y : 0u) + (wave > 2 ? c.z : 0u);
         // Scan: keys of smaller digits anywhere = exclusive scan of the digit totals
-        const uint32_t dtot = s_pre[sd];
-        const uint32_t gpre = (row16_inclusive_scan(dtot) - dtot) + s_pre[kBins + sd] + pre;
+        uint32_t dtot, ahead;
+        if constexpr (FED) {
+            static_assert(kSortWaves == 4, "four partial sums per digit");
+            dtot = (s_pre[sd] + s_pre[2 * kBins + sd]) + (s_pre[4 * kBins + sd] + s_pre[6 * kBins + sd]);
+            ahead = (s_pre[kBins + sd] + s_pre[3 * kBins + sd]) + (s_pre[5 * kBins + sd] + s_pre[7 * kBins + sd]);
+        } else {
+            dtot = s_pre[sd];
+            ahead = s_pre[kBins + sd] + pre;
+        }
+        const uint32_t gpre = (row16_inclusive_scan(dtot) - dtot) + ahead;
         gofs = gpre - dstart;                                            // global = gofs(digit) + local position
+        if constexpr (FED) { if (tid < kBins) s_first[tid] = gpre; }     // where the group's run of digit `tid` begins (read after barrier 2)
     }
 
     // ---- local sort into LDS.  The cross-lane reads run with every lane active (a lane past the end of a ragged
@@ -383,12 +467,38 @@ __device__ __forceinline__ void scatter_group(
             if constexpr (HI16) reinterpret_cast<uint16_t*>(out_hi)[o] = (uint16_t)h;
             else out_hi[o] = h;
             out_id[o] = sl.x;
+            if constexpr (FED) {
+                if (seg_sum) {   // not the last pass: the key's NEXT digit, counted under (run, destination group)
+                    const uint32_t ns = shift + (uint32_t)kRadixBits;
+                    const uint32_t nd = ns >= 32u ? digit_of(h, ns - 32u) : digit_of(l, LO_IN == 2 ? ns - 16u : ns);
+                    const uint32_t j = (o >> kSortTileLog2) - (s_first[d] >> kSortTileLog2);          // 0 or 1
+                    (void)__hip_atomic_fetch_add(&s_next[((d * 2u + j) << kRadixBits) | nd], 1u, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    }
+    if constexpr (FED) {
+        if (seg_sum) {
+            __syncthreads();
+            uint32_t* __restrict__ next_rows = const_cast<uint32_t*>(seg_sum);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {        // 512 counters: 16 runs x 2 destination groups x 16 digits
+                const uint32_t idx = (uint32_t)(k * kSortThreads + tid);
+                const uint32_t c = s_next[idx];
+                const uint32_t dgrp = (s_first[idx >> 5] >> kSortTileLog2) + ((idx >> 4) & 1u);
+                if (c != 0u)
+                    (void)__hip_atomic_fetch_add(&next_rows[dgrp * kBins + (idx & 15u)], c, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
 
-template <int LO_IN, int LO_OUT, bool HI16>
-__global__ __launch_bounds__(kSortThreads, (LO_IN == 4 || (LO_IN == 2 && !HI16)) ? GS_SCATTER_MINWAVES_KEY : GS_SCATTER_MINWAVES_SMALL)
+// (the fed kind keeps a batch of count rows in registers beside the keys: four workgroups per CU, 128 VGPRs -- its lists
+// are short, a CU never holds more than four of its workgroups anyway)
+template <int LO_IN, int LO_OUT, bool HI16, bool FED>
+__global__ __launch_bounds__(kSortThreads, FED ? 4 : ((LO_IN == 4 || (LO_IN == 2 && !HI16)) ? GS_SCATTER_MINWAVES_KEY : GS_SCATTER_MINWAVES_SMALL))
 void k_scatter(const SortParams* __restrict__ params, const uint32_t* __restrict__ in_lo,
                const uint32_t* __restrict__ in_hi, const uint32_t* __restrict__ in_id,
                uint32_t* __restrict__ out_lo, uint32_t* __restrict__ out_hi, uint32_t* __restrict__ out_id,
@@ -398,7 +508,9 @@ void k_scatter(const SortParams* __restrict__ params, const uint32_t* __restrict
     __shared__ uint2 s_slot[kSortTile];
     __shared__ typename std::conditional<HI16, uint16_t, uint32_t>::type s_third[kThird ? kSortTile : 1];
     __shared__ __attribute__((aligned(16))) uint32_t s_wcnt[kBins * kSortWaves];
-    __shared__ uint32_t s_pre[2 * kBins];
+    __shared__ __attribute__((aligned(16))) uint32_t s_pre[FED ? 2 * kBins * kSortWaves : 2 * kBins];
+    __shared__ uint32_t s_next[FED ? 2 * kBins * kBins : 1];      // [run][destination group 0 / 1][next digit]
+    __shared__ uint32_t s_first[FED ? kBins : 1];
     const uint32_t e = params->num_elems, G = params->num_groups, K = params->groups_per_seg;
     // one group per workgroup as a rule: the grid is sized from an upper estimate of the element count (the list
     // capacity scaled to the context's share of the tiles) and walks on only if a frame exceeds it
@@ -412,22 +524,23 @@ void k_scatter(const SortParams* __restrict__ params, const uint32_t* __restrict
         if (again) __syncthreads();   // LDS is reused
         again = true;
         if (grp * kSortTile + kSortTile <= e)
-            scatter_group<LO_IN, LO_OUT, HI16, true>(e, G, K, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table,
-                                                     seg_sum, coarse, shift, s_slot, s_third, s_wcnt, s_pre);
+            scatter_group<LO_IN, LO_OUT, HI16, true, FED>(e, G, K, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table,
+                                                          seg_sum, coarse, shift, s_slot, s_third, s_wcnt, s_pre, s_next, s_first);
         else
-            scatter_group<LO_IN, LO_OUT, HI16, false>(e, G, K, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table,
-                                                      seg_sum, coarse, shift, s_slot, s_third, s_wcnt, s_pre);
+            scatter_group<LO_IN, LO_OUT, HI16, false, FED>(e, G, K, grp, in_lo, in_hi, in_id, out_lo, out_hi, out_id, table,
+                                                           seg_sum, coarse, shift, s_slot, s_third, s_wcnt, s_pre, s_next, s_first);
     }
 }
 
 int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sort_bits,
                       hipStream_t stream, hipEvent_t* scatter_events, uint32_t first_bit,
                       bool drop_depth_payload, bool hi16, float share, int start, uint32_t coarse_pass,
-                      const SortParams* params, uint32_t digit_bits) {
+                      const SortParams* params, uint32_t digit_bits, bool fed) {
     if (sb.digit_bits != digit_bits) return -1;   // table / seg_sum are sized per digit width (alloc_sort)
     if (digit_bits == 8u)
         return launch_radix_sort8(sb, capacity, num_sort_bits, stream, scatter_events, first_bit, drop_depth_payload, hi16,
                                   share, start, coarse_pass, params);
+    if (fed && !sb.fed[0]) return -1;
     if (!params) params = sb.params;
     uint32_t max_groups = (capacity + kSortTile - 1) / kSortTile;
     // a context that owns a share of the tiles (tile-row band of a multi-GPU frame) launches Scatter over twice
@@ -436,6 +549,9 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
         const uint32_t g = (uint32_t)((float)max_groups * 2.0f * share) + 64u;
         max_groups = g < max_groups ? g : max_groups;
     }
+    // a fed sort is chosen for short lists (gs_api.cpp: from the element count of the frame before): its grid need not
+    // cover more groups than such a list has; k_scatter walks on if this frame holds more
+    if (fed && max_groups > 2u * kFedMaxGroups) max_groups = 2u * kFedMaxGroups;
     // sb.coarse (the coarse digit totals of every pass; Count adds into them with atomics) must be zero on entry:
     // k_scan_blocks clears it in a frame, k_set_sort_params for the stand-alone sorter
     int src = start;
@@ -443,6 +559,7 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
     for (uint32_t shift = first_bit; shift < num_sort_bits; shift += kRadixBits, ++pass) { // RadixSort.cpp:309
         const int dst = src ^ 1;
         const bool tile_pass = shift >= 32u;
+        const bool last = shift + kRadixBits >= num_sort_bits;
         const uint32_t* word = tile_pass ? sb.hi[src] : sb.lo[src];
         // 16-bit words: the tile ids of a band (hi16) and, in a frame, the upper half of the depth word once the
         // lower half is consumed (passes 4-7, see k_scatter)
@@ -451,29 +568,42 @@ int launch_radix_sort(const SortBuffers& sb, uint32_t capacity, uint32_t num_sor
         const bool lo16 = !tile_pass && cin == 2;
         const bool word16 = (tile_pass && hi16) || lo16;
         uint32_t* coarse = sb.coarse + (size_t)(coarse_pass + pass) * kBins * kCoarse;   // zeroed above; this pass's Count adds into it
-        if (word16)
-            hipLaunchKernelGGL((k_count<true>), dim3(kSegments), dim3(kCountThreads), 0, stream, params,
-                               word, sb.table, sb.seg_sum, coarse, lo16 ? shift - 16u : shift & 31u);
-        else
-            hipLaunchKernelGGL((k_count<false>), dim3(kSegments), dim3(kCountThreads), 0, stream, params,
-                               word, sb.table, sb.seg_sum, coarse, shift & 31u);
+        // fed counts: one Count launch per SORT (the rows of pass 0); pass p reads set p % 3, adds into (p + 1) % 3
+        // (nothing in the last pass) and clears (p + 2) % 3
+        uint32_t* const rows_in = fed ? sb.fed[pass % 3u] : nullptr;
+        uint32_t* const rows_next = fed && !last ? sb.fed[(pass + 1u) % 3u] : nullptr;
+        uint32_t* const rows_zero = fed ? sb.fed[(pass + 2u) % 3u] : nullptr;
+        if (!fed || pass == 0u) {
+            uint32_t* const fr = fed ? rows_in : nullptr;
+            uint32_t* const fz = fed ? sb.fed[1] : nullptr;
+            if (word16)
+                hipLaunchKernelGGL((k_count<true>), dim3(kSegments), dim3(kCountThreads), 0, stream, params,
+                                   word, sb.table, sb.seg_sum, coarse, lo16 ? shift - 16u : shift & 31u, fr, fz);
+            else
+                hipLaunchKernelGGL((k_count<false>), dim3(kSegments), dim3(kCountThreads), 0, stream, params,
+                                   word, sb.table, sb.seg_sum, coarse, shift & 31u, fr, fz);
+        }
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass], stream);
         // bytes of the depth word read / written by this pass (see k_scatter)
         int lo_in, lo_out;
         scatter_depth_bytes(shift, first_bit, drop_depth_payload, &lo_in, &lo_out);
         const uint32_t pgrid = max_groups;
-#define GS_LAUNCH_SCATTER(LO_IN, LO_OUT, HI16)                                                                       \
-        hipLaunchKernelGGL((k_scatter<LO_IN, LO_OUT, HI16>), dim3(pgrid), dim3(kSortThreads), 0, stream, params, \
+#define GS_LAUNCH_SCATTER(LO_IN, LO_OUT, HI16, FED, T0, T1, T2)                                                        \
+        hipLaunchKernelGGL((k_scatter<LO_IN, LO_OUT, HI16, FED>), dim3(pgrid), dim3(kSortThreads), 0, stream, params, \
                            sb.lo[src], sb.hi[src], sb.id[src], sb.lo[dst], sb.hi[dst], sb.id[dst],                  \
-                           sb.table, sb.seg_sum, coarse, shift)
+                           T0, T1, T2, shift)
+#define GS_LAUNCH_SCATTER_F(LO_IN, LO_OUT, HI16) \
+        do { if (fed) GS_LAUNCH_SCATTER(LO_IN, LO_OUT, HI16, true, rows_in, rows_next, rows_zero); \
+             else GS_LAUNCH_SCATTER(LO_IN, LO_OUT, HI16, false, sb.table, sb.seg_sum, coarse); } while (0)
 #define GS_LAUNCH_SCATTER_H(LO_IN, LO_OUT) \
-        do { if (hi16) GS_LAUNCH_SCATTER(LO_IN, LO_OUT, true); else GS_LAUNCH_SCATTER(LO_IN, LO_OUT, false); } while (0)
+        do { if (hi16) GS_LAUNCH_SCATTER_F(LO_IN, LO_OUT, true); else GS_LAUNCH_SCATTER_F(LO_IN, LO_OUT, false); } while (0)
         if (lo_in == 4 && lo_out == 4) GS_LAUNCH_SCATTER_H(4, 4);
         else if (lo_in == 4 && lo_out == 2) GS_LAUNCH_SCATTER_H(4, 2);
         else if (lo_in == 2 && lo_out == 2) GS_LAUNCH_SCATTER_H(2, 2);
         else if (lo_in == 2 && lo_out == 0) GS_LAUNCH_SCATTER_H(2, 0);
         else GS_LAUNCH_SCATTER_H(0, 0);
 #undef GS_LAUNCH_SCATTER_H
+#undef GS_LAUNCH_SCATTER_F
 #undef GS_LAUNCH_SCATTER
         if (scatter_events) (void)hipEventRecord(scatter_events[2 * pass + 1], stream);
         src = dst;                                                            // RadixSort.cpp:638-641

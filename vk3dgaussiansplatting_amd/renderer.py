@@ -269,7 +269,7 @@ class _Context:
 
     def __init__(self, device: int = 0, render_mode: int = _lib.GS_RENDER_EXACT, record_timings=True,
                  sort_algorithm: int = _lib.GS_SORT_RADIX4, render_kernel: int = _lib.GS_RENDER_KERNEL_AUTO,
-                 tile_order: int = _lib.GS_TILE_ORDER_LONGEST_FIRST):
+                 tile_order: int = _lib.GS_TILE_ORDER_LONGEST_FIRST, count_launches: int = _lib.GS_COUNT_AUTO):
         L = _lib.lib()
         cfg = GsConfig()
         L.gs_default_config(C.byref(cfg))
@@ -278,6 +278,7 @@ class _Context:
         cfg.sort_algorithm = sort_algorithm
         cfg.render_kernel = render_kernel
         cfg.tile_order = tile_order
+        cfg.count_launches = count_launches
         cfg.record_timings = int(record_timings)   # 0 off, 1 buckets, 2 buckets + per-Scatter events
         self.cfg = cfg
         self.handle = C.c_void_p()
@@ -325,8 +326,8 @@ class RadixSort(GpuSort):
     RS_BIN_COUNT = 16
     SORT_ALGORITHM = _lib.GS_SORT_RADIX4
 
-    def __init__(self, device: int = 0):
-        self._ctx = _Context(device, sort_algorithm=self.SORT_ALGORITHM)
+    def __init__(self, device: int = 0, count_launches: int = _lib.GS_COUNT_AUTO):
+        self._ctx = _Context(device, sort_algorithm=self.SORT_ALGORITHM, count_launches=count_launches)
         self.maxNumSortElements = 0
         self.radixSortNumSortBits = 0
 
@@ -381,10 +382,11 @@ class Renderer:
                  render_mode: int = _lib.GS_RENDER_EXACT, record_timings: bool = True,
                  warmup_frames: int | None = None, sort_algorithm: int = _lib.GS_SORT_RADIX4,
                  render_kernel: int = _lib.GS_RENDER_KERNEL_AUTO,
-                 tile_order: int = _lib.GS_TILE_ORDER_LONGEST_FIRST):
+                 tile_order: int = _lib.GS_TILE_ORDER_LONGEST_FIRST, count_launches: int = _lib.GS_COUNT_AUTO):
         self.width, self.height = int(width), int(height)   # swapchain extent (Engine.cpp:35)
         self._render_kernel = render_kernel
         self._tile_order = tile_order
+        self._count_launches = count_launches     # GS_COUNT_*: a Count launch per radix pass, or per sort (short lists)
         self._device, self._render_mode, self._record = device, render_mode, record_timings
         self._sort_algorithm = sort_algorithm   # GPU_SORT_ALGORITHM, Renderer.h:33
         self._ctx: _Context | None = None
@@ -403,7 +405,7 @@ class Renderer:
     def init(self, resourceManager: ResourceManager):
         self.resourceManager = resourceManager
         self._ctx = _Context(self._device, self._render_mode, self._record, self._sort_algorithm,
-                             self._render_kernel, self._tile_order)
+                             self._render_kernel, self._tile_order, self._count_launches)
 
     # -- Renderer.cpp:696-710
     def getNumTiles(self) -> int:
