@@ -309,7 +309,9 @@ int gs_dist_destroy(gs_ctx* ctx);
  * Collective safety: these calls pair with the other ranks' calls.  A rank that fails a PRECONDITION (no shard, rows changed
  * behind the library's back, a NULL rgba_out on rank 0, an allocation that failed in gs_dist_shard_rows) returns before the
  * exchange and its peers wait in theirs: check the status of gs_dist_shard_rows on every rank (e.g. exchange a flag over the
- * channel that carried the unique id) before the first frame.  A failure of the rank's own FRAME is collective-safe (above). */
+ * channel that carried the unique id) before the first frame.  A failure of the rank's own FRAME is collective-safe (above), and so
+ * is a HIP error of the calls around the exchange (the event / copy calls of gs_render_sharded_async and gs_dist_rebalance once
+ * the preconditions have passed): the rank still takes part in the exchange and reports its first error afterwards. */
 #define GS_ROWS_CONTIGUOUS 0u
 #define GS_ROWS_INTERLEAVED 1u
 #define GS_ROWS_BALANCED 2u

@@ -77,3 +77,25 @@ def test_two_rank_rehearsal(rows):
     d = _one_line(p.stdout)
     assert d["n_gpus"] == 2 and d["backend"] == "gloo" and d["sharded_image_matches_single_gpu"] is True and d["ms_per_step"] > 0
     assert rows in d["config"]["parallelism"] and sum(d["per_rank_sort_elements"]) == d["config"]["sort_elements"]
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two MI355X (RCCL wants one device per rank)")
+@pytest.mark.parametrize("rows", ["contiguous", "balanced"])
+def test_two_gpus_over_rccl(rows):
+    """--gpus 2 for real: one rank per device, strips gathered over RCCL, and the library's own exchange (`c_abi_gather`: gs_dist_init /
+    gs_render_sharded_async over the same communicator ids) -- both must assemble the one-GPU frame."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rows", rows, "--config", "A", "--steps", "10", "--warmup", "3", "--extras"],
+                       env=_env(), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _one_line(p.stdout)
+    assert d["n_gpus"] == 2 and d["backend"] == "nccl" and d["sharded_image_matches_single_gpu"] is True and d["ms_per_step"] > 0
+    assert sum(d["per_rank_sort_elements"]) == d["config"]["sort_elements"]
+    assert d["c_abi_gather"].get("assembled_frame_matches") is True, d["c_abi_gather"]

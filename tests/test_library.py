@@ -450,10 +450,13 @@ def test_partition_rule_is_one_rule_in_both_languages():
     rng = np.random.default_rng(0)
     for t in range(2000):
         ty, world = int(rng.integers(1, 140)), int(rng.integers(1, 9))
-        w = [rng.integers(0, 500000, ty).astype(np.float64), rng.random(ty), np.zeros(ty), np.where(rng.random(ty) < 0.1, 1e6, 1.0)][t % 4]
+        w = [rng.integers(0, 500000, ty).astype(np.float64), rng.random(ty), np.zeros(ty), np.where(rng.random(ty) < 0.1, 1e6, 1.0),
+             rng.normal(1.0, 2.0, ty)][t % 5]                 # the last: negative weights among positive ones -> equal rows, both sides
         e = (C.c_uint32 * (world + 1))()
         assert L.gs_balance_rows(w.ctypes.data_as(C.POINTER(C.c_double)), ty, world, e) == 0
-        assert [(e[k], e[k + 1]) for k in range(world)] == dist.balanced_row_partition(w, world), (ty, world, t % 4)
+        assert [(e[k], e[k + 1]) for k in range(world)] == dist.balanced_row_partition(w, world), (ty, world, t % 5)
+        if (w < 0).any():
+            assert dist.balanced_row_partition(w, world) == dist.balanced_row_partition(np.ones(ty), world)
     e = (C.c_uint32 * 3)()
     assert L.gs_balance_rows(None, 0, 2, e) == 0 and list(e) == [0, 0, 0]
     assert L.gs_balance_rows(None, 4, 2, e) == _lib.GS_ERR_INVALID and L.gs_balance_rows(None, 0, 0, e) == _lib.GS_ERR_INVALID

@@ -1013,6 +1013,38 @@ def test_cpp_host_several_ranks_over_a_mock_rccl(tmp_path, ranks, rows):
         assert len(vals) == ranks and all(v > 0.0 for v in vals), share
 
 
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()          # counting devices does not initialise the GPU in this process
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two MI355X: the exchange over a real RCCL (one GPU boxes run the mock above)")
+@pytest.mark.parametrize("rows", ["contiguous", "interleaved", "balanced", "contiguous-sync"])
+def test_cpp_host_two_devices_over_real_rccl(tmp_path, rows):
+    """csrc/gs_dist.cpp's exchange on TWO devices over the real librccl: what no one-GPU box can show -- the hand-declared RCCL
+    ABI against the library itself, band Recvs landing in place in the root's frame while the root renders its own band, the
+    gather on its own stream with two frames in flight, the R(R-1) send/recv group of gs_dist_rebalance.  The assembled frame must
+    be, byte for byte, the file one GPU writes alone.  (Until this test has run somewhere, every multi-GPU figure in README.md /
+    DESIGN.md is a one-GPU projection.)"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(_lib.LIB_PATH), "gsplat_bench")
+    base = ["--synthetic", "60000", "--res", "640x360", "--warmup", "2", "--frames", "6"]
+    if rows == "balanced":
+        base = ["--synthetic", "60000", "--skew", "--res", "640x360", "--warmup", "4", "--frames", "8"]
+    alone = str(tmp_path / "alone.ppm")
+    subprocess.run([exe] + base + ["--ppm", alone], check=True, capture_output=True, timeout=300)
+    out = str(tmp_path / "sharded.ppm")
+    env = {k: v for k, v in os.environ.items() if k not in ("GSPLAT_BENCH_SAME_DEVICE", "GS_RCCL_LIBRARY", "MOCK_RCCL_DIR")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    flags = {"interleaved": ["--interleaved"], "balanced": ["--balanced", "--rebalance", "2"], "contiguous-sync": ["--sync"]}.get(rows, [])
+    p = subprocess.run([exe] + base + ["--ppm", out, "--ranks", "2"] + flags, capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "ranks: 2" in p.stdout, (p.stdout[-500:], p.stderr[-2000:])
+    assert open(out, "rb").read() == open(alone, "rb").read()
+
+
 def test_cpp_host_leaves_when_a_rank_cannot_come_up(tmp_path):
     """A rank that fails before the communicator exists (here: rank 1 asks for a device that is not there) says so over the
     pipe it shares with rank 0; everybody leaves with a non-zero exit code instead of waiting in ncclCommInitRank."""

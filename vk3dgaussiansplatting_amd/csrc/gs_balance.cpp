@@ -17,9 +17,9 @@ std::vector<uint32_t> balanced_edges(const std::vector<double>& weights_in, uint
     if (ty == 0u) return edges;
     std::vector<double> w = weights_in;
     double total = 0.0;
-    bool finite = true;
-    for (double x : w) { total += x; finite = finite && std::isfinite(x); }
-    if (!finite || total <= 0.0) w.assign(ty, 1.0);
+    bool usable = true;       // finite and non-negative: a negative weight would make the prefix non-monotone (binary search below)
+    for (double x : w) { total += x; usable = usable && std::isfinite(x) && x >= 0.0; }
+    if (!usable || total <= 0.0) w.assign(ty, 1.0);
     std::vector<double> prefix(ty + 1u, 0.0);
     for (uint32_t k = 0; k < ty; ++k) prefix[k + 1u] = prefix[k] + w[k];
     for (uint32_t r = 1; r < world; ++r) {

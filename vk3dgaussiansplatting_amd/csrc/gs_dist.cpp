@@ -277,8 +277,9 @@ int gs_dist_shard_rows(gs_ctx* c, uint32_t dealing) {
         rc = gs_set_tile_rows_interleaved(c, r, R, 1u);
         if (rc == GS_OK) remember_rows(c);
     } else {
-        // GS_ROWS_BALANCED starts from equal row counts too (no frame has been seen yet); gs_dist_rebalance moves the edges
-        c->dist_edges = dealing == GS_ROWS_BALANCED ? gs::balanced_edges(std::vector<double>(c->grid_h, 1.0), R) : gs::equal_row_edges(c->grid_h, R);
+        // GS_ROWS_BALANCED starts from the same equal bands (no frame has been seen yet) -- ceil(Ty / R) rows each, what
+        // dist.RowBalancer starts from, so that the two balancers walk the same trajectory; gs_dist_rebalance moves the edges
+        c->dist_edges = gs::equal_row_edges(c->grid_h, R);
         rc = apply_band(c);
     }
     if (rc != GS_OK) return rc;
@@ -321,25 +322,30 @@ int gs_render_sharded_async(gs_ctx* c, const float view[16], const float proj[16
     const int slot = c->dist_next;
     const bool root = c->dist_rank == 0;
     // the slot's buffers were last touched by the gather of the frame before the previous one
-    if (c->dist_used[slot]) DIST_TRY(c, hipStreamWaitEvent(c->stream, c->dist_done[slot], 0));
-    DIST_TRY(c, hipEventRecord(c->dist_begin[slot], c->stream));
+    hipError_t before = hipSuccess;                 // see below: no return between check_sharded and the exchange
+    if (c->dist_used[slot]) before = hipStreamWaitEvent(c->stream, c->dist_done[slot], 0);
+    { const hipError_t e = hipEventRecord(c->dist_begin[slot], c->stream); if (before == hipSuccess) before = e; }
     uint8_t* target;
     if (c->dist_dealing == GS_ROWS_INTERLEAVED) target = static_cast<uint8_t*>(c->dist_strip[slot]);      // packed rows (compact_output)
     else if (root) target = static_cast<uint8_t*>(c->dist_image[slot]);                                   // in place, real rows
     else target = static_cast<uint8_t*>(c->dist_strip[slot]) - (size_t)c->row_begin * 16u * c->width * 4u;   // band at the top of the strip
     const int rc_render = c->rows_owned ? gs_render_device_async(c, view, proj, cam_pos, sh_mode, target) : GS_OK;
     // a rank whose frame failed still takes part in the exchange (with whatever its rows hold) -- leaving now would leave
-    // the other ranks waiting in theirs -- and reports its error afterwards
+    // the other ranks waiting in theirs -- and reports its error afterwards.  The same holds for the event calls around the
+    // exchange: from here on nothing returns before enqueue_gather has been called; the first HIP error is reported after it.
     const std::string render_error = rc_render < 0 ? c->last_error : std::string();
-    DIST_TRY(c, hipEventRecord(c->dist_rendered[slot], c->stream));
-    DIST_TRY(c, hipStreamWaitEvent(c->dist_stream, c->dist_rendered[slot], 0));
+    hipError_t first_hip = before;
+    auto note = [&](hipError_t e) { if (e != hipSuccess && first_hip == hipSuccess) first_hip = e; };
+    note(hipEventRecord(c->dist_rendered[slot], c->stream));
+    note(hipStreamWaitEvent(c->dist_stream, c->dist_rendered[slot], 0));
     const int rc_gather = enqueue_gather(c, slot, c->dist_stream);
-    DIST_TRY(c, hipEventRecord(c->dist_done[slot], c->dist_stream));
+    note(hipEventRecord(c->dist_done[slot], c->dist_stream));
     c->dist_used[slot] = true;
     c->dist_recent[1] = c->dist_recent[0];
     c->dist_recent[0] = slot;
     c->dist_next = slot ^ 1;
     if (rc_gather < 0) return rc_gather;
+    if (first_hip != hipSuccess) { (void)hipGetLastError(); return fail(c, GS_ERR_HIP, std::string("gs_render_sharded_async: ") + hipGetErrorString(first_hip)); }
     if (rc_render < 0) return fail(c, rc_render, render_error);
     return rc_render;
 }
@@ -394,13 +400,17 @@ int gs_dist_rebalance(gs_ctx* c, uint32_t* moved_out) {
     if (last < 0) return fail(c, GS_ERR_NO_SCENE, "gs_dist_rebalance: no sharded frame yet");
     Rccl& r = rccl();
     const uint32_t R = (uint32_t)c->dist_world, me = (uint32_t)c->dist_rank, ty = c->grid_h, words = ty + 1u;
-    DIST_TRY(c, hipSetDevice(c->device));
-    DIST_TRY(c, hipStreamSynchronize(c->stream));
-    DIST_TRY(c, hipStreamSynchronize(c->dist_stream));
+    // from here to the exchange nothing returns: a rank that left on a HIP error of its own would leave the others waiting in
+    // their Send / Recv group; the first such error is reported after the group
+    hipError_t first_hip = hipSuccess;
+    auto note = [&](hipError_t e) { if (e != hipSuccess && first_hip == hipSuccess) first_hip = e; };
+    note(hipSetDevice(c->device));
+    note(hipStreamSynchronize(c->stream));
+    note(hipStreamSynchronize(c->dist_stream));
     // this rank's contribution: the sort elements of each of its tile rows (the last frame's tile ranges) and the GPU time
     // of its share (events around the frame; the gather is not in it)
     std::vector<uint32_t> ranges((size_t)c->grid_w * ty * 2u);
-    DIST_TRY(c, hipMemcpy(ranges.data(), c->ranges, ranges.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    note(hipMemcpy(ranges.data(), c->ranges, ranges.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     std::vector<uint32_t> all((size_t)R * words, 0u);
     uint32_t* mine = &all[(size_t)me * words];
     for (uint32_t row = c->row_begin; row < c->row_end; ++row) {
@@ -416,7 +426,7 @@ int gs_dist_rebalance(gs_ctx* c, uint32_t* moved_out) {
     std::memcpy(&mine[ty], &ms, sizeof(ms));
     // all-gather as R (R - 1) small point-to-point transfers in one group (at most a few KB each)
     uint32_t* xchg = static_cast<uint32_t*>(c->dist_xchg);
-    DIST_TRY(c, hipMemcpy(xchg + (size_t)me * words, mine, words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    note(hipMemcpy(xchg + (size_t)me * words, mine, words * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (R > 1u) {
         RcclResult rc = r.GroupStart();
         for (uint32_t p = 0; p < R && rc == 0; ++p)
@@ -427,6 +437,7 @@ int gs_dist_rebalance(gs_ctx* c, uint32_t* moved_out) {
         if (rc == 0) rc = rc_end;
         if (rc != 0) return fail(c, GS_ERR_HIP, std::string("gs_dist_rebalance: ") + r.GetErrorString(rc));
     }
+    if (first_hip != hipSuccess) { (void)hipGetLastError(); return fail(c, GS_ERR_HIP, std::string("gs_dist_rebalance: ") + hipGetErrorString(first_hip)); }
     DIST_TRY(c, hipStreamSynchronize(c->stream));
     DIST_TRY(c, hipMemcpy(all.data(), xchg, all.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     // dist.py: RowBalancer.update, statement for statement.  T_r = F + sum of weight(row): F = the intercept of the

@@ -35,7 +35,7 @@ def balanced_row_partition(row_weights, world_size: int) -> List[Tuple[int, int]
     tiles_y = int(wts.shape[0])
     if tiles_y == 0:
         return [(0, 0)] * world_size
-    if not np.isfinite(wts).all() or wts.sum() <= 0.0:
+    if not np.isfinite(wts).all() or (wts < 0.0).any() or wts.sum() <= 0.0:   # a negative weight: prefix not monotone
         wts = np.ones(tiles_y)
     prefix = np.concatenate([[0.0], np.cumsum(wts)])          # prefix[k] = weight of rows [0, k)
     edges = [0]
