@@ -206,5 +206,7 @@ def test_gpu_suite_log_is_of_this_tree():
     m = re.search(r"src_sha256=([0-9a-f]{64})", text)
     assert m, "the log carries no source hash"
     assert m.group(1) == src_hash.source_hash(), "sources changed after the GPU suite ran: run tools/gpu_suite.sh again"
-    tail = re.search(r"(\d+) passed, (\d+) deselected", text)
-    assert tail and int(tail.group(1)) >= 191 and " failed" not in text and " error" not in text.lower().replace("errors='", "")
+    tail = re.search(r"^(\d+) passed(?:, (\d+) skipped)?, \d+ deselected in ", text, re.M)
+    assert tail and int(tail.group(1)) >= 191 and " failed" not in text and " error" not in text.lower()
+    # what may be skipped on a one-GPU box: the tests that want two devices (the exchange over the real RCCL), nothing else
+    assert int(tail.group(2) or 0) <= 6
