@@ -1,4 +1,4 @@
-"""The committed measurements must be recomputable: the bench line of the round (profiles/r05_bench_configC.json) against
+"""The committed measurements must be recomputable: the bench line of the round (profiles/r06_bench_configC.json) against
 the profile files collected separately with rocprofv3 (kernel stats, PMC traffic), and its derived figures against its
 own inputs.  No GPU, no oracle."""
 import json
@@ -9,7 +9,8 @@ import pytest
 
 from conftest import ROOT
 
-P = os.path.join(ROOT, "profiles", "r05_")
+P = os.path.join(ROOT, "profiles", "r06_")
+P5 = os.path.join(ROOT, "profiles", "r05_")      # what round 6 did not re-measure (same kernels): the pose study, the capture-like cloud's rank costs
 HBM_PEAK = 8000.0
 
 
@@ -61,7 +62,7 @@ def test_dominant_kernel_roofline_recomputes(line):
     # rocprofv3 --kernel-trace --stats of the same command: mean duration of the eight depth-word Scatter launches
     per = {}
     for ln in open(P + "bench_configC_kernel_stats.txt"):
-        m = re.match(r"void gs::k_scatter<(\d), (\d), true>.*calls=\s*(\d+) avg_us=\s*([\d.]+)", ln)
+        m = re.match(r"void gs::k_scatter<(\d), (\d), true, false>.*calls=\s*(\d+) avg_us=\s*([\d.]+)", ln)
         if m:
             per[(int(m.group(1)), int(m.group(2)))] = float(m.group(4))
     mean_us = (3 * per[(4, 4)] + per[(4, 2)] + 3 * per[(2, 2)] + per[(2, 0)]) / 8
@@ -133,7 +134,7 @@ def test_benchmark_pose_block_and_its_kernel_table(line):
     assert bp["vs_baseline"] == pytest.approx(28.499 / bp["ms_per_step"], rel=2e-3)
     assert abs(bp["depth_scatter"]["frac"] - line["roofline"]["moved"]["frac_of_peak"]) < 0.03
     rows = {}
-    for ln in open(P + "pose_study_configC.txt"):
+    for ln in open(P5 + "pose_study_configC.txt"):
         m = re.match(r"(k_\S+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+) \|\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)", ln)
         if m and float(m.group(2)) >= 1.0:                                  # the frame's kernels (>= one launch per frame)
             rows[m.group(1)] = [float(x) for x in m.groups()[1:]]
@@ -142,14 +143,14 @@ def test_benchmark_pose_block_and_its_kernel_table(line):
         assert 0.93 < us_pose / us_own < 1.12, k                            # k_emit is the outlier (+ 8 %)
         assert abs(rd1 - rd0) <= 0.02 * max(rd0, 1.0) + 0.2 and abs(wr1 - wr0) <= 0.02 * max(wr0, 1.0) + 0.2, k    # no extra traffic
     # the posed frame's own tables in the formats of the other profiles
-    txt = open(P + "bench_configC_garden_pose_kernel_stats.txt").read()
+    txt = open(P5 + "bench_configC_garden_pose_kernel_stats.txt").read()
     assert "k_project<true>" in txt and "k_render_wg" in txt
-    assert "k_scatter<4, 4, true>" in open(P + "pmc_frame_traffic_configC_garden_pose.txt").read()
+    assert "k_scatter<4, 4, true>" in open(P5 + "pmc_frame_traffic_configC_garden_pose.txt").read()
 
 
 def _rank_costs(tag):
     rows, one = {}, None
-    for ln in open(P + f"rank_costs_{tag}.txt"):
+    for ln in open((P if tag in ("C_radix4", "D_radix4") else P5) + f"rank_costs_{tag}.txt"):
         m = re.match(r"config \S+ pose \S+ \S+ sorter \S+: one GPU ([\d.]+) ms", ln)
         if m:
             one = float(m.group(1))
@@ -183,7 +184,7 @@ def test_pose_sweep_is_flat():
     """tools/pose_sweep.sh: both clouds under the generator's own camera and the reference's three benchmark poses -- the frame time
     does not depend on how the stored order lies relative to the screen."""
     rows = {}
-    for ln in open(P + "pose_sweep.txt"):
+    for ln in open(P5 + "pose_sweep.txt"):
         m = re.match(r"config (\S+)\s+pose (\S+)\s*: frame ([\d.]+) ms\s+E (\d+)", ln)
         if m:
             rows[(m.group(1), m.group(2))] = (float(m.group(3)), int(m.group(4)))
