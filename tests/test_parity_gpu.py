@@ -700,8 +700,13 @@ def full_size_parity(oracle_mod, name, sorts, capacity, sort_bits, pixel_tile_ro
                                         row_begin=tr, row_end=tr + 1)
             oracle_mod.render(pb, aos, s1["color"], s1["cov"], oi, oranges, out=ref_img, threads=threads)
         row_sel = np.concatenate([np.arange(tr * 16, min(tr * 16 + 16, h)) for tr in pixel_tile_rows])
-    for sort in sorts:
-        r = make_renderer(sc, w, h, sort=sort)
+    # the contractual sorter once more with fed counts forced (gs_config.count_launches: GS_COUNT_AUTO would choose them only
+    # for lists of up to 1.8 M elements): lists of up to 8 M elements, i.e. thousands of count rows per prologue
+    runs = [(sort, gs.GS_COUNT_AUTO) for sort in sorts]
+    if gs.GS_SORT_RADIX4 in sorts and e <= 8_000_000:
+        runs.append((gs.GS_SORT_RADIX4, gs.GS_COUNT_FED))
+    for sort, count in runs:
+        r = make_renderer(sc, w, h, sort=sort, count=count)
         img = r.draw(sc)
         info, t = r.sceneInfo(), r.timings()
         assert info.capacity == capacity and info.num_sort_bits == sort_bits
@@ -716,7 +721,7 @@ def full_size_parity(oracle_mod, name, sorts, capacity, sort_bits, pixel_tile_ro
         lens = ranges[:, 1].astype(np.int64) - ranges[:, 0]
         assert lens.sum() == e and np.all(lens >= 0)        # ranges partition [0, E)
         assert np.array_equal(np.bincount(tile, minlength=ranges.shape[0]), lens)
-        assert np.array_equal(img[row_sel], ref_img[row_sel]), f"pixels differ (sorter {sort})"
+        assert np.array_equal(img[row_sel], ref_img[row_sel]), f"pixels differ (sorter {sort}, count launches {count})"
         assert np.all(img[..., 3] == 255)
         r.cleanup()
         del tile, ranges, img
@@ -741,6 +746,7 @@ def full_size_parity(oracle_mod, name, sorts, capacity, sort_bits, pixel_tile_ro
         else:
             rows = np.asarray(gsdist.interleaved_rows(gh, rank, world))
             r.setTileRowsInterleaved(rank, world, compact_output=False)
+        r.draw(sc)                     # GS_COUNT_AUTO learns the share's length from this frame: the one compared is fed if it is short
         img = r.draw(sc)
         mine = np.isin(ot[:e] // gw, rows)
         assert r.timings().num_sort_elements == int(mine.sum())
@@ -1625,17 +1631,22 @@ def test_randomized_frames(oracle_mod):
         kernel = kernels[int(rng.integers(0, len(kernels)))]
         sc = make_scene(aos, w, h, pos=pos, yaw=yaw, pitch=pitch, sh_mode=sh_mode)
         order = gs.GS_TILE_ORDER_RASTER if case % 4 == 3 else gs.GS_TILE_ORDER_LONGEST_FIRST
-        r = make_renderer(sc, w, h, sort=sort, kernel=kernel, order=order)
+        # gs_config.count_launches rotates with the case (not drawn from rng: the cases of earlier rounds stay what they were); every
+        # frame is drawn twice, so that GS_COUNT_AUTO sorts the one that is compared knowing the length of the one before: fed
+        count = (gs.GS_COUNT_AUTO, gs.GS_COUNT_PER_PASS, gs.GS_COUNT_FED)[case % 3]
+        r = make_renderer(sc, w, h, sort=sort, kernel=kernel, order=order, count=count)
         gh = r.sceneInfo().tiles_y
         share = rng.random()
-        what = f"case {case}: n={n} {w}x{h} mu={mu:.2f} sh={sh_mode} sort={sort} kernel={kernel} order={order}"
+        what = f"case {case}: n={n} {w}x{h} mu={mu:.2f} sh={sh_mode} sort={sort} kernel={kernel} order={order} count={count}"
         if share < 0.5 or gh < 2:
+            r.draw(sc)
             img = r.draw(sc)
             _, ref = oracle_run(oracle_mod, sc, w, h)
             assert_frame_equals_oracle(r, img, ref)
         elif share < 0.8:
             rb = int(rng.integers(0, gh)); re = int(rng.integers(rb + 1, gh + 1))
             r.setTileRows(rb, re)
+            r.draw(sc)
             img = r.draw(sc)
             _, band = oracle_run(oracle_mod, sc, w, h, row_begin=rb, row_end=re)
             e = band["e"]
@@ -1648,6 +1659,7 @@ def test_randomized_frames(oracle_mod):
         else:
             world = int(rng.integers(2, 5)); rank = int(rng.integers(0, world))
             r.setTileRowsInterleaved(rank, world)
+            r.draw(sc)
             img = r.draw(sc)
             _, ref = oracle_run(oracle_mod, sc, w, h)
             e, gw = ref["e"], r.sceneInfo().tiles_x
