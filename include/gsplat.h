@@ -87,7 +87,7 @@ typedef struct gs_ctx gs_ctx;
  * SORT with every Scatter launch counting the next pass's digits of the keys it stores ("fed" counts: for short lists -- a
  * tile-row band of a multi-GPU frame, a small frame -- where a pass is two fixed launch latencies and little else).  Same
  * sorted list either way. */
-#define GS_COUNT_AUTO 0u      /* fed when a recent frame held at most 896 groups of 2048 elements = 1.8 M (default) */
+#define GS_COUNT_AUTO 0u      /* fed when a recent frame held at most 1024 groups of 2048 elements = 2.1 M (default) */
 #define GS_COUNT_PER_PASS 1u  /* always a Count launch per pass */
 #define GS_COUNT_FED 2u       /* always fed (correct at every size; slow for long lists) */
 

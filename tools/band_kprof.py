@@ -13,7 +13,8 @@ aos = synth.generate_config(name)[0]
 w, h = cfg["width"], cfg["height"]
 rm = gs.ResourceManager(); rm.setGaussians(aos)
 sc = gs.Scene(rm, aspect_ratio=w / h); cam = sc.getCamera(); cam.setPosition((0, 0, 0)); cam.setRotation(0, 0); cam.recalculate()
-r = gs.Renderer(w, h, record_timings=0, warmup_frames=0); r.init(rm); r.initForScene(sc)
+count = {"per_pass": gs.GS_COUNT_PER_PASS, "fed": gs.GS_COUNT_FED}.get(os.environ.get("GS_COUNT", ""), gs.GS_COUNT_AUTO)   # gs_config.count_launches
+r = gs.Renderer(w, h, record_timings=0, warmup_frames=0, count_launches=count); r.init(rm); r.initForScene(sc)
 bands = dist.tile_row_partition((h + 15) // 16, R)
 if inter: r.setTileRowsInterleaved(R // 2, R, False)
 else: r.setTileRows(*bands[R // 2])

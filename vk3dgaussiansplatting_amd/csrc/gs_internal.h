@@ -28,7 +28,7 @@ constexpr int kMaxSortPasses = 16;            // 64 key bits / 4
 // Fed counts (gs_sort.hip, k_scatter<.., FED>): lists of at most this many groups may sort without per-pass Count
 // launches -- every Scatter workgroup then sums the count rows of all groups itself (G x 64 bytes out of L2).
 #ifndef GS_FED_MAX_GROUPS
-#define GS_FED_MAX_GROUPS 896     /* measured on MI355X (profiles/r06_fed_probe.txt): fed wins below ~900 groups, by more the shorter the list */
+#define GS_FED_MAX_GROUPS 1024    /* measured on MI355X (profiles/r06_fed_probe.txt): fed wins below ~1100 groups, by more the shorter the list */
 #endif
 constexpr uint32_t kFedMaxGroups = GS_FED_MAX_GROUPS;
 

@@ -329,9 +329,9 @@ __device__ __forceinline__ void scatter_group(
     //      digit; DPP scan inside the row, lane 15 of the row holds the sums) -> LDS, read after barrier 1
     if constexpr (FED) {
         uint4 fa = make_uint4(0u, 0u, 0u, 0u), fb = make_uint4(0u, 0u, 0u, 0u);    // all groups / the groups ahead of this one
-        auto take = [&](const uint4& v, uint32_t r) {
-            fa.x += v.x; fa.y += v.y; fa.z += v.z; fa.w += v.w;
-            if (r < grp) { fb.x += v.x; fb.y += v.y; fb.z += v.z; fb.w += v.w; }
+        auto take = [&](const uint4& v, uint32_t r) {     // a thread's rows come in ascending order: the sum ahead of the group is a
+            fa.x += v.x; fa.y += v.y; fa.z += v.z; fa.w += v.w;   // snapshot of the running sum, taken as long as the row lies ahead
+            if (r < grp) fb = fa;
         };
 #pragma unroll
         for (int k = 0; k < kFedBatch; ++k) take(fv[k], ((uint32_t)tid >> 2) + 64u * (uint32_t)k);
@@ -467,14 +467,25 @@ __device__ __forceinline__ void scatter_group(
             if constexpr (HI16) reinterpret_cast<uint16_t*>(out_hi)[o] = (uint16_t)h;
             else out_hi[o] = h;
             out_id[o] = sl.x;
-            if constexpr (FED) {
-                if (seg_sum) {   // not the last pass: the key's NEXT digit, counted under (run, destination group)
-                    const uint32_t ns = shift + (uint32_t)kRadixBits;
-                    const uint32_t nd = ns >= 32u ? digit_of(h, ns - 32u) : digit_of(l, LO_IN == 2 ? ns - 16u : ns);
-                    const uint32_t j = (o >> kSortTileLog2) - (s_first[d] >> kSortTileLog2);          // 0 or 1
-                    (void)__hip_atomic_fetch_add(&s_next[((d * 2u + j) << kRadixBits) | nd], 1u, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+        }
+        if constexpr (FED) {
+            if (seg_sum) {   // not the last pass: the key's NEXT digit, counted under (run, destination group)
+                // Lanes hold consecutive sorted positions, and in the depth passes the elements of one splat lie side by side
+                // with one depth word: neighbouring lanes want the same counter (64 lanes on one LDS address serialise).  So
+                // equal neighbours are added once: a lane whose counter differs from its left neighbour's (inside its row of
+                // 16 lanes) heads a run and adds the run's length -- the distance to the next head in the ballot.
+                const uint32_t ns = shift + (uint32_t)kRadixBits;
+                const uint32_t nd = ns >= 32u ? digit_of(h, ns - 32u) : digit_of(l, LO_IN == 2 ? ns - 16u : ns);
+                const uint32_t j = (o >> kSortTileLog2) - (s_first[d] >> kSortTileLog2);          // 0 or 1 for a stored element
+                const bool stored = FULL || p < valid;
+                const uint32_t ctr = stored ? (((d * 2u + j) << kRadixBits) | nd) : 0xFFFFFFFFu;
+                const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)ctr, 0x111, 0xf, 0xf, false);   // row_shr:1
+                const bool head = ctr != left;
+                const uint64_t heads = __ballot(head);
+                const uint64_t after = lane == 63 ? 0ull : heads >> (lane + 1);
+                const uint32_t len = after ? (uint32_t)__builtin_ctzll(after) + 1u : 64u - (uint32_t)lane;
+                if (head && stored)
+                    (void)__hip_atomic_fetch_add(&s_next[ctr], len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
