@@ -17,6 +17,8 @@
 //                       of ScanAdd); there is no Scan launch.
 //              Scatter: one 256-thread workgroup per group (5-6 resident per CU): wave64 match-mask ranking (stable),
 //                       LDS-staged local sort, run-wise coalesced stores (RadixSortScatter.comp:58-171).
+// Short lists (at most kFedMaxGroups groups; gs_config.count_launches) sort with ONE k_count launch: every Scatter counts the next
+// pass's digit of the keys it stores and feeds the next pass's per-group count rows (k_scatter<.., FED>, "fed counts").
 // Inside a frame the words are narrower than the reference's: 16-bit compact tile ids when they fit, and depth words
 // that shrink as their digits are consumed (see k_scatter); the stand-alone sorter (gs_sort_host) always moves three
 // 32-bit words.  Output is bit-identical to a stable sort by the low num_sort_bits of the key.
@@ -47,9 +49,21 @@ constexpr int kSortWaves = kSortThreads / 64;
 // widened into 16-bit fields and summed over the wave with DPP adds; no LDS atomics.
 // W16: the word the digit lives in is stored as 16 bits (tile ids of a frame; the upper depth half in passes 4-7).
 // ---------------------------------------------------------------------------------------------
+// inclusive prefix sum inside each row of 16 lanes (DPP row_shr 1/2/4/8; lanes shifted in from outside the row add 0)
+__device__ __forceinline__ uint32_t row16_inclusive_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);   // row_shr:8
+    return v;
+}
+
 constexpr int kCountKeysPerLane = kSortTile / 64;   // 32
 constexpr int kCountMaxK = 128;                     // groups per segment whose counts are kept in LDS (8 KB)
-constexpr int kCountWaves = 8;                      // waves of a Count workgroup = groups of the segment counted side by side
+#ifndef GS_COUNT_WAVES
+#define GS_COUNT_WAVES 8
+#endif
+constexpr int kCountWaves = GS_COUNT_WAVES;         // waves of a Count workgroup = groups of the segment counted side by side
                                                     // (8 measured 1.6 % better than 4 on config C's sort, 16 no better)
 constexpr int kCountThreads = kCountWaves * 64;
 static_assert(kCountKeysPerLane % 8 == 0, "k_count consumes the group in chunks of 8 keys per lane");
@@ -177,18 +191,39 @@ __global__ __launch_bounds__(kCountThreads) void k_count(const SortParams* __res
     // ScanAdd inside the segment (RadixSortScanAdd.comp:34-66), here rather than in every Scatter workgroup: the table
     // gets, per group and digit, the number of keys of that digit in the EARLIER groups of the segment (bin-major,
     // RadixSortCount.comp:89); the segment totals go to the reduce buffer (RadixSortReduce.comp:34-72).
-    if (tid < kBins) {
-        const uint32_t n_grp = grp_end > grp0 ? grp_end - grp0 : 0u;
+    const uint32_t n_grp = grp_end > grp0 ? grp_end - grp0 : 0u;
+    if (n_grp <= (uint32_t)kCountMaxK) {
+        // every list below 268 M elements: a row of 16 lanes per digit scans the segment's groups sixteen at a time (DPP
+        // row scan + the carry of the chunks before) -- four steps where one thread per digit used to walk K groups, one
+        // LDS round trip each (K = 13 at config C, 32 at D, 58 at E)
+        if (tid < kBins * 16) {
+            const uint32_t d = (uint32_t)tid >> 4, jj = (uint32_t)tid & 15u;
+            uint32_t carry = 0;
+            for (uint32_t cb = 0; cb < n_grp; cb += 16u) {           // workgroup-uniform trip count
+                const uint32_t j = cb + jj;
+                const uint32_t t = j < n_grp ? s_hist[j][d] : 0u;
+                const uint32_t inc = row16_inclusive_scan(t);
+                if (j < n_grp) table[d * G + grp0 + j] = carry + inc - t;
+                carry += (uint32_t)__shfl((int)inc, (lane & ~15) | 15, 64);     // the chunk's total: lane 15 of the row
+            }
+            if (jj == 0u) {
+                seg_sum[d * kSegments + blockIdx.x] = carry;   // zero for empty segments
+                // Reduce, second level: kCoarse coarse segments of kSegments / kCoarse segments each, summed with one
+                // agent-scope atomic add per digit and workgroup (no return value, nothing waits for it; the launch boundary
+                // publishes it).  Scatter's prologue scans these 16 x kCoarse totals itself -- there is no Scan launch.
+                if (carry != 0u)
+                    (void)__hip_atomic_fetch_add(&coarse[d * kCoarse + blockIdx.x / (kSegments / kCoarse)], carry,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    } else if (tid < kBins) {        // segments of more than kCountMaxK groups: the counts beyond lie in the table itself
         uint32_t run = 0;
         for (uint32_t j = 0; j < n_grp; ++j) {
             const uint32_t t = j < (uint32_t)kCountMaxK ? s_hist[j][tid] : table[tid * G + grp0 + j];
             table[tid * G + grp0 + j] = run;
             run += t;
         }
-        seg_sum[tid * kSegments + blockIdx.x] = run;   // zero for empty segments
-        // Reduce, second level: kCoarse coarse segments of kSegments / kCoarse segments each, summed with one
-        // agent-scope atomic add per digit and workgroup (no return value, nothing waits for it; the launch boundary
-        // publishes it).  Scatter's prologue scans these 16 x kCoarse totals itself -- there is no Scan launch.
+        seg_sum[tid * kSegments + blockIdx.x] = run;
         if (run != 0u)
             (void)__hip_atomic_fetch_add(&coarse[tid * kCoarse + blockIdx.x / (kSegments / kCoarse)], run,
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -226,14 +261,6 @@ constexpr uint32_t kSortTileLog2 = 11;
 static_assert((1u << kSortTileLog2) == (uint32_t)kSortTile, "destination group of an element = index >> kSortTileLog2");
 __device__ __forceinline__ void fed_zero_row(uint32_t* rows, uint32_t grp, int d) { rows[grp * kBins + d] = 0u; }
 
-// inclusive prefix sum inside each row of 16 lanes (DPP row_shr 1/2/4/8; lanes shifted in from outside the row add 0)
-__device__ __forceinline__ uint32_t row16_inclusive_scan(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);   // row_shr:8
-    return v;
-}
 
 // LO_IN / LO_OUT = bytes of the depth word read / written per element (4, 2 or 0).  The stand-alone sorter
 // (gs_sort_host) and GS_SORT_TILE_BUCKET use <4, 4>: everything moves.  In a frame the depth word is needed only as a
@@ -252,7 +279,7 @@ __device__ __forceinline__ uint32_t row16_inclusive_scan(uint32_t v) {
 // sums S groups would take 16 S requests per line).  The prologue of pass p + 1 therefore sums the rows of ALL groups
 // itself (those ahead of its own for the prefix, all of them for the digit totals): G x 64 bytes per workgroup out of
 // L2, affordable for lists of up to ~1000 groups (a tile-row band of a multi-GPU frame, config A), where a Count launch
-// is one fixed ~8 us latency chain per pass.  Three row sets rotate: pass p reads set p % 3, adds into (p + 1) % 3 and
+// is one fixed ~6-8 us latency chain per pass (profiles/r06_fed_probe.txt, r06_fed_kernels_band8_configC.txt).  Three row sets rotate: pass p reads set p % 3, adds into (p + 1) % 3 and
 // clears its own row of (p + 2) % 3; pass 0's rows come from k_count (one launch per sort instead of one per pass).
 // In this mode the kernel's `table` argument is the row set read, `seg_sum` the set added into (null in the last
 // pass) and `coarse` the set cleared.
